@@ -1,0 +1,327 @@
+"""GPU parity tests: every plugin of the hot path through the C-ABI (include/tllm_plugin_api.h) against the
+CPU oracle (oracle/llama_oracle.py) on the same seeded inputs.  Integer paths bit-exact; fp16 paths within the
+tolerances the reference's own tests state, written next to each assert.
+
+Shapes/seeds follow the reference tests where they exist:
+  T/tests/quantization/test_smooth_quant_gemm.py:20-41,104-121   (M=32, K=768, N in {2304, 3072}, scales k*1e-2)
+  T/tests/quantization/test_weight_only_quant_matmul.py:112-119  ((1,1024,4096), (128,6144,12288))
+  T/tests/quantization/test_functional.py:48-50,146-155          (quantisers, exact)
+  T/tests/attention/test_gpt_attention.py:30-73                   (llama attention: H=4, Dh in {32,64,128})
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import HostTensor, as_f32, f32, h, i8, i32, make_plugin, run_plugin
+from oracle import llama_oracle as O
+from tensorrt_llm.plugin import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def rng(seed):
+    return np.random.default_rng(seed)
+
+
+# ---------------------------------------------------------------------------------------------- quantisers
+@pytest.mark.parametrize('dtype', ['float16', 'float32'])
+def test_quantize_tensor_exact(dtype):
+    r = rng(0)
+    x = r.standard_normal((4, 33, 256)).astype(np.float32) * 50
+    # ties (x.5), saturation and NaN edge cases (SURVEY §8c golden list)
+    x.reshape(-1)[:12] = [0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 127.5, -128.5, 200, -200, 126.5, np.nan]
+    scale = np.float32(1.0)
+    if dtype == 'float16':
+        xt = h(x)
+        xin = as_f32(xt)
+    else:
+        xt = torch.from_numpy(x).cuda()
+        xin = x
+    out = torch.empty(x.shape, dtype=torch.int8, device='cuda')
+    p = make_plugin('QuantizeTensor', [])
+    run_plugin(p, [xt, torch.tensor([[scale]], device='cuda')], [out])
+    np.testing.assert_array_equal(out.cpu().numpy(), O.quantize_tensor(xin, scale))
+    # reference test scale (test_functional.py:48: 0.01-ish scales)
+    scale = np.float32(0.37)
+    run_plugin(p, [xt, torch.tensor([[scale]], device='cuda')], [out])
+    np.testing.assert_array_equal(out.cpu().numpy(), O.quantize_tensor(xin, scale))
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'float32'])
+@pytest.mark.parametrize('shape', [(1, 4096), (7, 11008), (3, 5, 130)])
+def test_quantize_per_token_exact(dtype, shape):
+    r = rng(1)
+    x = r.standard_normal(shape).astype(np.float32) * 3
+    x[0, ..., :] *= 0  # an all-zero row exercises the 1e-6 amax floor
+    if dtype == 'float16':
+        xt = h(x)
+        xin = as_f32(xt)
+    else:
+        xt = torch.from_numpy(x).cuda()
+        xin = x
+    q = torch.empty(shape, dtype=torch.int8, device='cuda')
+    s = torch.empty(shape[:-1] + (1, ), dtype=torch.float32, device='cuda')
+    run_plugin(make_plugin('QuantizePerToken', []), [xt], [q, s])
+    qo, so = O.quantize_per_token(xin, is_half=dtype == 'float16')
+    np.testing.assert_array_equal(s.cpu().numpy(), so)
+    np.testing.assert_array_equal(q.cpu().numpy(), qo)
+
+
+# ---------------------------------------------------------------------------------------------- RMSNorm
+@pytest.mark.parametrize('shape', [(1, 4096), (5, 64), (2, 3, 11008)])
+def test_rmsnorm(shape):
+    r = rng(2)
+    x = h(r.standard_normal(shape) * 2)
+    g = h(1 + 0.1 * r.uniform(-1, 1, shape[-1]))
+    y = torch.empty_like(x)
+    p = make_plugin('Rmsnorm', [('eps', f32(1e-6)), ('type_id', i32([capi.HALF]))])
+    run_plugin(p, [x, g], [y])
+    ref = O.rmsnorm(as_f32(x), as_f32(g), 1e-6)
+    # fp32 statistics differ only by summation order: at most 1 fp16 ulp on the output
+    np.testing.assert_allclose(as_f32(y), ref, rtol=2e-3, atol=1e-5)
+    assert np.mean(as_f32(y) == ref) > 0.99
+
+
+@pytest.mark.parametrize('dyn', [0, 1])
+def test_rmsnorm_quantization(dyn):
+    r = rng(3)
+    shape = (6, 4096)
+    x = h(r.standard_normal(shape) * 2)
+    g = h(1 + 0.1 * r.uniform(-1, 1, shape[-1]))
+    scale = torch.tensor([23.5], dtype=torch.float32, device='cuda')
+    q = torch.empty(shape, dtype=torch.int8, device='cuda')
+    outs = [q]
+    if dyn:
+        s = torch.empty((6, 1), dtype=torch.float32, device='cuda')
+        outs.append(s)
+    p = make_plugin('RmsnormQuantization', [('eps', f32(1e-6)), ('dyn_act_scaling', i32([dyn])),
+                                            ('type_id', i32([capi.HALF]))])
+    run_plugin(p, [x, g, scale], outs)
+    qo, so = O.rmsnorm_quant(as_f32(x), as_f32(g), 1e-6, None if dyn else 23.5)
+    # +-1 LSB, the reference's own bound for LayerNorm+quant (test_smooth_quant_layer_norm.py:103-108)
+    d = np.abs(q.cpu().numpy().astype(np.int32) - qo.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d == 0) > 0.99
+    if dyn:
+        np.testing.assert_allclose(s.cpu().numpy(), so, rtol=1e-2)  # test_smooth_quant_layer_norm.py:110-114
+
+
+def test_swiglu():
+    r = rng(4)
+    a, b = h(r.standard_normal((3, 11008)) * 3), h(r.standard_normal((3, 11008)))
+    y = torch.empty_like(a)
+    run_plugin(make_plugin('SwiGLU', [('type_id', i32([capi.HALF]))]), [a, b], [y])
+    np.testing.assert_allclose(as_f32(y), O.swiglu(as_f32(a), as_f32(b)), rtol=2e-3, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------- SmoothQuant GEMM
+@pytest.mark.parametrize('out_dtype', ['float16', 'float32', 'int32'])
+@pytest.mark.parametrize('per_token,per_channel', [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize('m,n,k', [(32, 2304, 768), (1, 4096, 4096), (5, 3072, 768)])
+def test_smooth_quant_gemm_exact(out_dtype, per_token, per_channel, m, n, k):
+    torch.manual_seed(0)
+    a = torch.randint(-128, 128, (m, k), dtype=torch.int8)
+    w = torch.randint(-128, 128, (n, k), dtype=torch.int8)
+    sa = (torch.randint(1, 13, (m if per_token else 1, 1)).float() * 1e-2)  # scales k * 1e-2
+    sb = (torch.randint(1, 13, (1, n if per_channel else 1)).float() * 1e-2)
+    tcode = {'float16': capi.HALF, 'float32': capi.FLOAT, 'int32': capi.INT32}[out_dtype]
+    tdt = {'float16': torch.float16, 'float32': torch.float32, 'int32': torch.int32}[out_dtype]
+    p = make_plugin('SmoothQuantGemm', [('has_per_channel_scaling', i32(per_channel)),
+                                        ('has_per_token_scaling', i32(per_token)), ('type_id', i32([tcode]))])
+    out = torch.empty((m, n), dtype=tdt, device='cuda')
+    run_plugin(p, [a.cuda(), w.cuda(), sa.cuda(), sb.cuda()], [out])
+    ref = O.sq_gemm(a.numpy(), w.numpy(), sa.numpy(), sb.numpy(), out_dtype)
+    got = out.cpu().numpy() if out_dtype == 'int32' else as_f32(out)
+    np.testing.assert_array_equal(got, ref)  # exact (test_smooth_quant_gemm.py:102)
+
+
+def test_smooth_quant_gemm_fp32_view_weight():
+    """The reference smuggles int8 weights through an fp32 port [N, K/4] (PY/quantization/layer.py:91-99)."""
+    torch.manual_seed(1)
+    m, n, k = 4, 256, 512
+    a = torch.randint(-128, 128, (m, k), dtype=torch.int8)
+    w = torch.randint(-128, 128, (n, k), dtype=torch.int8)
+    sa, sb = torch.full((1, 1), 0.03), torch.full((1, 1), 0.05)
+    p = make_plugin('SmoothQuantGemm', [('has_per_channel_scaling', i32(0)), ('has_per_token_scaling', i32(0)),
+                                        ('type_id', i32([capi.HALF]))])
+    out = torch.empty((m, n), dtype=torch.float16, device='cuda')
+    wv = w.cuda().view(torch.float32)
+    assert list(wv.shape) == [n, k // 4]
+    run_plugin(p, [a.cuda(), wv, sa.cuda(), sb.cuda()], [out])
+    np.testing.assert_array_equal(as_f32(out), O.sq_gemm(a.numpy(), w.numpy(), sa.numpy(), sb.numpy()))
+
+
+# ---------------------------------------------------------------------------------------------- weight-only
+@pytest.mark.parametrize('bits', [8, 4])
+@pytest.mark.parametrize('m,n,k', [(1, 1024, 4096), (3, 4096, 4096), (1, 4096, 11008), (24, 512, 1024)])
+def test_weight_only_quant_matmul(bits, m, n, k):
+    torch.manual_seed(0)
+    w = (torch.rand(k, n) * 2 - 1).half()  # [in, out], as the loaders pass it
+    x = (torch.rand(m, k) * 2 - 1).half()
+    processed, scales, unprocessed = capi.symmetric_quantize_last_axis(w.numpy(), bits)
+    q_ref, s_ref = O.woq_quantize(w.float().numpy(), bits)
+    # quantiser parity (host path): scales and integers exact
+    np.testing.assert_array_equal(scales.astype(np.float32), s_ref)
+    if bits == 8:
+        np.testing.assert_array_equal(unprocessed, q_ref)
+    else:
+        np.testing.assert_array_equal(unprocessed, O.pack_int4_kn(q_ref))
+    p = make_plugin('WeightOnlyQuantMatmul', [('type_id', i32([capi.HALF])), ('weight_type_id', i32(1 if bits == 8 else 2))])
+    wt = torch.from_numpy(processed).cuda().view(torch.float32).reshape(k, -1)  # fp32 view [K, N/4 | N/8]
+    assert wt.shape[1] == n // (4 if bits == 8 else 8)
+    out = torch.empty((m, n), dtype=torch.float16, device='cuda')
+    run_plugin(p, [x.cuda(), wt, torch.from_numpy(scales).cuda()], [out])
+    ref = O.woq_matmul(x.float().numpy(), q_ref, s_ref)
+    # reference bound: per-column atol = 1.5 * max|ref col| / 2^(bits-1) (tests/quantization/_utils.py:66-88);
+    # this implementation is far inside it (fp32 accumulate of exact products):
+    np.testing.assert_allclose(as_f32(out), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max())
+    # and against the un-quantised fp16 matmul with the reference's tolerance
+    full = x.float().numpy() @ w.float().numpy()
+    atol = 1.5 * np.abs(full).max(axis=0) / (1 << (bits - 1))
+    assert np.all(np.abs(as_f32(out) - full) <= atol[None, :] + 1e-2)
+
+
+@pytest.mark.parametrize('m,n,k', [(1, 4096, 4096), (2, 32000, 4096), (1, 4096, 11008), (19, 192, 64), (8, 24, 64)])
+def test_gemm_fp16(m, n, k):
+    r = rng(5)
+    x, w = h(r.standard_normal((m, k))), h(r.standard_normal((n, k)) / np.sqrt(k))
+    p = make_plugin('Gemm', [('transa', i32(0)), ('transb', i32(1)), ('type_id', i32([capi.HALF]))])
+    out = torch.empty((m, n), dtype=torch.float16, device='cuda')
+    run_plugin(p, [x, w], [out])
+    np.testing.assert_allclose(as_f32(out), O.gemm_fp16(as_f32(x), as_f32(w)), rtol=2e-3, atol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def attention_plugin(H, Dh, int8_kv, rot=None, neox=1):
+    return make_plugin('GPTAttention', [
+        ('num_heads', i32(H)), ('head_size', i32(Dh)), ('unidirectional', i32(1)), ('q_scaling', f32(1.0)),
+        ('rotary_embedding_dim', i32(Dh if rot is None else rot)), ('neox_rotary_style', i8(neox)),
+        ('context_fmha_type', i8(0)), ('multi_block_mode', i8(0)), ('multi_query_mode', i8(0)),
+        ('int8_kv_cache', i32(int8_kv)), ('fp8_kv_cache', i32(0)), ('remove_input_padding', i8(0)),
+        ('mask_type', i32([1])), ('paged_kv_cache', i32(0)), ('type_id', i32([capi.HALF])), ('in_flight_batching', i32(0)),
+    ])
+
+
+def run_attention(p, qkv, cache, seq_len, past_len, is_context, masked, in_len, max_in, smax, scales=None):
+    B = qkv.shape[0]
+    out = torch.empty(qkv.shape[:-1] + (qkv.shape[-1] // 3, ), dtype=torch.float16, device='cuda')
+    ins = [qkv, cache, torch.tensor(seq_len, dtype=torch.int32, device='cuda'),
+           HostTensor([past_len, 1 if is_context else 0]),
+           torch.tensor(masked, dtype=torch.int32, device='cuda'),
+           torch.tensor(in_len, dtype=torch.int32, device='cuda'),
+           HostTensor(np.zeros(0), shape=[max_in]),  # value carried by the shape
+           HostTensor(np.zeros(0), shape=[B, 1, smax])]
+    # shape-only tensors still need a non-null device pointer in the reference; give them one
+    dummy = torch.zeros(max(max_in, B * smax), dtype=torch.int32, device='cuda')
+    ins[6] = dummy[:max_in]
+    ins[7] = dummy[:B * smax].view(B, 1, smax)
+    if scales is not None:
+        ins += [torch.tensor([scales[0]], dtype=torch.float32, device='cuda'),
+                torch.tensor([scales[1]], dtype=torch.float32, device='cuda')]
+    run_plugin(p, ins, [out, cache])
+    return out
+
+
+@pytest.mark.parametrize('int8_kv', [0, 1])
+@pytest.mark.parametrize('H,Dh', [(4, 128), (4, 64), (2, 32), (32, 128)])
+@pytest.mark.parametrize('L', [1, 17, 128, 1023])
+def test_mmha_decode_vs_oracle(int8_kv, H, Dh, L):
+    """Generation step: new token at slot L; half of batch element 1's prompt is padding (test_gpt_attention.py:437-449)."""
+    r = rng(100 + L)
+    B, smax = 2, 1152
+    max_in = max(L - 3, 1) if L > 4 else L
+    in_len = [max_in, max(max_in // 2, 1)]
+    masked = np.zeros((B, smax), dtype=np.int32)
+    masked[1, in_len[1]:max_in] = 1
+    kv_scale = 0.05  # int8 scale: values ~N(0,1) -> +-6 sigma covered by 127 * 0.05
+    scales = (1.0 / kv_scale, kv_scale) if int8_kv else None
+    past = r.standard_normal((B, 2, H, smax, Dh)).astype(np.float32)
+    past[:, :, :, L:] = 0
+    if int8_kv:
+        cache_np = O.rni_sat_i8(past * np.float32(scales[0]))
+        cache = torch.from_numpy(cache_np.copy()).cuda()
+    else:
+        cache_np = past.astype(np.float16)
+        cache = torch.from_numpy(cache_np.copy()).cuda()
+    qkv = h(r.standard_normal((B, 1, 3 * H * Dh)))
+    p = attention_plugin(H, Dh, int8_kv)
+    out = run_attention(p, qkv, cache, [L, L], L, False, masked, in_len, max_in, smax, scales)
+    ref_cache = cache_np.copy()
+    ref = O.mmha_decode(as_f32(qkv)[:, 0], ref_cache, [L, L], in_len, max_in, L, H, Dh, Dh, True, 1.0, masked,
+                        scales[0] if scales else None, scales[1] if scales else None)
+    # generation-step tolerance of the reference's plugin test: atol 2e-3 (test_gpt_attention.py:828-831)
+    np.testing.assert_allclose(as_f32(out)[:, 0], ref, atol=2e-3, rtol=0)
+    # cache: nothing but slot L may change; slot L within 1 fp16 ulp / 1 int8 LSB of the oracle (RoPE uses fma)
+    got = cache.cpu().numpy()
+    keep = np.ones(smax, dtype=bool)
+    keep[L] = False
+    np.testing.assert_array_equal(got[:, :, :, keep], cache_np[:, :, :, keep])
+    if int8_kv:
+        d = np.abs(got[:, :, :, L].astype(np.int32) - ref_cache[:, :, :, L].astype(np.int32))
+        assert d.max() <= 1 and np.mean(d == 0) > 0.98
+    else:
+        np.testing.assert_allclose(got[:, :, :, L].astype(np.float32), ref_cache[:, :, :, L].astype(np.float32),
+                                   atol=2e-4, rtol=2e-3)  # KV tolerance of test_gpt_attention.py:561-578 (+1 ulp)
+
+
+@pytest.mark.parametrize('int8_kv', [0, 1])
+def test_kv_cache_append_bit_exact(int8_kv):
+    """A3 bit-exact row: without RoPE the appended K/V are pure copies / quantisations, so the cache must equal
+    the oracle's kv_flat_index/kv_store element for element (layout K/kvCacheUtils.h:114-170; KAT shape of
+    T/cpp/tests/runtime/transposeKVKernelTest.cpp: B=2, H=8, Dh=256, Smax=32, scale 0.1)."""
+    r = rng(7)
+    B, H, Dh, smax, L = 2, 8, 256, 32, 16
+    scale = 0.1
+    x = (r.uniform(-1, 1, (B, 1, 3 * H * Dh)) / scale).astype(np.float32)
+    x.reshape(-1)[:8] = np.array([0.5, 1.5, 2.5, -0.5, -1.5, 1270, -1290, 3.5]) / scale  # ties + saturation
+    qkv = h(x)
+    dt = torch.int8 if int8_kv else torch.float16
+    cache = torch.zeros((B, 2, H, smax, Dh), dtype=dt, device='cuda')
+    p = attention_plugin(H, Dh, int8_kv, rot=0)
+    scales = (scale, 1.0 / scale) if int8_kv else None
+    run_attention(p, qkv, cache, [L, L], L, False, np.zeros((B, smax), np.int32), [L, L], L, smax, scales)
+    flat = cache.cpu().numpy().reshape(-1)
+    src = as_f32(qkv).reshape(B, 3, H, Dh)
+    expect = np.zeros_like(flat)
+    for b in range(B):
+        for kv in range(2):
+            for hh in range(H):
+                vals = O.kv_store(src[b, 1 + kv, hh], scale if int8_kv else None)
+                i0 = O.kv_flat_index(b, kv, hh, L, 0, H, smax, Dh)
+                expect[i0:i0 + Dh] = vals
+    np.testing.assert_array_equal(flat, expect)
+
+
+@pytest.mark.parametrize('int8_kv', [0, 1])
+@pytest.mark.parametrize('H,Dh,S', [(4, 128, 90), (2, 32, 128), (4, 64, 33)])
+def test_context_attention_vs_oracle(int8_kv, H, Dh, S):
+    r = rng(200 + S)
+    B, smax = 2, S + 8
+    in_len = [S, S // 2]  # half of sequence 1 is padding
+    qkv = h(r.standard_normal((B, S, 3 * H * Dh)))
+    dt = torch.int8 if int8_kv else torch.float16
+    cache = torch.zeros((B, 2, H, smax, Dh), dtype=dt, device='cuda')
+    kv_scale = 0.05
+    scales = (1.0 / kv_scale, kv_scale) if int8_kv else None
+    p = attention_plugin(H, Dh, int8_kv)
+    qkv_in = qkv.clone()
+    masked = np.zeros((B, smax), np.int32)
+    out = run_attention(p, qkv, cache, [S, S], 0, True, masked, in_len, S, smax, scales)
+    ref_cache = np.zeros((B, 2, H, smax, Dh), dtype=np.int8 if int8_kv else np.float16)
+    ref, _ = O.context_attention(as_f32(qkv_in), ref_cache, in_len, H, Dh, Dh, True, 1.0, scales[0] if scales else None)
+    # context tolerance of the reference's plugin test: atol 5e-3 (test_gpt_attention.py:685-695)
+    np.testing.assert_allclose(as_f32(out), ref, atol=5e-3, rtol=0)
+    got = cache.cpu().numpy()
+    if int8_kv:
+        d = np.abs(got.astype(np.int32) - ref_cache.astype(np.int32))
+        assert d.max() <= 1 and np.mean(d == 0) > 0.98
+        # V is never rotated: bit-exact
+        np.testing.assert_array_equal(got[:, 1], ref_cache[:, 1])
+    else:
+        np.testing.assert_array_equal(got[:, 1], ref_cache[:, 1])
+        np.testing.assert_allclose(got[:, 0].astype(np.float32), ref_cache[:, 0].astype(np.float32), atol=2e-4,
+                                   rtol=2e-3)
+
+
+def test_plugin_rejects_unbuilt_features():
+    p = capi.Plugin.create('GPTAttention', [capi.PluginField('num_heads', i32(4))])
+    assert p is None and 'missing plugin field' in capi.last_error()

@@ -1,0 +1,148 @@
+// Device-side helpers shared by the gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tllm
+{
+namespace dev
+{
+
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+
+// int8 = cvt.rni.sat.s8.f32: round-half-even, saturate to [-128, 127], NaN -> 0
+// (reference: T/cpp/tensorrt_llm/common/cudaTypeUtils.cuh:361-371).
+__device__ __forceinline__ int8_t f2i8_rni_sat(float x)
+{
+    float r = __builtin_rintf(x);              // v_rndne_f32, ties to even
+    r = __builtin_fminf(__builtin_fmaxf(r, -128.f), 127.f); // NaN -> -128 by fmax semantics; fix below
+    int v = (int) r;
+    return (int8_t) ((x != x) ? 0 : v);
+}
+
+__device__ __forceinline__ float h2f(uint16_t bits)
+{
+    _Float16 h;
+    __builtin_memcpy(&h, &bits, 2);
+    return (float) h;
+}
+
+__device__ __forceinline__ uint16_t f2h(float f)
+{
+    _Float16 h = (_Float16) f; // v_cvt_f16_f32, round-to-nearest-even
+    uint16_t b;
+    __builtin_memcpy(&b, &h, 2);
+    return b;
+}
+
+__device__ __forceinline__ h2_t u32_as_h2(uint32_t u)
+{
+    h2_t r;
+    __builtin_memcpy(&r, &u, 4);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t h2_as_u32(h2_t h)
+{
+    uint32_t r;
+    __builtin_memcpy(&r, &h, 4);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t pack_h2(float lo, float hi)
+{
+    h2_t r;
+    r.x = (_Float16) lo;
+    r.y = (_Float16) hi;
+    return h2_as_u32(r);
+}
+
+// fp32 += a.lo*b.lo + a.hi*b.hi with fp16 operands (v_dot2_f32_f16: exact products, fp32 accumulate).
+__device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c)
+{
+    return __builtin_amdgcn_fdot2(u32_as_h2(a), u32_as_h2(b), c, false);
+}
+
+// int32 += sum of 4 signed int8 products (v_dot4_i32_i8).
+__device__ __forceinline__ int sdot4(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot4((int) a, (int) b, c, false);
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// Sum over groups of G consecutive lanes (G power of two <= 64); every lane of the group gets the total.
+template <int G>
+__device__ __forceinline__ float group_sum(float v)
+{
+#pragma unroll
+    for (int m = G / 2; m >= 1; m >>= 1)
+        v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// Block-wide reductions through LDS.  `red` must hold >= 32 floats.  All threads get the result.
+__device__ __forceinline__ float block_sum(float v, float* red)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0)
+        red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i)
+        t += red[i];
+    return t;
+}
+
+__device__ __forceinline__ float block_max(float v, float* red)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0)
+        red[wid] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i)
+        t = fmaxf(t, red[i]);
+    return t;
+}
+
+// 16-byte streaming load that bypasses temporal caching (weights / KV read once per token).
+__device__ __forceinline__ uint4 ld_nt16(const void* p)
+{
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ uint2 ld_nt8(const void* p)
+{
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    u2 v = __builtin_nontemporal_load(reinterpret_cast<const u2*>(p));
+    return make_uint2(v.x, v.y);
+}
+
+} // namespace dev
+} // namespace tllm

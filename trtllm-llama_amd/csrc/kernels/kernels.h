@@ -1,0 +1,194 @@
+// Host-side launch interface of the gfx950 kernels.  Every launcher enqueues on `stream`, never
+// synchronises, returns 0 on success or a negative code (and sets tllm::set_error) on a shape it
+// cannot run.  SURVEY.md §8a row ids (A2, A5, ...) are cited per kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace tllm
+{
+
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+namespace kernels
+{
+
+enum DType : int32_t
+{
+    DT_FLOAT = 0,
+    DT_HALF = 1,
+    DT_INT8 = 2,
+    DT_INT32 = 3
+};
+
+// ---------------------------------------------------------------------------------------------
+// Skinny GEMM (M <= 8 rows; decode).  y[m,n] = epi( scale * sum_k x'[m,k] * W[n,k] ),  x' = pro(x).
+//   A7 (fp16 Gemm), A8 (weight-only int8/int4), A10 (SmoothQuant int8xint8->int32), with the
+//   A5 RMSNorm / A11 activation quantisers as prologues and A6 SwiGLU / residual add as epilogues.
+// HBM-bound: streams W once with 16-byte non-temporal loads, x' staged in LDS once per workgroup.
+// ---------------------------------------------------------------------------------------------
+enum WType : int32_t
+{
+    W_FP16 = 0,     // W fp16 [N, K] row-major
+    W_INT8_WOQ = 1, // W u8 = q + 128, [N, ldw] (k contiguous), fp16 per-column scales; x fp16
+    W_INT4_WOQ = 2, // W packed nibbles n = q + 8, see weight_layout.h; fp16 per-column scales; x fp16
+    W_INT8_SQ = 3   // W s8 [N, ldw]; x s8; int32 accumulate; fp32 per-row x per-col scales
+};
+
+enum Prologue : int32_t
+{
+    PRO_NONE = 0,            // x already in the operand type (fp16, or s8 for W_INT8_SQ)
+    PRO_RMSNORM = 1,         // x fp16 -> rmsnorm(x) * gamma (fp16)
+    PRO_RMSNORM_QSTATIC = 2, // ... -> s8 with static scale act_scale[0]          (W_INT8_SQ)
+    PRO_RMSNORM_QDYN = 3,    // ... -> s8 with per-token scale amax/127            (W_INT8_SQ)
+    PRO_QSTATIC = 4,         // x fp16 -> s8 static                                (W_INT8_SQ)
+    PRO_QDYN = 5             // x fp16 -> s8 per-token                             (W_INT8_SQ)
+};
+
+enum Epilogue : int32_t
+{
+    EPI_NONE = 0,
+    EPI_RESIDUAL = 1,      // y = fp16(fp16(v) + residual)
+    EPI_SWIGLU = 2,        // W rows [0,N) gate (mlp.fc), [N,2N) up (mlp.gate): y = fp16(silu(g) * u)
+    EPI_SWIGLU_QSTATIC = 3 // ... then s8 with static scale epi_scale[0]
+};
+
+struct GemvParams
+{
+    int32_t wtype = W_FP16, pro = PRO_NONE, epi = EPI_NONE;
+    int32_t out_dtype = DT_HALF; // DT_HALF | DT_FLOAT | DT_INT32 (SQ only) | DT_INT8 (EPI_SWIGLU_QSTATIC)
+    int32_t M = 1, N = 0, K = 0; // N = output columns (for SWIGLU the weight has 2N rows)
+    const void* x = nullptr;     // [M, ldx] fp16 or s8
+    int64_t ldx = 0;             // elements
+    const void* w = nullptr;
+    int64_t ldw = 0;                  // bytes per weight row, multiple of 16
+    const void* scale_col = nullptr;  // WOQ: fp16 [N(*2 for swiglu)]; SQ: f32 [N] or [1]
+    const float* scale_row = nullptr; // SQ: f32 [M] or [1] (ignored when the prologue quantises per token)
+    int32_t per_channel = 0, per_token = 0;
+    const void* gamma = nullptr; // fp16 [K]
+    float eps = 1e-6f;
+    const float* act_scale = nullptr; // PRO_*QSTATIC: f32 [1] (scale_to_int)
+    float* dyn_scale_out = nullptr;   // optional f32 [M]: per-token scales computed by the prologue
+    void* x_pro_out = nullptr;        // optional [M, K]: the prologue's result (fp16 or s8), written by workgroup 0
+    const void* residual = nullptr;   // fp16 [M, ldy]
+    const float* epi_scale = nullptr; // EPI_SWIGLU_QSTATIC: f32 [1]
+    void* y = nullptr;
+    int64_t ldy = 0; // elements
+};
+
+int launch_gemv(const GemvParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm (A5) with optional fused int8 quantisation (A11 pattern of layernormKernels.cu:162-183).
+//   y = fp16( fp16(x * rsqrt(mean(x^2) + eps)) * gamma ); q = sat(rni(y * s)).
+// ---------------------------------------------------------------------------------------------
+struct RmsnormParams
+{
+    int32_t M = 0, N = 0;
+    const void* x = nullptr;        // fp16 [M, N]
+    const void* residual = nullptr; // optional fp16 [M, N]: x <- x + residual first, sum written to sum_out
+    void* sum_out = nullptr;        // fp16 [M, N] (required when residual != nullptr)
+    const void* gamma = nullptr;    // fp16 [N]
+    float eps = 1e-6f;
+    void* y = nullptr;                // fp16 [M, N] (may be null when only q is wanted)
+    int8_t* q = nullptr;              // optional s8 [M, N]
+    const float* static_scale = nullptr; // f32 [1] -> static quant
+    float* dyn_scale_out = nullptr;      // f32 [M] -> per-token dynamic quant (amax / 127)
+};
+int launch_rmsnorm(const RmsnormParams& p, hipStream_t stream);
+
+// A11: quantize_tensor (static per-tensor) and quantize_per_token.  K/quantization.cu:31-128.
+int launch_quantize_tensor(int8_t* dst, const void* src, int32_t src_dtype, int64_t size, const float* scale,
+    hipStream_t stream);
+int launch_quantize_per_token(int8_t* dst, const void* src, int32_t src_dtype, int64_t rows, int64_t cols,
+    float* scale_out, hipStream_t stream);
+
+// A6 standalone SwiGLU: y = fp16(silu(a) * b), a,b fp16 [n].
+int launch_swiglu(void* y, const void* a, const void* b, int64_t n, hipStream_t stream);
+// elementwise fp16 add: y = a + b
+int launch_add(void* y, const void* a, const void* b, int64_t n, hipStream_t stream);
+// A16 embedding gather: out[t, :] = table[ids[t], :] (fp16), ids int32; out-of-range id -> zeros.
+int launch_embedding(void* out, const int32_t* ids, const void* table, int64_t tokens, int32_t hidden, int32_t vocab,
+    hipStream_t stream);
+// A16 gather_last_token_logits input: out[b,:] = hidden[b, last_token_ids[b]-1, :] (padded layout)
+int launch_gather_last_token(void* out, const void* hidden, const int32_t* last_token_ids, int32_t batch, int32_t seq,
+    int32_t hidden_size, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// Decode attention (A2/A3): masked multi-head attention for one new token per sequence, with RoPE,
+// KV-cache write (fp16 or int8) and split-KV across workgroups.
+// ---------------------------------------------------------------------------------------------
+struct MmhaParams
+{
+    int32_t batch = 0, num_heads = 0, head_size = 0;
+    int32_t rotary_dim = 0, neox = 1;
+    float inv_sqrt_dh = 1.f;
+    int32_t int8_kv = 0;
+    int32_t max_seq_len = 0;   // cache capacity Smax
+    int32_t max_input_len = 0; // padded prompt length (RoPE position = timestep - (max_input_len - input_len[b]))
+    const void* qkv = nullptr; // fp16 [B, 3*H*Dh] (q | k | v)
+    void* kv_cache = nullptr;  // [B, 2, H, Smax, Dh] fp16 or s8
+    const int32_t* sequence_length = nullptr; // [B] device: tlength (slots already used)
+    const int32_t* input_lengths = nullptr;   // [B] device
+    const int32_t* masked_tokens = nullptr;   // [B, Smax] device or null
+    int32_t timestep_host = -1;               // past_kv_len from the host scalar; -1 => use sequence_length[0]
+    const float* kv_scale_orig_quant = nullptr; // f32 [1]
+    const float* kv_scale_quant_orig = nullptr; // f32 [1]
+    const float* rope_table = nullptr;          // f32 [max_pos, rotary_dim/2, 2] (cos, sin)
+    int32_t rope_table_len = 0;
+    void* out = nullptr;       // fp16 [B, H*Dh]
+    void* workspace = nullptr; // mmha_workspace_size bytes
+};
+size_t mmha_workspace_size(int32_t batch, int32_t num_heads, int32_t head_size, int32_t max_seq_len);
+int launch_mmha(const MmhaParams& p, hipStream_t stream);
+
+// RoPE table builder (host -> device buffer owned by caller): cos/sin(pos / 10000^(2j/rot)) in fp32,
+// formula of K/decoderMaskedMultiheadAttentionUtils.h:1511-1515.
+void fill_rope_table_host(float* table, int32_t max_pos, int32_t rotary_dim);
+
+// ---------------------------------------------------------------------------------------------
+// Context attention (A4): RoPE + KV-cache write + causal/padding-masked softmax(QK^T)V for the prompt.
+// ---------------------------------------------------------------------------------------------
+struct ContextAttnParams
+{
+    int32_t batch = 0, seq = 0, num_heads = 0, head_size = 0;
+    int32_t rotary_dim = 0, neox = 1;
+    float inv_sqrt_dh = 1.f;
+    int32_t int8_kv = 0, max_seq_len = 0;
+    void* qkv = nullptr;      // fp16 [B, S, 3*H*Dh]; q,k rewritten in place with RoPE applied (reference :1401-1403)
+    void* kv_cache = nullptr; // [B, 2, H, Smax, Dh]
+    const int32_t* input_lengths = nullptr; // [B]
+    const float* kv_scale_orig_quant = nullptr;
+    const float* rope_table = nullptr;
+    int32_t rope_table_len = 0;
+    void* out = nullptr; // fp16 [B, S, H*Dh]; rows >= input_len[b] are zero
+};
+int launch_context_attention(const ContextAttnParams& p, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// MFMA GEMMs for M > 8 (prefill): C[m,n] = sum_k A[m,k] * B[n,k].
+// ---------------------------------------------------------------------------------------------
+struct GemmParams
+{
+    int32_t wtype = W_FP16; // same weight layouts as GemvParams
+    int32_t out_dtype = DT_HALF;
+    int32_t M = 0, N = 0, K = 0;
+    const void* a = nullptr; // fp16 [M, lda] or s8 [M, lda]
+    int64_t lda = 0;
+    const void* w = nullptr;
+    int64_t ldw = 0; // bytes
+    const void* scale_col = nullptr;
+    const float* scale_row = nullptr;
+    int32_t per_channel = 0, per_token = 0;
+    void* c = nullptr;
+    int64_t ldc = 0;
+};
+int launch_gemm(const GemmParams& p, hipStream_t stream);
+
+// Greedy sampler: argmax over fp32 logits [B, V] -> ids; ties -> lowest index.
+int launch_argmax(int32_t* out_ids, const float* logits, int32_t batch, int32_t vocab, hipStream_t stream);
+
+} // namespace kernels
+} // namespace tllm

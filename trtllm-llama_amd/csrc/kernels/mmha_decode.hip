@@ -1,0 +1,445 @@
+// Decode-step masked multi-head attention for gfx950.
+//
+// Reference: masked_multihead_attention_kernel, MM/decoderMaskedMultiheadAttentionTemplate.h:1195-2183
+// (one CTA per (head, batch); 32 CTAs at B=1 cannot feed 256 CUs).  Here the KV range of every (batch, head)
+// is split over workgroups of 4 waves (grid = splits x H x B); each wave keeps 8 K rows and 8 V rows per
+// lane-group in flight as 16-byte (fp16) / 8-byte (int8) loads issued up front, computes the scores with
+// v_dot2_f32_f16 + intra-group shuffles, an online softmax per wave, P.V from registers, and the wave / block /
+// split partials {max, sum, out[Dh]} are merged by a tiny second kernel (flash-decoding).
+//
+// Numerics follow SURVEY Appendix A.1: RoPE in fp32 -> fp16; int8 cache store = sat(rni(float(k16) * s)),
+// load = fp16(float(q8) * s^-1); q.k products fp32-accumulated, * inv_sqrt_dh in fp32; masked positions are
+// dropped (weight 0, excluded from the max); probabilities rounded to fp16 before P.V; fp32 accumulation;
+// normaliser (sum + 1e-6); one final rounding to fp16.  The split only reorders fp32 additions and rounds the
+// un-normalised probability instead of the normalised one.
+//
+// Cache layout (bit-exact row A3, K/kvCacheUtils.h:114-170): [B, 2, H, Smax, Dh];
+//   element (b, kv, h, t, d) at ((b*2 + kv)*H + h)*Smax*Dh + t*Dh + d.
+#include "dev_utils.h"
+#include "kernels.h"
+#include <math.h>
+
+namespace tllm
+{
+namespace kernels
+{
+using namespace dev;
+
+namespace
+{
+
+constexpr int kRowsPerLane = 8; // cache rows each lane-group keeps in flight per wave
+
+template <int DH>
+struct MmhaGeom
+{
+    static constexpr int LPR = DH / 8;         // lanes per cache row (8 elements per lane)
+    static constexpr int RPW = 64 / LPR;       // rows per wave instruction
+    static constexpr int WAVE_ROWS = RPW * kRowsPerLane;
+    static constexpr int TCHUNK = 4 * WAVE_ROWS; // timesteps per workgroup
+};
+
+__device__ __forceinline__ void h8_to_f(const uint4& v, float* f)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+        h2_t h = u32_as_h2(w[j]);
+        f[2 * j] = (float) h.x;
+        f[2 * j + 1] = (float) h.y;
+    }
+}
+
+__device__ __forceinline__ uint4 f_to_h8(const float* f)
+{
+    return make_uint4(pack_h2(f[0], f[1]), pack_h2(f[2], f[3]), pack_h2(f[4], f[5]), pack_h2(f[6], f[7]));
+}
+
+// 8 cached int8 -> 8 fp16: fp16(float(q) * s)   (…Utils.h:2358-2365)
+__device__ __forceinline__ uint4 dequant8(const uint2& q, float s)
+{
+    const float nb = -128.f * s; // float(u) * s - 128 s == (u - 128) * s exactly (one rounding)
+    const uint32_t a = q.x ^ 0x80808080u, b = q.y ^ 0x80808080u;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+        f[j] = fmaf((float) ((a >> (8 * j)) & 0xffu), s, nb);
+        f[4 + j] = fmaf((float) ((b >> (8 * j)) & 0xffu), s, nb);
+    }
+    return f_to_h8(f);
+}
+
+// 8 fp16 -> 8 int8: sat(rni(float(x16) * s))   (…Utils.h:2383-2390, 2276-2286)
+__device__ __forceinline__ uint2 quant8(const uint4& v, float s)
+{
+    float f[8];
+    h8_to_f(v, f);
+    uint32_t o[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        o[j >> 2] |= ((uint32_t) (uint8_t) f2i8_rni_sat(f[j] * s)) << (8 * (j & 3));
+    return make_uint2(o[0], o[1]);
+}
+
+template <int DH, bool INT8KV>
+__global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, float2* ws_ml, float* ws_o, int nsplit_max)
+{
+    using G = MmhaGeom<DH>;
+    constexpr int LPR = G::LPR, RPW = G::RPW, NIT = kRowsPerLane;
+    const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane % LPR, grp = lane / LPR;
+    const int H = p.num_heads, Smax = p.max_seq_len;
+
+    const int tl = p.sequence_length[b]; // slots already used; the new token goes to slot tl
+    const int t0 = c * G::TCHUNK;
+    if (t0 > tl)
+        return;
+    const int timestep = p.timestep_host >= 0 ? p.timestep_host : tl;
+
+    constexpr int ESZ = INT8KV ? 1 : 2;
+    const char* kbase = reinterpret_cast<const char*>(p.kv_cache) + ((int64_t) (b * 2 + 0) * H + h) * Smax * DH * ESZ;
+    const char* vbase = reinterpret_cast<const char*>(p.kv_cache) + ((int64_t) (b * 2 + 1) * H + h) * Smax * DH * ESZ;
+
+    // ---- issue the cache loads first (they do not depend on anything computed below)
+    uint4 kreg[NIT], vreg[NIT];
+    int trow[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+    {
+        const int t = t0 + wid * G::WAVE_ROWS + i * RPW + grp;
+        trow[i] = t;
+        kreg[i] = make_uint4(0, 0, 0, 0);
+        vreg[i] = make_uint4(0, 0, 0, 0);
+        if (t < tl && t < Smax)
+        {
+            const int64_t off = ((int64_t) t * DH + li * 8) * ESZ;
+            if constexpr (INT8KV)
+            {
+                const uint2 k8 = *reinterpret_cast<const uint2*>(kbase + off);
+                const uint2 v8 = *reinterpret_cast<const uint2*>(vbase + off);
+                kreg[i].x = k8.x;
+                kreg[i].y = k8.y;
+                vreg[i].x = v8.x;
+                vreg[i].y = v8.y;
+            }
+            else
+            {
+                kreg[i] = *reinterpret_cast<const uint4*>(kbase + off);
+                vreg[i] = *reinterpret_cast<const uint4*>(vbase + off);
+            }
+        }
+    }
+
+    // ---- q, k, v of the new token (+ RoPE)
+    const uint16_t* qkv = reinterpret_cast<const uint16_t*>(p.qkv) + (int64_t) b * 3 * H * DH;
+    const uint4 q_raw = *reinterpret_cast<const uint4*>(qkv + (int64_t) h * DH + li * 8);
+    const uint4 k_raw = *reinterpret_cast<const uint4*>(qkv + (int64_t) (H + h) * DH + li * 8);
+    const uint4 v_new = *reinterpret_cast<const uint4*>(qkv + (int64_t) (2 * H + h) * DH + li * 8);
+    float qf[8], kf[8];
+    h8_to_f(q_raw, qf);
+    h8_to_f(k_raw, kf);
+    if (p.rotary_dim > 0)
+    {
+        const int pad = p.max_input_len - p.input_lengths[b];
+        int pos = timestep - pad;
+        pos = pos < 0 ? 0 : (pos >= p.rope_table_len ? p.rope_table_len - 1 : pos);
+        const int half = p.rotary_dim >> 1;
+        const float2* tab = reinterpret_cast<const float2*>(p.rope_table) + (int64_t) pos * half;
+        if (p.neox)
+        {
+            // pair (j, j + rot/2); rot == DH: the partner sits in lane li ^ (LPR/2)
+            float qp[8], kp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                qp[j] = __shfl_xor(qf[j], LPR / 2, 64);
+                kp[j] = __shfl_xor(kf[j], LPR / 2, 64);
+            }
+            const bool second = li >= LPR / 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                const int d = li * 8 + j;
+                const float2 cs = tab[second ? d - half : d];
+                // first half:  x' = x cos - y sin ; second half: y' = y cos + x sin
+                // fp16 rounding of the rotated value (…Utils.h:1517-1531)
+                const float sn = second ? cs.y : -cs.y;
+                qf[j] = h2f(f2h(cs.x * qf[j] + sn * qp[j]));
+                kf[j] = h2f(f2h(cs.x * kf[j] + sn * kp[j]));
+            }
+        }
+        else
+        {
+            // GPT-J style: pair (2i, 2i+1), both in this lane
+#pragma unroll
+            for (int j = 0; j < 8; j += 2)
+            {
+                const int d = li * 8 + j;
+                if (d < p.rotary_dim)
+                {
+                    const float2 cs = tab[d >> 1];
+                    const float q0 = qf[j], q1 = qf[j + 1], k0 = kf[j], k1 = kf[j + 1];
+                    qf[j] = h2f(f2h(cs.x * q0 - cs.y * q1));
+                    qf[j + 1] = h2f(f2h(cs.x * q1 + cs.y * q0));
+                    kf[j] = h2f(f2h(cs.x * k0 - cs.y * k1));
+                    kf[j + 1] = h2f(f2h(cs.x * k1 + cs.y * k0));
+                }
+            }
+        }
+    }
+    const uint4 q16 = f_to_h8(qf);
+    const uint4 k_new = f_to_h8(kf);
+
+    float s_oq = 1.f, s_qo = 1.f;
+    if constexpr (INT8KV)
+    {
+        s_oq = p.kv_scale_orig_quant[0];
+        s_qo = p.kv_scale_quant_orig[0];
+    }
+
+    // ---- the workgroup that owns slot tl appends the new token to the cache
+    if (tl / G::TCHUNK == c && wid == 0 && grp == 0 && tl < Smax)
+    {
+        const int64_t off = ((int64_t) tl * DH + li * 8) * ESZ;
+        if constexpr (INT8KV)
+        {
+            *reinterpret_cast<uint2*>(const_cast<char*>(kbase) + off) = quant8(k_new, s_oq);
+            *reinterpret_cast<uint2*>(const_cast<char*>(vbase) + off) = quant8(v_new, s_oq);
+        }
+        else
+        {
+            *reinterpret_cast<uint4*>(const_cast<char*>(kbase) + off) = k_new;
+            *reinterpret_cast<uint4*>(const_cast<char*>(vbase) + off) = v_new;
+        }
+    }
+
+    // ---- scores
+    const int32_t* mask = p.masked_tokens ? p.masked_tokens + (int64_t) b * Smax : nullptr;
+    float s[NIT];
+    float m_w = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+    {
+        const int t = trow[i];
+        uint4 kk;
+        if constexpr (INT8KV)
+            kk = dequant8(make_uint2(kreg[i].x, kreg[i].y), s_qo);
+        else
+            kk = kreg[i];
+        if (t == tl)
+            kk = k_new;
+        float d = 0.f;
+        d = dot2(q16.x, kk.x, d);
+        d = dot2(q16.y, kk.y, d);
+        d = dot2(q16.z, kk.z, d);
+        d = dot2(q16.w, kk.w, d);
+        d = group_sum<LPR>(d) * p.inv_sqrt_dh;
+        bool valid = t <= tl && t < Smax;
+        if (valid && mask && t < tl)
+            valid = mask[t] == 0;
+        s[i] = valid ? d : -INFINITY;
+        m_w = fmaxf(m_w, s[i]);
+    }
+#pragma unroll
+    for (int mk = 32; mk >= LPR; mk >>= 1)
+        m_w = fmaxf(m_w, __shfl_xor(m_w, mk, 64));
+
+    // ---- probabilities and P.V
+    float l_w = 0.f;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+    {
+        const float pr = (s[i] == -INFINITY) ? 0.f : __expf(s[i] - m_w);
+        l_w += pr;
+        const float p16 = h2f(f2h(pr));
+        uint4 vv;
+        if constexpr (INT8KV)
+            vv = dequant8(make_uint2(vreg[i].x, vreg[i].y), s_qo);
+        else
+            vv = vreg[i];
+        if (trow[i] == tl)
+            vv = v_new;
+        float vf[8];
+        h8_to_f(vv, vf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j] = fmaf(p16, vf[j], o[j]);
+    }
+#pragma unroll
+    for (int mk = 32; mk >= LPR; mk >>= 1)
+    {
+        l_w += __shfl_xor(l_w, mk, 64);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            o[j] += __shfl_xor(o[j], mk, 64);
+    }
+
+    // ---- merge the 4 waves through LDS, publish the split partial
+    __shared__ float sm_m[4], sm_l[4];
+    __shared__ float sm_o[4][DH];
+    if (grp == 0)
+    {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            sm_o[wid][li * 8 + j] = o[j];
+        if (li == 0)
+        {
+            sm_m[wid] = m_w;
+            sm_l[wid] = l_w;
+        }
+    }
+    __syncthreads();
+    if (tid < DH)
+    {
+        float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+        {
+            const float e = (sm_m[w] == -INFINITY) ? 0.f : __expf(sm_m[w] - M);
+            L += sm_l[w] * e;
+            O += sm_o[w][tid] * e;
+        }
+        const int64_t pi = ((int64_t) b * H + h) * nsplit_max + c;
+        ws_o[pi * DH + tid] = O;
+        if (tid == 0)
+            ws_ml[pi] = make_float2(M, L);
+    }
+}
+
+template <int DH>
+__global__ void mmha_combine_kernel(const MmhaParams p, const float2* ws_ml, const float* ws_o, int nsplit_max)
+{
+    using G = MmhaGeom<DH>;
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const int tl = p.sequence_length[b];
+    int ns = tl / G::TCHUNK + 1;
+    ns = ns > nsplit_max ? nsplit_max : ns;
+    const int64_t base = ((int64_t) b * p.num_heads + h) * nsplit_max;
+    float M = -INFINITY;
+    for (int i = 0; i < ns; ++i)
+        M = fmaxf(M, ws_ml[base + i].x);
+    float L = 0.f, O = 0.f;
+    for (int i = 0; i < ns; ++i)
+    {
+        const float2 ml = ws_ml[base + i];
+        const float e = (ml.x == -INFINITY) ? 0.f : __expf(ml.x - M);
+        L += ml.y * e;
+        if (d < DH)
+            O += ws_o[(base + i) * DH + d] * e;
+    }
+    if (d < DH)
+    {
+        // inv_sum = 1 / (sum + 1e-6)  (MM/...Template.h:1756)
+        const float r = O * (1.f / (L + 1.e-6f));
+        reinterpret_cast<uint16_t*>(p.out)[((int64_t) b * p.num_heads + h) * DH + d] = f2h(r);
+    }
+}
+
+template <int DH>
+int nsplit_for(int max_seq_len)
+{
+    return (max_seq_len + MmhaGeom<DH>::TCHUNK - 1) / MmhaGeom<DH>::TCHUNK;
+}
+
+int nsplit_any(int head_size, int max_seq_len)
+{
+    switch (head_size)
+    {
+    case 32: return nsplit_for<32>(max_seq_len);
+    case 64: return nsplit_for<64>(max_seq_len);
+    case 128: return nsplit_for<128>(max_seq_len);
+    case 256: return nsplit_for<256>(max_seq_len);
+    default: return -1;
+    }
+}
+
+template <int DH>
+int launch_dh(const MmhaParams& p, hipStream_t stream)
+{
+    const int ns = nsplit_for<DH>(p.max_seq_len);
+    float2* ws_ml = reinterpret_cast<float2*>(p.workspace);
+    const size_t ml_bytes = ((size_t) p.batch * p.num_heads * ns * sizeof(float2) + 255) / 256 * 256;
+    float* ws_o = reinterpret_cast<float*>(reinterpret_cast<char*>(p.workspace) + ml_bytes);
+    dim3 grid(ns, p.num_heads, p.batch);
+    if (p.int8_kv)
+        hipLaunchKernelGGL((mmha_partial_kernel<DH, true>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
+    else
+        hipLaunchKernelGGL((mmha_partial_kernel<DH, false>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
+    hipLaunchKernelGGL((mmha_combine_kernel<DH>), dim3(p.num_heads, p.batch), dim3(DH < 64 ? 64 : DH), 0, stream, p,
+        ws_ml, ws_o, ns);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+        set_error("mmha launch failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
+}
+
+} // namespace
+
+size_t mmha_workspace_size(int32_t batch, int32_t num_heads, int32_t head_size, int32_t max_seq_len)
+{
+    const int ns = nsplit_any(head_size, max_seq_len);
+    if (ns < 0)
+        return 0;
+    const size_t ml = ((size_t) batch * num_heads * ns * sizeof(float2) + 255) / 256 * 256;
+    return ml + (size_t) batch * num_heads * ns * head_size * sizeof(float);
+}
+
+void fill_rope_table_host(float* table, int32_t max_pos, int32_t rotary_dim)
+{
+    const int half = rotary_dim / 2;
+    for (int pos = 0; pos < max_pos; ++pos)
+        for (int j = 0; j < half; ++j)
+        {
+            // rotary_embedding_coefficient(zid = 2j, rot, t): inv_freq = t / pow(10000, zid / rot)  (fp32)
+            const float inv_freq = (float) pos / powf(10000.0f, (float) (2 * j) / (float) rotary_dim);
+            table[((int64_t) pos * half + j) * 2 + 0] = cosf(inv_freq);
+            table[((int64_t) pos * half + j) * 2 + 1] = sinf(inv_freq);
+        }
+}
+
+int launch_mmha(const MmhaParams& p, hipStream_t stream)
+{
+    if (p.rotary_dim > 0)
+    {
+        if (!p.rope_table || p.rope_table_len <= 0)
+        {
+            set_error("mmha: rotary embedding requested without a RoPE table");
+            return -1;
+        }
+        if (p.neox && p.rotary_dim != p.head_size)
+        {
+            set_error("mmha: NeoX rotary needs rotary_dim == head_size (got %d vs %d)", p.rotary_dim, p.head_size);
+            return -1;
+        }
+    }
+    if (p.int8_kv && (!p.kv_scale_orig_quant || !p.kv_scale_quant_orig))
+    {
+        set_error("mmha: int8 KV cache needs both scales");
+        return -1;
+    }
+    if (p.timestep_host >= p.max_seq_len)
+    {
+        set_error("mmha: timestep %d exceeds cache capacity %d (circular cache not supported)", p.timestep_host,
+            p.max_seq_len);
+        return -1;
+    }
+    switch (p.head_size)
+    {
+    case 32: return launch_dh<32>(p, stream);
+    case 64: return launch_dh<64>(p, stream);
+    case 128: return launch_dh<128>(p, stream);
+    case 256: return launch_dh<256>(p, stream);
+    default: set_error("mmha: head_size %d not supported (32, 64, 128, 256)", p.head_size); return -1;
+    }
+}
+
+} // namespace kernels
+} // namespace tllm

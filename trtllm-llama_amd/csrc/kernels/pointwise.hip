@@ -1,0 +1,372 @@
+// Row-wise and element-wise kernels of the LLaMA layer: RMSNorm (+ int8 quant), the activation
+// quantisers, SwiGLU, residual add, embedding gather, last-token gather, greedy argmax.
+// All HBM/latency-bound: 16-byte accesses, one workgroup per row, wave64 shuffles for reductions.
+#include "dev_utils.h"
+#include "kernels.h"
+
+namespace tllm
+{
+namespace kernels
+{
+using namespace dev;
+
+namespace
+{
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+    {
+        h2_t h = u32_as_h2(w[j]);
+        f[2 * j] = (float) h.x;
+        f[2 * j + 1] = (float) h.y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm (+ residual add, + int8 quant).  A5: PY/functional.py:3195-3219 (fp32 statistics, fp16 io);
+// quant tail: K/layernormKernels.cu:146-183 (normalise -> round to fp16 -> quantise; amax floor 1e-6 in T).
+// One workgroup per row; the row lives in LDS between the passes.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const RmsnormParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);
+    uint16_t* row = reinterpret_cast<uint16_t*>(smem + 128);
+    const int m = blockIdx.x, tid = threadIdx.x, N = p.N;
+    const uint16_t* x = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * N;
+    const uint16_t* res = p.residual ? reinterpret_cast<const uint16_t*>(p.residual) + (int64_t) m * N : nullptr;
+    uint16_t* so = p.sum_out ? reinterpret_cast<uint16_t*>(p.sum_out) + (int64_t) m * N : nullptr;
+    const uint16_t* g = reinterpret_cast<const uint16_t*>(p.gamma);
+
+    float ss = 0.f;
+    for (int k = tid; k < N; k += 256)
+    {
+        uint16_t b = x[k];
+        if (res)
+        {
+            b = f2h(h2f(b) + h2f(res[k]));
+            so[k] = b;
+        }
+        row[k] = b;
+        const float f = h2f(b);
+        ss += f * f;
+    }
+    ss = block_sum(ss, red);
+    const float inv = 1.0f / sqrtf(ss / (float) N + p.eps);
+
+    uint16_t* y = p.y ? reinterpret_cast<uint16_t*>(p.y) + (int64_t) m * N : nullptr;
+    int8_t* q = p.q ? p.q + (int64_t) m * N : nullptr;
+    float amax = 0.f;
+    for (int k = tid; k < N; k += 256)
+    {
+        const float n16 = h2f(f2h(h2f(row[k]) * inv));
+        const uint16_t yb = f2h(n16 * h2f(g[k]));
+        row[k] = yb;
+        if (y)
+            y[k] = yb;
+        amax = fmaxf(amax, fabsf(h2f(yb)));
+    }
+    if (!q)
+        return;
+    float qs;
+    if (p.dyn_scale_out)
+    {
+        amax = block_max(amax, red);
+        amax = fmaxf(amax, h2f(f2h(1e-6f)));
+        qs = 127.f / amax;
+        if (tid == 0)
+            p.dyn_scale_out[m] = amax / 127.f;
+    }
+    else
+    {
+        qs = p.static_scale[0];
+    }
+    for (int k = tid; k < N; k += 256)
+        q[k] = f2i8_rni_sat(h2f(row[k]) * qs);
+}
+
+// A11 static per-tensor quantiser.  K/quantization.cu:31-64: q = sat(rni(float(x) * scale)).
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_tensor_kernel(int8_t* dst, const T* src, int64_t size, const float* scale)
+{
+    const float s = scale[0];
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < size; i += (int64_t) gridDim.x * blockDim.x)
+    {
+        float f;
+        if constexpr (sizeof(T) == 2)
+            f = h2f(src[i]);
+        else
+            f = src[i];
+        dst[i] = f2i8_rni_sat(f * s);
+    }
+}
+
+// A11 per-token quantiser.  K/quantization.cu:94-118: amax in T with floor T(1e-6), scale_out = amax / 127,
+// q = sat(rni(float(x) * (127 / amax))).
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_per_token_kernel(
+    int8_t* dst, const T* src, int64_t cols, float* scale_out)
+{
+    __shared__ float red[32];
+    const T* s = src + (int64_t) blockIdx.x * cols;
+    int8_t* d = dst + (int64_t) blockIdx.x * cols;
+    float amax;
+    if constexpr (sizeof(T) == 2)
+        amax = h2f(f2h(1e-6f));
+    else
+        amax = 1e-6f;
+    for (int64_t i = threadIdx.x; i < cols; i += blockDim.x)
+    {
+        float f;
+        if constexpr (sizeof(T) == 2)
+            f = h2f(s[i]);
+        else
+            f = s[i];
+        amax = fmaxf(amax, fabsf(f));
+    }
+    amax = block_max(amax, red);
+    if (threadIdx.x == 0)
+        scale_out[blockIdx.x] = amax / 127.f;
+    const float qs = 127.f / amax;
+    for (int64_t i = threadIdx.x; i < cols; i += blockDim.x)
+    {
+        float f;
+        if constexpr (sizeof(T) == 2)
+            f = h2f(s[i]);
+        else
+            f = s[i];
+        d[i] = f2i8_rni_sat(f * qs);
+    }
+}
+
+__global__ __launch_bounds__(256) void swiglu_kernel(uint16_t* y, const uint16_t* a, const uint16_t* b, int64_t n)
+{
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+    {
+        const float g = h2f(a[i]);
+        const float s = h2f(f2h(g / (1.f + __expf(-g))));
+        y[i] = f2h(s * h2f(b[i]));
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(uint16_t* y, const uint16_t* a, const uint16_t* b, int64_t n)
+{
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+        y[i] = f2h(h2f(a[i]) + h2f(b[i]));
+}
+
+__global__ __launch_bounds__(256) void embedding_kernel(
+    uint16_t* out, const int32_t* ids, const uint16_t* table, int32_t hidden, int32_t vocab)
+{
+    const int64_t t = blockIdx.x;
+    const int32_t id = ids[t];
+    const bool ok = id >= 0 && id < vocab;
+    const uint16_t* src = table + (int64_t) (ok ? id : 0) * hidden;
+    uint16_t* dst = out + t * hidden;
+    if ((hidden & 7) == 0)
+    {
+        for (int k = threadIdx.x * 8; k < hidden; k += blockDim.x * 8)
+        {
+            uint4 v = ok ? *reinterpret_cast<const uint4*>(src + k) : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(dst + k) = v;
+        }
+    }
+    else
+    {
+        for (int k = threadIdx.x; k < hidden; k += blockDim.x)
+            dst[k] = ok ? src[k] : (uint16_t) 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_last_token_kernel(
+    uint16_t* out, const uint16_t* hidden, const int32_t* last_token_ids, int32_t seq, int32_t hs)
+{
+    const int b = blockIdx.x;
+    int pos = last_token_ids[b] - 1;
+    pos = pos < 0 ? 0 : (pos >= seq ? seq - 1 : pos);
+    const uint16_t* src = hidden + ((int64_t) b * seq + pos) * hs;
+    uint16_t* dst = out + (int64_t) b * hs;
+    for (int k = threadIdx.x; k < hs; k += blockDim.x)
+        dst[k] = src[k];
+}
+
+// greedy argmax; ties -> lowest index (torch.argmax / top-k=1 of the reference sampler)
+__global__ __launch_bounds__(1024) void argmax_kernel(int32_t* out_ids, const float* logits, int32_t vocab)
+{
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const float* l = logits + (int64_t) blockIdx.x * vocab;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < vocab; i += blockDim.x)
+    {
+        const float v = l[i];
+        if (v > best || (v == best && i < bi))
+        {
+            best = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+    {
+        const float ov = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        if (ov > best || (ov == best && oi < bi))
+        {
+            best = ov;
+            bi = oi;
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0)
+    {
+        sv[wid] = best;
+        si[wid] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 1; w < nw; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi))
+            {
+                best = sv[w];
+                bi = si[w];
+            }
+        out_ids[blockIdx.x] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+
+inline int check_launch(const char* what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+        set_error("%s launch failed: %s", what, hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
+}
+
+inline int grid_for(int64_t n)
+{
+    int64_t b = (n + 255) / 256;
+    return (int) (b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+} // namespace
+
+int launch_rmsnorm(const RmsnormParams& p, hipStream_t stream)
+{
+    if (p.M <= 0 || p.N <= 0)
+        return 0;
+    if (p.residual && !p.sum_out)
+    {
+        set_error("rmsnorm: residual given without sum_out");
+        return -1;
+    }
+    if (p.q && !p.static_scale && !p.dyn_scale_out)
+    {
+        set_error("rmsnorm: quantised output needs a static scale or a dynamic-scale output");
+        return -1;
+    }
+    const size_t smem = 128 + (size_t) p.N * 2;
+    if (smem > 64 * 1024)
+    {
+        set_error("rmsnorm: N=%d too large", p.N);
+        return -1;
+    }
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3(p.M), dim3(256), smem, stream, p);
+    return check_launch("rmsnorm");
+}
+
+int launch_quantize_tensor(
+    int8_t* dst, const void* src, int32_t src_dtype, int64_t size, const float* scale, hipStream_t stream)
+{
+    if (size <= 0)
+        return 0;
+    if (src_dtype == DT_HALF)
+        hipLaunchKernelGGL(quantize_tensor_kernel<uint16_t>, dim3(grid_for(size)), dim3(256), 0, stream, dst,
+            reinterpret_cast<const uint16_t*>(src), size, scale);
+    else if (src_dtype == DT_FLOAT)
+        hipLaunchKernelGGL(quantize_tensor_kernel<float>, dim3(grid_for(size)), dim3(256), 0, stream, dst,
+            reinterpret_cast<const float*>(src), size, scale);
+    else
+    {
+        set_error("quantize_tensor: unsupported dtype %d", src_dtype);
+        return -1;
+    }
+    return check_launch("quantize_tensor");
+}
+
+int launch_quantize_per_token(int8_t* dst, const void* src, int32_t src_dtype, int64_t rows, int64_t cols,
+    float* scale_out, hipStream_t stream)
+{
+    if (rows <= 0 || cols <= 0)
+        return 0;
+    if (src_dtype == DT_HALF)
+        hipLaunchKernelGGL(quantize_per_token_kernel<uint16_t>, dim3((unsigned) rows), dim3(256), 0, stream, dst,
+            reinterpret_cast<const uint16_t*>(src), cols, scale_out);
+    else if (src_dtype == DT_FLOAT)
+        hipLaunchKernelGGL(quantize_per_token_kernel<float>, dim3((unsigned) rows), dim3(256), 0, stream, dst,
+            reinterpret_cast<const float*>(src), cols, scale_out);
+    else
+    {
+        set_error("quantize_per_token: unsupported dtype %d", src_dtype);
+        return -1;
+    }
+    return check_launch("quantize_per_token");
+}
+
+int launch_swiglu(void* y, const void* a, const void* b, int64_t n, hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(swiglu_kernel, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(y),
+        reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(b), n);
+    return check_launch("swiglu");
+}
+
+int launch_add(void* y, const void* a, const void* b, int64_t n, hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(y),
+        reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(b), n);
+    return check_launch("add");
+}
+
+int launch_embedding(void* out, const int32_t* ids, const void* table, int64_t tokens, int32_t hidden, int32_t vocab,
+    hipStream_t stream)
+{
+    if (tokens <= 0)
+        return 0;
+    hipLaunchKernelGGL(embedding_kernel, dim3((unsigned) tokens), dim3(256), 0, stream,
+        reinterpret_cast<uint16_t*>(out), ids, reinterpret_cast<const uint16_t*>(table), hidden, vocab);
+    return check_launch("embedding");
+}
+
+int launch_gather_last_token(void* out, const void* hidden, const int32_t* last_token_ids, int32_t batch, int32_t seq,
+    int32_t hidden_size, hipStream_t stream)
+{
+    if (batch <= 0)
+        return 0;
+    hipLaunchKernelGGL(gather_last_token_kernel, dim3(batch), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(out),
+        reinterpret_cast<const uint16_t*>(hidden), last_token_ids, seq, hidden_size);
+    return check_launch("gather_last_token");
+}
+
+int launch_argmax(int32_t* out_ids, const float* logits, int32_t batch, int32_t vocab, hipStream_t stream)
+{
+    if (batch <= 0)
+        return 0;
+    hipLaunchKernelGGL(argmax_kernel, dim3(batch), dim3(1024), 0, stream, out_ids, logits, vocab);
+    return check_launch("argmax");
+}
+
+} // namespace kernels
+} // namespace tllm

@@ -1,0 +1,204 @@
+#include "comm.h"
+#include "../kernels/kernels.h"
+#include <cstring>
+#include <dlfcn.h>
+#include <map>
+#include <mutex>
+#include <rccl/rccl.h>
+
+namespace tllm
+{
+namespace comm
+{
+namespace
+{
+struct Api
+{
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+std::mutex g_mu;
+Api g_api;
+std::map<std::vector<int32_t>, ncclComm_t> g_comms; // keyed by rank set (P/common/plugin.h:181-188)
+
+bool load_api()
+{
+    if (g_api.lib)
+        return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (auto n : names)
+    {
+        g_api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_api.lib)
+            break;
+    }
+    if (!g_api.lib)
+    {
+        set_error("comm: cannot dlopen librccl: %s", dlerror());
+        return false;
+    }
+#define SYM(field, name)                                                                                               \
+    g_api.field = reinterpret_cast<decltype(g_api.field)>(dlsym(g_api.lib, name));                                     \
+    if (!g_api.field)                                                                                                  \
+    {                                                                                                                  \
+        set_error("comm: librccl lacks %s", name);                                                                     \
+        return false;                                                                                                  \
+    }
+    SYM(GetUniqueId, "ncclGetUniqueId")
+    SYM(CommInitRank, "ncclCommInitRank")
+    SYM(AllReduce, "ncclAllReduce")
+    SYM(AllGather, "ncclAllGather")
+    SYM(CommDestroy, "ncclCommDestroy")
+    SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return true;
+}
+
+bool to_nccl_type(int32_t dtype, ncclDataType_t* t)
+{
+    switch (dtype)
+    {
+    case 0: *t = ncclFloat32; return true;
+    case 1: *t = ncclFloat16; return true;
+    case 2: *t = ncclInt8; return true;
+    case 3: *t = ncclInt32; return true;
+    default: set_error("comm: unsupported dtype %d", dtype); return false;
+    }
+}
+
+ncclComm_t find(const std::vector<int32_t>& group)
+{
+    auto it = g_comms.find(group);
+    if (it == g_comms.end())
+    {
+        set_error("comm: no communicator registered for this group (call tllm_comm_init_rank first)");
+        return nullptr;
+    }
+    return it->second;
+}
+} // namespace
+
+int get_unique_id(void* id128)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!load_api())
+        return -1;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId must be 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t r = g_api.GetUniqueId(&id);
+    if (r != ncclSuccess)
+    {
+        set_error("comm: ncclGetUniqueId: %s", g_api.GetErrorString(r));
+        return -1;
+    }
+    memcpy(id128, &id, 128);
+    return 0;
+}
+
+int init_rank(const std::vector<int32_t>& group, int32_t rank, const void* id128)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!load_api())
+        return -1;
+    if (g_comms.count(group))
+        return 0;
+    int my = -1;
+    for (size_t i = 0; i < group.size(); ++i)
+        if (group[i] == rank)
+            my = (int) i;
+    if (my < 0)
+    {
+        set_error("comm: rank %d is not in the group", rank);
+        return -1;
+    }
+    ncclUniqueId id;
+    memcpy(&id, id128, 128);
+    ncclComm_t c;
+    ncclResult_t r = g_api.CommInitRank(&c, (int) group.size(), id, my);
+    if (r != ncclSuccess)
+    {
+        set_error("comm: ncclCommInitRank: %s", g_api.GetErrorString(r));
+        return -1;
+    }
+    g_comms[group] = c;
+    return 0;
+}
+
+bool has_comm(const std::vector<int32_t>& group)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_comms.count(group) != 0;
+}
+
+int all_reduce_sum(const std::vector<int32_t>& group, const void* in, void* out, int64_t count, int32_t dtype,
+    hipStream_t stream)
+{
+    if (group.size() <= 1)
+    {
+        if (in != out)
+        {
+            const int es = dtype == 1 ? 2 : (dtype == 2 ? 1 : 4);
+            if (hipMemcpyAsync(out, in, count * es, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                return -1;
+        }
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    ncclComm_t c = find(group);
+    ncclDataType_t t;
+    if (!c || !to_nccl_type(dtype, &t))
+        return -1;
+    ncclResult_t r = g_api.AllReduce(in, out, (size_t) count, t, ncclSum, c, stream);
+    if (r != ncclSuccess)
+    {
+        set_error("comm: ncclAllReduce: %s", g_api.GetErrorString(r));
+        return -1;
+    }
+    return 0;
+}
+
+int all_gather(const std::vector<int32_t>& group, const void* in, void* out, int64_t count, int32_t dtype,
+    hipStream_t stream)
+{
+    if (group.size() <= 1)
+    {
+        if (in != out)
+        {
+            const int es = dtype == 1 ? 2 : (dtype == 2 ? 1 : 4);
+            if (hipMemcpyAsync(out, in, count * es, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                return -1;
+        }
+        return 0;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    ncclComm_t c = find(group);
+    ncclDataType_t t;
+    if (!c || !to_nccl_type(dtype, &t))
+        return -1;
+    ncclResult_t r = g_api.AllGather(in, out, (size_t) count, t, c, stream);
+    if (r != ncclSuccess)
+    {
+        set_error("comm: ncclAllGather: %s", g_api.GetErrorString(r));
+        return -1;
+    }
+    return 0;
+}
+
+int destroy_all()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_comms)
+        if (g_api.CommDestroy)
+            g_api.CommDestroy(kv.second);
+    g_comms.clear();
+    return 0;
+}
+
+} // namespace comm
+} // namespace tllm
