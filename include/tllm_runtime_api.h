@@ -1,0 +1,118 @@
+/*
+ * tllm_runtime_api.h — host decode loop of the MI355X LLaMA path behind a C ABI.
+ *
+ * Takes the place of the TensorRT engine + execution context that the reference's runtime drives
+ * (T/tensorrt_llm/runtime/generation.py:43-100 `_Runtime`, :413-488 `setup`, :782-997 `decode`) and of the
+ * C++ GptSession host loop (T/cpp/tensorrt_llm/runtime/gptSession.cpp:252,700).  The Python front-end
+ * (tensorrt_llm.runtime.GenerationSession) keeps its reference signature and calls these entry points;
+ * PyTorch is only used to own device buffers that are handed in as raw pointers.
+ *
+ * An "engine" here is: a text configuration (key=value lines, the builder_config / plugin_config of
+ * config.json, T/tensorrt_llm/builder.py:259-267) plus named weight tensors (module paths of the reference's
+ * LLaMAForCausalLM, T/examples/llama_quant/llama_model.py:122-251).  Execution = the plugin kernels of
+ * tllm_plugin_api.h enqueued layer by layer on one HIP stream; the generation step is fused
+ * (RMSNorm / quantisation / SwiGLU / residual folded into the GEMV launches) and replayed as a hipGraph.
+ */
+#ifndef TLLM_RUNTIME_API_H
+#define TLLM_RUNTIME_API_H
+
+#include "tllm_plugin_api.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tllm_session* tllm_session_t;
+
+/* Create a session from a configuration text.  Recognised keys (defaults in parentheses):
+ *   num_layers, num_heads, hidden_size, inter_size, vocab_size, max_position_embeddings (2048),
+ *   rms_norm_eps (1e-6), tp_size (1), tp_rank (0), quant_mode (0: QuantMode bits,
+ *   T/tensorrt_llm/quantization/mode.py:6-21), weight_only_precision (int8|int4),
+ *   use_gpt_attention_plugin/use_gemm_plugin (informational), neox_rotary_style (1).
+ * Returns NULL on error (tllm_last_error()). */
+tllm_session_t tllm_session_create(const char* config_text);
+
+/* Register one weight tensor by module path, e.g. "layers.3.attention.qkv.weight", "vocab_embedding.weight",
+ * "ln_f.weight", "lm_head.weight" (reference attribute names, T/examples/llama_quant/weight_quant.py:172-446).
+ *   location 0: `data` is a HOST pointer, the bytes are copied to device memory owned by the session;
+ *   location 1: `data` is a DEVICE pointer that outlives the session (tensor handoff from torch). */
+int32_t tllm_session_set_tensor(tllm_session_t s, const char* name, int32_t dtype, const int64_t* dims, int32_t nbDims,
+    const void* data, int32_t location);
+
+/* Resolve the weights against the configuration; fails listing the first missing / mis-shaped tensor. */
+int32_t tllm_session_finalize(tllm_session_t s);
+
+/* Parse a serialized engine (format written by tensorrt_llm.Builder.build_engine: "TLLMENG1" header, config
+ * text, tensor table, data) = create + set_tensor(location 0) + finalize. */
+tllm_session_t tllm_session_load_engine(const void* engine, size_t nbytes);
+
+/* GenerationSession.setup (generation.py:413-488): allocates the per-layer KV cache
+ * [B, 2, H/tp, max_input_len + max_new_tokens, Dh] (fp16 or int8), activations and the RoPE table. */
+int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_input_len, int32_t max_new_tokens);
+
+/* GenerationSession.decode (generation.py:782-997), greedy (top-k = 1): context step on the padded prompts,
+ * then up to max_new_tokens generation steps with the sampler on device and no per-step host sync
+ * (the reference syncs every step, generation.py:963).
+ *   input_ids     HOST int32 [B, max_input_len] (padded with pad_id), input_lengths HOST int32 [B];
+ *   output_ids    HOST int32 [B, max_input_len + max_new_tokens]: the prompt followed by the generated ids;
+ *   end_id < 0 disables early stopping (benchmarks).  Blocks until the ids are on the host. */
+int32_t tllm_session_generate(tllm_session_t s, const int32_t* input_ids, const int32_t* input_lengths,
+    int32_t max_new_tokens, int32_t end_id, int32_t pad_id, int32_t* output_ids, tllm_stream_t stream);
+
+/* Step-wise interface (parity tests, benchmarks):
+ *   context: runs the prompt, leaves the fp32 logits of the last real token of every sequence in the session;
+ *   step:    runs `n_steps` generation steps (greedy feedback on device); timing is the caller's business.
+ *   use_graph != 0 replays the captured generation step. */
+int32_t tllm_session_context(tllm_session_t s, const int32_t* input_ids, const int32_t* input_lengths,
+    tllm_stream_t stream);
+int32_t tllm_session_step(tllm_session_t s, int32_t n_steps, int32_t use_graph, tllm_stream_t stream);
+/* Fill the KV cache for `length` positions with pseudo-random content (as a prompt of that length would)
+ * without running a prefill; for decode-rate benchmarks at a given context length. */
+int32_t tllm_session_fake_context(tllm_session_t s, int32_t length, uint32_t seed, tllm_stream_t stream);
+/* Copy state to HOST buffers (synchronises the stream). */
+int32_t tllm_session_get_logits(tllm_session_t s, float* logits /* [B, vocab] */, tllm_stream_t stream);
+int32_t tllm_session_get_output_ids(tllm_session_t s, int32_t* ids /* [B, max_in + max_new] */, tllm_stream_t stream);
+/* Device pointer of a layer's KV cache (layout [B,2,H/tp,Smax,Dh]) for inspection. */
+void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer);
+/* Bytes a generation step must move from HBM at context length L (weights + KV read + KV write): the
+ * algorithmic-bytes model of SURVEY.md §8(d), evaluated for this session's configuration. */
+int64_t tllm_session_step_bytes(tllm_session_t s, int32_t context_len);
+
+void tllm_session_destroy(tllm_session_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Kernel-level entry for the fused skinny GEMM that the generation step is built from (kernels/gemv.hip);
+ * exposed so that parity tests and the micro-benchmark can drive every prologue / epilogue directly.
+ * Field meanings: trtllm-llama_amd/csrc/kernels/kernels.h (GemvParams).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct
+{
+    int32_t wtype, pro, epi, out_dtype;
+    int32_t M, N, K;
+    const void* x;
+    int64_t ldx;
+    const void* w;
+    int64_t ldw;
+    const void* scale_col;
+    const float* scale_row;
+    int32_t per_channel, per_token;
+    const void* gamma;
+    float eps;
+    const float* act_scale;
+    float* dyn_scale_out;
+    void* x_pro_out;
+    const void* residual;
+    const float* epi_scale;
+    void* y;
+    int64_t ldy;
+} tllm_gemv_params_t;
+
+int32_t tllm_gemv(const tllm_gemv_params_t* p, tllm_stream_t stream);
+/* Test/bench knob: rows of W per wave (0 = heuristic). */
+void tllm_gemv_set_rows_per_wave(int32_t r);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* TLLM_RUNTIME_API_H */

@@ -190,5 +190,28 @@ int launch_gemm(const GemmParams& p, hipStream_t stream);
 // Greedy sampler: argmax over fp32 logits [B, V] -> ids; ties -> lowest index.
 int launch_argmax(int32_t* out_ids, const float* logits, int32_t batch, int32_t vocab, hipStream_t stream);
 
+// One greedy sampling step with the bookkeeping of GenerationSession.decode kept on the device
+// (PY/runtime/generation.py:943-983: DynamicDecodeOp top-k=1 + sequence-length update + stop criteria):
+//   id = argmax_v logits[b, v]   (logits may be the all-gather of `nparts` vocabulary shards [nparts, B, vocab_part])
+//   if advance: seq_len[b] += 1 ;  finished sequences keep emitting end_id ;  out_ids[b, seq_len[b]] = id ;
+//   cur_ids[b] = id ;  finished[b] |= (id == end_id)
+struct GreedyParams
+{
+    const float* logits = nullptr;
+    int32_t batch = 0, vocab_part = 0, nparts = 1, vocab = 0;
+    int32_t* cur_ids = nullptr;
+    int32_t* out_ids = nullptr;
+    int32_t out_stride = 0;
+    int32_t* seq_len = nullptr;
+    int32_t* finished = nullptr;
+    int32_t end_id = -1, advance = 0;
+};
+int launch_greedy_step(const GreedyParams& p, hipStream_t stream);
+
+// deterministic pseudo-random fill (fp16 ~U(-scale, scale) or int8 ~U[-127,127]) for synthetic KV caches
+int launch_fill_random(void* dst, int32_t dtype, int64_t n, uint32_t seed, float scale, hipStream_t stream);
+// int32 fill
+int launch_fill_i32(int32_t* dst, int32_t value, int64_t n, hipStream_t stream);
+
 } // namespace kernels
 } // namespace tllm

@@ -241,6 +241,106 @@ __global__ __launch_bounds__(1024) void argmax_kernel(int32_t* out_ids, const fl
     }
 }
 
+__global__ __launch_bounds__(1024) void greedy_step_kernel(const GreedyParams p)
+{
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int b = blockIdx.x;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int part = 0; part < p.nparts; ++part)
+    {
+        const float* l = p.logits + ((int64_t) part * p.batch + b) * p.vocab_part;
+        for (int i = threadIdx.x; i < p.vocab_part; i += blockDim.x)
+        {
+            const int id = part * p.vocab_part + i;
+            if (id >= p.vocab)
+                break;
+            const float v = l[i];
+            if (v > best || (v == best && id < bi))
+            {
+                best = v;
+                bi = id;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+    {
+        const float ov = __shfl_xor(best, m, 64);
+        const int oi = __shfl_xor(bi, m, 64);
+        if (ov > best || (ov == best && oi < bi))
+        {
+            best = ov;
+            bi = oi;
+        }
+    }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0)
+    {
+        sv[wid] = best;
+        si[wid] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int w = 1; w < nw; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi))
+            {
+                best = sv[w];
+                bi = si[w];
+            }
+        int id = bi == 0x7fffffff ? 0 : bi;
+        int sl = p.seq_len[b];
+        if (p.advance)
+        {
+            sl += 1;
+            p.seq_len[b] = sl;
+        }
+        if (p.finished)
+        {
+            if (p.finished[b])
+                id = p.end_id;
+            else if (p.end_id >= 0 && id == p.end_id)
+                p.finished[b] = 1;
+        }
+        if (sl < p.out_stride)
+            p.out_ids[(int64_t) b * p.out_stride + sl] = id;
+        p.cur_ids[b] = id;
+    }
+}
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x)
+{
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void fill_random_kernel(void* dst, int dtype, int64_t n, uint32_t seed, float scale)
+{
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+    {
+        const uint32_t r = hash32((uint32_t) i * 2654435761u + seed) ^ hash32((uint32_t) (i >> 32) + seed * 31u);
+        if (dtype == DT_HALF)
+            reinterpret_cast<uint16_t*>(dst)[i] = f2h(((float) (r >> 8) * (1.f / 8388608.f) - 1.f) * scale);
+        else if (dtype == DT_INT8)
+            reinterpret_cast<int8_t*>(dst)[i] = (int8_t) ((int) (r % 255u) - 127);
+        else
+            reinterpret_cast<float*>(dst)[i] = ((float) (r >> 8) * (1.f / 8388608.f) - 1.f) * scale;
+    }
+}
+
+__global__ void fill_i32_kernel(int32_t* dst, int32_t v, int64_t n)
+{
+    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+        dst[i] = v;
+}
+
 inline int check_launch(const char* what)
 {
     hipError_t e = hipGetLastError();
@@ -358,6 +458,30 @@ int launch_gather_last_token(void* out, const void* hidden, const int32_t* last_
     hipLaunchKernelGGL(gather_last_token_kernel, dim3(batch), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(out),
         reinterpret_cast<const uint16_t*>(hidden), last_token_ids, seq, hidden_size);
     return check_launch("gather_last_token");
+}
+
+int launch_greedy_step(const GreedyParams& p, hipStream_t stream)
+{
+    if (p.batch <= 0)
+        return 0;
+    hipLaunchKernelGGL(greedy_step_kernel, dim3(p.batch), dim3(1024), 0, stream, p);
+    return check_launch("greedy_step");
+}
+
+int launch_fill_random(void* dst, int32_t dtype, int64_t n, uint32_t seed, float scale, hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(fill_random_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dst, dtype, n, seed, scale);
+    return check_launch("fill_random");
+}
+
+int launch_fill_i32(int32_t* dst, int32_t value, int64_t n, hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dst, value, n);
+    return check_launch("fill_i32");
 }
 
 int launch_argmax(int32_t* out_ids, const float* logits, int32_t batch, int32_t vocab, hipStream_t stream)
