@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decode tokens/sec of LLaMA-7B, batch 1, 1024-token context (BASELINE.json `metric`),
+int8 (SmoothQuant per-channel int8 weights+activations, int8 KV cache — BASELINE.json configs[3]) on N GPUs of
+one node with tensor parallelism TP = N (the reference's only sharding).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config sq|woq8|woq4|fp16] [--context 1024]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one generation step (one new token for the whole batch) through all 32 layers + lm_head + greedy
+sampler, replayed from the captured hipGraph with the KV cache holding `context` tokens (+ the tokens generated so
+far).  Weights are synthetic (seeded random of the LLaMA-7B architecture, generated on the GPU in the storage format
+of the chosen config); inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line with
+`roofline` (dominant kernel = the layer GEMV, HBM-bound) and `cpu_baseline` (HF transformers LLaMA on the host CPU,
+the reference's run_hf.py path, bounded sample) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'trtllm-llama_amd'))
+sys.path.insert(0, ROOT)
+
+LLAMA_7B = dict(num_layers=32, num_heads=32, hidden_size=4096, inter_size=11008, vocab_size=32000,
+                max_position_embeddings=2048, rms_norm_eps=1e-6)  # T/examples/llama_quant/build.py:59-71
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+QM = dict(fp16=0, woq8=2, woq4=1, sq=2 | 4 | 8)  # QuantMode bits (T/tensorrt_llm/quantization/mode.py:6-21)
+INT8_KV = 32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=128)
+    ap.add_argument('--warmup', type=int, default=8)
+    ap.add_argument('--config', default='sq', choices=['sq', 'woq8', 'woq4', 'fp16'])
+    ap.add_argument('--context', type=int, default=1024)
+    ap.add_argument('--layers', type=int, default=32, help='debug only: fewer layers (the result line says so)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
+    ap.add_argument('--cpu-tokens', type=int, default=3)
+    return ap.parse_args()
+
+
+def synth_weights(torch, cfg, mode, int8_kv, tp, rank, dev):
+    """Seeded random LLaMA-7B-shaped weights directly in the engine's storage formats (per-rank shards)."""
+    D, I, V, H = cfg['hidden_size'], cfg['inter_size'], cfg['vocab_size'], cfg['num_heads']
+    Dr, Ir, Vr = D // tp, I // tp, (V + tp - 1) // tp
+    g_rep = torch.Generator(device=dev).manual_seed(0)  # replicated tensors: same on every rank
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)  # shards
+    t = {}
+
+    def u(gen, shape, r):  # fp16 U(-r, r)
+        return ((torch.rand(shape, generator=gen, device=dev, dtype=torch.float32) * 2 - 1) * r).half()
+
+    def xavier(n, k):
+        return (6.0 / (n + k)) ** 0.5
+
+    t['vocab_embedding.weight'] = (torch.randn((V, D), generator=g_rep, device=dev) * 0.5).half()
+    t['ln_f.weight'] = (1 + 0.1 * (torch.rand(D, generator=g_rep, device=dev) * 2 - 1)).half()
+    t['lm_head.weight'] = u(g, (Vr, D), xavier(V, D))
+    f32 = lambda v: torch.tensor([v], dtype=torch.float32, device=dev)
+
+    def linear(prefix, n, k, fan):
+        r = fan
+        if mode == 'fp16':
+            t[prefix + '.weight'] = u(g, (n, k), r)
+        elif mode == 'sq':
+            t[prefix + '.weight'] = torch.randint(-127, 128, (n, k), generator=g, device=dev, dtype=torch.int8)
+            # static per-channel SmoothQuant: y = acc * per_channel_scale[n] * act_scale, activations ~ 28 / unit
+            t[prefix + '.per_channel_scale'] = torch.full((1, n), r / 127.0 / 28.0, dtype=torch.float32, device=dev)
+            t[prefix + '.act_scale'] = torch.ones((1, 1), dtype=torch.float32, device=dev)
+        else:
+            bits = 8 if mode == 'woq8' else 4
+            row = k if bits == 8 else k // 2
+            t[prefix + '.weight'] = torch.randint(0, 256, (n, row), generator=g, device=dev, dtype=torch.uint8)
+            t[prefix + '.per_channel_scale'] = torch.full((n, ), r / (127.0 if bits == 8 else 7.0), dtype=torch.float16,
+                                                          device=dev)
+
+    for i in range(cfg['num_layers']):
+        p = f'layers.{i}.'
+        t[p + 'input_layernorm.weight'] = (1 + 0.1 * (torch.rand(D, generator=g_rep, device=dev) * 2 - 1)).half()
+        t[p + 'post_layernorm.weight'] = (1 + 0.1 * (torch.rand(D, generator=g_rep, device=dev) * 2 - 1)).half()
+        linear(p + 'attention.qkv', 3 * Dr, D, xavier(3 * D, D))
+        linear(p + 'attention.dense', D, Dr, xavier(D, D))
+        linear(p + 'mlp.fc', Ir, D, xavier(I, D))
+        linear(p + 'mlp.gate', Ir, D, xavier(I, D))
+        linear(p + 'mlp.proj', D, Ir, xavier(D, I))
+        if mode == 'sq':
+            t[p + 'input_layernorm.scale_to_int'] = f32(28.0)
+            t[p + 'post_layernorm.scale_to_int'] = f32(28.0)
+            t[p + 'attention.quantization_scaling_factor'] = f32(60.0)
+            t[p + 'mlp.quantization_scaling_factor'] = f32(40.0)
+        if int8_kv:
+            t[p + 'attention.kv_orig_quant_scale'] = f32(127.0 / 6.0)
+            t[p + 'attention.kv_quant_orig_scale'] = f32(6.0 / 127.0)
+    return t
+
+
+def run_config(torch, dist, args, mode, rank, world, dev):
+    from tensorrt_llm.runtime.native import NativeSession
+    cfg = dict(LLAMA_7B, num_layers=args.layers)
+    int8_kv = mode != 'fp16'  # BASELINE.json configs: fp16 + fp16 KV; every int8 config with int8 KV
+    qm = QM[mode] | (INT8_KV if int8_kv else 0)
+    sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=world, tp_rank=rank))
+    weights = synth_weights(torch, cfg, mode, int8_kv, world, rank, dev)
+    for k, v in weights.items():
+        sess.set_tensor(k, v)
+    sess.finalize()
+    K, W = args.steps, args.warmup
+    sess.setup(1, args.context, K + W + 4)
+    stream = torch.cuda.current_stream().cuda_stream
+    sess.fake_context(args.context, seed=1, stream=stream)
+    sess.step(2, use_graph=False, stream=stream)  # eager: lazy init outside the capture
+    sess.step(max(W, 1), use_graph=True, stream=stream)  # captures the graph, W untimed warm-up steps
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    sess.step(K, use_graph=True, stream=stream)
+    e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+    logits = sess.logits(stream=stream)
+    finite = bool((logits == logits).all() and abs(logits).max() < 1e30)
+    # context length seen by the timed steps: context + 2 + W ... + K (mean)
+    l_mean = args.context + 2 + max(W, 1) + (K - 1) / 2.0
+    step_bytes = sess.step_bytes(int(round(l_mean)))
+    res = dict(mode=mode, wall_s=wall, dev_ms=dev_ms, ms_per_step=wall * 1e3 / K, tokens_per_s=K / wall, finite=finite,
+               step_bytes=step_bytes, mean_context=l_mean)
+    # instrumented pass for the roofline of the dominant kernel (layer GEMVs) — rank 0 reports
+    prof = sess.profile(8, stream=stream)
+    res['profile'] = prof
+    # algorithmic bytes of the layer GEMVs per step = step bytes - lm_head - KV traffic
+    sess_b0 = sess.step_bytes(0)
+    kv_row = sess.step_bytes(1) - sess_b0
+    head_bytes = ((cfg['vocab_size'] + world - 1) // world) * cfg['hidden_size'] * 2
+    res['gemv_layer_bytes_per_step'] = sess_b0 - kv_row - head_bytes
+    sess.close()
+    del weights
+    torch.cuda.empty_cache()
+    return res
+
+
+def cpu_baseline(n_tokens, context):
+    """HF transformers LlamaForCausalLM on the host CPU (the reference's run_hf.py flow,
+    T/examples/llama_quant/run_hf.py:41-104, minus .cuda()): greedy decode of `n_tokens` tokens at batch 1 with a
+    `context`-token KV cache.  Bounded sample: synthetic weights tiled from a random pool, synthetic KV cache instead
+    of a CPU prefill (13 TFLOP), a handful of tokens."""
+    import torch
+    try:
+        import transformers
+        from transformers import LlamaConfig, LlamaForCausalLM
+        from transformers.cache_utils import DynamicCache
+    except Exception as e:  # pragma: no cover
+        return dict(value=None, unit='tokens/s', cores=os.cpu_count(), kind='reference', sample=f'transformers unavailable: {e}')
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 0
+    dtype = torch.float32 if avail > 80e9 else torch.bfloat16
+    torch.set_num_threads(cores)
+    cfg = LlamaConfig(hidden_size=4096, num_attention_heads=32, num_key_value_heads=32, intermediate_size=11008,
+                      vocab_size=32000, num_hidden_layers=32, max_position_embeddings=2048, rms_norm_eps=1e-6,
+                      attention_bias=False, tie_word_embeddings=False)
+    t_build = time.perf_counter()
+    with torch.device('meta'):
+        model = LlamaForCausalLM(cfg)
+    model = model.to_empty(device='cpu').to(dtype).eval()
+    pool = (torch.rand(1 << 24) * 2 - 1).mul_(0.02).to(dtype)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            flat = p.data.view(-1)
+            if 'norm' in name:
+                flat.fill_(1.0)
+                continue
+            n = flat.numel()
+            for off in range(0, n, pool.numel()):
+                m = min(pool.numel(), n - off)
+                flat[off:off + m].copy_(pool[:m])
+        # rotary buffers are not parameters: re-create them
+        if hasattr(model.model, 'rotary_emb'):
+            model.model.rotary_emb = type(model.model.rotary_emb)(config=cfg)
+    cache = DynamicCache(config=cfg) if 'config' in DynamicCache.__init__.__code__.co_varnames else DynamicCache()
+    kv = (torch.rand(1, 32, context, 128) * 2 - 1).to(dtype)
+    for li in range(32):
+        cache.update(kv.clone(), kv.clone(), li)
+    build_s = time.perf_counter() - t_build
+    ids = torch.tensor([[3]])
+    pos = context
+    with torch.no_grad():
+        # one untimed token (page-in), then the timed ones
+        out = model(input_ids=ids, past_key_values=cache, use_cache=True, position_ids=torch.tensor([[pos]]))
+        ids = out.logits[:, -1].argmax(-1, keepdim=True)
+        pos += 1
+        t0 = time.perf_counter()
+        for _ in range(n_tokens):
+            out = model(input_ids=ids, past_key_values=cache, use_cache=True, position_ids=torch.tensor([[pos]]))
+            ids = out.logits[:, -1].argmax(-1, keepdim=True)
+            pos += 1
+        dt = time.perf_counter() - t0
+    return dict(value=n_tokens / dt, unit='tokens/s', cores=cores, kind='reference',
+                sample=(f'HF transformers {transformers.__version__} LlamaForCausalLM (reference run_hf.py path) on the host CPU, '
+                        f'{str(dtype).split(".")[-1]}, {cores} threads, LLaMA-7B synthetic weights, batch 1, '
+                        f'{n_tokens} greedy decode steps at context {context} (synthetic KV cache, no prefill), '
+                        f'{dt:.1f} s timed, {build_s:.0f} s untimed model build'))
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        # TP communicator for the plugin library: rank 0's unique id -> everyone (replaces the MPI bootstrap)
+        import ctypes
+
+        from tensorrt_llm.plugin import capi
+        lib = capi.load_library()
+        idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            raw = (ctypes.c_char * 128)()
+            if lib.tllm_comm_get_unique_id(raw):
+                raise SystemExit(capi.last_error())
+            idbuf.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
+        dist.broadcast(idbuf, 0)
+        raw = (ctypes.c_char * 128).from_buffer_copy(bytes(idbuf.cpu().numpy().tobytes()))
+        group = (ctypes.c_int32 * world)(*range(world))
+        if lib.tllm_comm_init_rank(group, world, rank, raw):
+            raise SystemExit(capi.last_error())
+
+    res = run_config(torch, dist, args, args.config, rank, world, dev)
+    fp16 = None
+    if args.config != 'fp16' and not args.no_fp16_ref:
+        fp16 = run_config(torch, dist, args, 'fp16', rank, world, dev)
+    if rank != 0:
+        if dist:
+            dist.destroy_process_group()
+        return
+
+    prof = res['profile']
+    gemv_ms, gemv_n = prof['gemv_layer']
+    prof_steps = 8
+    avg_dur_s = gemv_ms * 1e-3 / max(gemv_n, 1)
+    bytes_per_launch = res['gemv_layer_bytes_per_step'] * prof_steps / max(gemv_n, 1)
+    achieved = bytes_per_launch / avg_dur_s / 1e9 if avg_dur_s > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(args.config, {}).get('gemv_layer_hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(args.cpu_tokens, args.context)
+        except Exception as e:
+            cpu = dict(value=None, unit='tokens/s', cores=os.cpu_count(), kind='reference', sample=f'failed: {e!r}')
+    names = {'sq': 'SmoothQuant per-channel int8 (act+weight) + int8 KV cache', 'woq8': 'weight-only int8 + int8 KV cache',
+             'woq4': 'weight-only int4 + int8 KV cache', 'fp16': 'fp16 + fp16 KV cache'}
+    line = {
+        'metric': 'decode tokens/sec LLaMA-7B int8' if args.config != 'fp16' else 'decode tokens/sec LLaMA-7B fp16',
+        'value': res['tokens_per_s'],
+        'unit': 'tokens/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': res['ms_per_step'],
+        'higher_is_better': True,
+        'scaling': 'strong',
+        'vs_baseline': None,
+        'dtype': {'sq': 'int8', 'woq8': 'f16', 'woq4': 'f16', 'fp16': 'f16'}[args.config],
+        'data': 'synthetic',
+        'config': {'workload': f'LLaMA-7B ({args.layers} layers) {names[args.config]}, batch 1, context {args.context} '
+                               f'(synthetic KV), greedy decode, TP={world}', 'global_batch': 1,
+                   'seq_len': args.context, 'parallelism': f'tp{world}'},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                     'kernel': 'gemv_kernel (layer GEMVs: QKV, O, gate|up, down)',
+                     'bytes_per_launch': bytes_per_launch, 'avg_launch_us': avg_dur_s * 1e6},
+        'cpu_baseline': cpu,
+        'step': {'hbm_bytes': res['step_bytes'], 'hbm_frac_of_peak': res['step_bytes'] / (res['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 'device_ms_per_step': res['dev_ms'] / args.steps, 'outputs_finite': res['finite'],
+                 'profile_ms_per_step': {k: v[0] / prof_steps for k, v in prof.items()},
+                 'launches_per_step': {k: v[1] / prof_steps for k, v in prof.items()}},
+    }
+    if fp16 is not None:
+        line['fp16_tokens_per_s'] = fp16['tokens_per_s']
+        line['int8_over_fp16'] = res['tokens_per_s'] / fp16['tokens_per_s']
+    print(json.dumps(line))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

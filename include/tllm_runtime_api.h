@@ -78,6 +78,14 @@ void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer);
  * algorithmic-bytes model of SURVEY.md §8(d), evaluated for this session's configuration. */
 int64_t tllm_session_step_bytes(tllm_session_t s, int32_t context_len);
 
+/* Instrumented generation steps (eager, a hipEvent pair around every launch) for the roofline report:
+ * elapsed milliseconds and launch counts per class over `n_steps` steps.
+ * Classes: 0 layer GEMVs (QKV, O, gate|up, down), 1 lm_head GEMV, 2 attention (split-KV + combine),
+ *          3 embedding + sampler, 4 tensor-parallel collectives.  Arrays of TLLM_PROFILE_CLASSES entries. */
+#define TLLM_PROFILE_CLASSES 5
+int32_t tllm_session_profile(tllm_session_t s, int32_t n_steps, float* ms_per_class, int64_t* launches_per_class,
+    tllm_stream_t stream);
+
 void tllm_session_destroy(tllm_session_t s);
 
 /* ------------------------------------------------------------------------------------------------
@@ -110,6 +118,8 @@ typedef struct
 int32_t tllm_gemv(const tllm_gemv_params_t* p, tllm_stream_t stream);
 /* Test/bench knob: rows of W per wave (0 = heuristic). */
 void tllm_gemv_set_rows_per_wave(int32_t r);
+/* Test/bench knob: persistent workgroups per CU (0 = occupancy query). */
+void tllm_gemv_set_blocks_per_cu(int32_t n);
 
 #ifdef __cplusplus
 }

@@ -73,30 +73,73 @@ __device__ __forceinline__ int sdot4(uint32_t a, uint32_t b, int c)
     return __builtin_amdgcn_sdot4((int) a, (int) b, c, false);
 }
 
-template <typename T>
-__device__ __forceinline__ T wave_sum(T v)
+// ---- wave64 reductions on the DPP network (no LDS crossbar round trips).
+// quad_perm xor1 / xor2 -> row_half_mirror -> row_mirror -> row_bcast:15 (rows 1,3) -> row_bcast:31 (rows 2,3);
+// the total lands in lane 63 and is broadcast through an SGPR (v_readlane).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int src, int old)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v += __shfl_xor(v, m, 64);
-    return v;
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#define TLLM_DPP_F(ctrl, mask) __builtin_bit_cast(float, dpp_i32<ctrl, mask>(__builtin_bit_cast(int, v), 0))
+    v += TLLM_DPP_F(0xB1, 0xf);  // quad_perm [1,0,3,2]
+    v += TLLM_DPP_F(0x4E, 0xf);  // quad_perm [2,3,0,1]
+    v += TLLM_DPP_F(0x141, 0xf); // row_half_mirror
+    v += TLLM_DPP_F(0x140, 0xf); // row_mirror
+    v += TLLM_DPP_F(0x142, 0xa); // row_bcast:15 -> rows 1, 3
+    v += TLLM_DPP_F(0x143, 0xc); // row_bcast:31 -> rows 2, 3
+#undef TLLM_DPP_F
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+    v += dpp_i32<0xB1, 0xf>(v, 0);
+    v += dpp_i32<0x4E, 0xf>(v, 0);
+    v += dpp_i32<0x141, 0xf>(v, 0);
+    v += dpp_i32<0x140, 0xf>(v, 0);
+    v += dpp_i32<0x142, 0xa>(v, 0);
+    v += dpp_i32<0x143, 0xc>(v, 0);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v = fmaxf(v, __shfl_xor(v, m, 64));
-    return v;
+    // `old` = the lane's own value: rows that a row_bcast step does not target keep max(v, v) = v
+#define TLLM_DPP_M(ctrl, mask)                                                                                         \
+    v = fmaxf(v, __builtin_bit_cast(float, dpp_i32<ctrl, mask>(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v))))
+    TLLM_DPP_M(0xB1, 0xf);
+    TLLM_DPP_M(0x4E, 0xf);
+    TLLM_DPP_M(0x141, 0xf);
+    TLLM_DPP_M(0x140, 0xf);
+    TLLM_DPP_M(0x142, 0xa);
+    TLLM_DPP_M(0x143, 0xc);
+#undef TLLM_DPP_M
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // Sum over groups of G consecutive lanes (G power of two <= 64); every lane of the group gets the total.
 template <int G>
 __device__ __forceinline__ float group_sum(float v)
 {
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1)
-        v += __shfl_xor(v, m, 64);
+    // DPP inside a 16-lane row (xor 1, xor 2, half-mirror, mirror); only G > 16 needs the LDS crossbar
+#define TLLM_DPP_G(ctrl) __builtin_bit_cast(float, dpp_i32<ctrl, 0xf>(__builtin_bit_cast(int, v), 0))
+    if constexpr (G >= 2)
+        v += TLLM_DPP_G(0xB1);
+    if constexpr (G >= 4)
+        v += TLLM_DPP_G(0x4E);
+    if constexpr (G >= 8)
+        v += TLLM_DPP_G(0x141);
+    if constexpr (G >= 16)
+        v += TLLM_DPP_G(0x140);
+#undef TLLM_DPP_G
+    if constexpr (G >= 32)
+        v += __shfl_xor(v, 16, 64);
+    if constexpr (G >= 64)
+        v += __shfl_xor(v, 32, 64);
     return v;
 }
 

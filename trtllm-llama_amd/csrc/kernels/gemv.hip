@@ -15,12 +15,17 @@
 #include "dev_utils.h"
 #include "kernels.h"
 #include "weight_layout.h"
+#include <algorithm>
+#include <map>
 
 namespace tllm
 {
 namespace kernels
 {
 using namespace dev;
+
+int gemv_tune_r = 0;             // test/bench override: rows per wave (0 = heuristic)
+int gemv_tune_blocks_per_cu = 0; // test/bench override: persistent workgroups per CU (0 = occupancy query)
 
 namespace
 {
@@ -139,7 +144,17 @@ __device__ __forceinline__ float silu_mul_fp16(float g, float u)
 }
 
 // ---- the kernel --------------------------------------------------------------------------------
-// LDS map: [0,128) reduction scratch | xh: MB rows of Kp fp16 (absent for raw-s8 input) | xq: MB rows of Kp s8 (SQ)
+// LDS map: [0,256) reduction scratch | xh: MB rows of Kp fp16 (absent for raw-s8 input) | xq: MB rows of Kp s8 (SQ)
+//
+// Latency structure (the per-launch floor matters: a 7B layer is 4 launches of 17-90 MB, i.e. 3-15 us each at HBM
+// speed): 1. the x (and gamma) vectors are requested first, 2. the first weight tile of every wave is requested
+// right behind them (it does not depend on x) and streams in while 3. the workgroup builds pro(x) in registers
+// (sum of squares -> one barrier -> normalise / quantise) and publishes it to LDS (one barrier); 4. dot products,
+// 5. cross-lane reduction + epilogue.  Further tiles (large N) are loaded in the loop; co-resident workgroups
+// (up to 8 per CU) overlap each other's phases.
+constexpr int kRedBytes = 256;
+constexpr int kNXV = 6; // x vectors (8 halfs) a thread keeps in registers: K <= 256 * 8 * 6 = 12288
+
 template <int WT, int R, int U, int MB>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 {
@@ -152,50 +167,207 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int K = p.K, Kp = a.Kp;
     float* red = reinterpret_cast<float*>(smem);
-    uint16_t* xh = reinterpret_cast<uint16_t*>(smem + 128);
-    int8_t* xq = reinterpret_cast<int8_t*>(smem + 128 + (size_t) a.xh_bytes * MB);
+    uint16_t* xh = reinterpret_cast<uint16_t*>(smem + kRedBytes);
+    int8_t* xq = reinterpret_cast<int8_t*>(smem + kRedBytes + (size_t) a.xh_bytes * MB);
     const bool x_is_half = !(SQ && p.pro == PRO_NONE);
     const bool do_norm = p.pro == PRO_RMSNORM || p.pro == PRO_RMSNORM_QSTATIC || p.pro == PRO_RMSNORM_QDYN;
     const bool q_static = p.pro == PRO_RMSNORM_QSTATIC || p.pro == PRO_QSTATIC;
     const bool q_dyn = p.pro == PRO_RMSNORM_QDYN || p.pro == PRO_QDYN;
     float row_scale[MB]; // per-token dequant scale when the prologue quantises dynamically
-
-    // ------------------------------------------------------------------ prologue: build pro(x) in LDS
 #pragma unroll
     for (int m = 0; m < MB; ++m)
-    {
         row_scale[m] = 1.f;
-        if (m >= p.M)
-            continue;
-        if (x_is_half)
-        {
-            const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * p.ldx;
-            uint16_t* xs = xh + (size_t) m * Kp;
-            float ss = 0.f;
-            const bool vec_ok = ((K & 7) == 0) && ((p.ldx & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
-            if (vec_ok)
-            {
-                for (int k = tid * 8; k < Kp; k += 256 * 8)
-                {
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (k < K)
-                        v = *reinterpret_cast<const uint4*>(xg + k);
-                    *reinterpret_cast<uint4*>(xs + k) = v;
-                    if (do_norm)
-                    {
-                        const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+
+    // ------------------------------------------------------------------ weight-tile helpers
+    const bool swiglu = p.epi == EPI_SWIGLU || p.epi == EPI_SWIGLU_QSTATIC;
+    const char* wbase = reinterpret_cast<const char*>(p.w);
+    const char* wup = p.w_up ? reinterpret_cast<const char*>(p.w_up) : wbase + (int64_t) p.N * p.ldw;
+    const int lane_kbyte = lane * 16; // byte offset of this lane's vector inside a chunk row
+
+    auto rows_of_group = [&](int g, const char* (&rowptr)[R]) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                        {
-                            h2_t h = u32_as_h2(ws[j]);
-                            const float f0 = (float) h.x, f1 = (float) h.y;
-                            ss += f0 * f0 + f1 * f1;
-                        }
-                    }
-                }
+        for (int r = 0; r < R; ++r)
+        {
+            if (swiglu)
+            {
+                const int o = g * (R / 2) + (r % (R / 2 > 0 ? R / 2 : 1));
+                rowptr[r] = ((r < R / 2) ? wbase : wup) + (o < p.N ? (int64_t) o * p.ldw : 0);
             }
             else
             {
+                const int row = g * R + r;
+                rowptr[r] = wbase + (row < p.N ? (int64_t) row * p.ldw : 0);
+            }
+        }
+    };
+    auto load_tile = [&](const char* const (&rowptr)[R], int c, uint4 (&wv)[U][R]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            const bool ok = ((c + u) * 64 + lane) * VEC < Kp;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+            {
+                wv[u][r] = make_uint4(0, 0, 0, 0);
+                if (ok)
+                    wv[u][r] = ld_nt16(rowptr[r] + (int64_t) (c + u) * 1024 + lane_kbyte);
+            }
+        }
+    };
+
+    // ------------------------------------------------------------------ prologue
+    const uint16_t* gam = reinterpret_cast<const uint16_t*>(p.gamma);
+    const bool vec_half = x_is_half && ((K & 7) == 0) && ((p.ldx & 7) == 0)
+        && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) && (!do_norm || (reinterpret_cast<uintptr_t>(p.gamma) & 15) == 0);
+    const bool reg_path = vec_half && Kp <= 256 * 8 * kNXV;
+
+    // 1. request x (row 0) and gamma
+    uint4 xv[kNXV], gv[kNXV];
+    if (reg_path)
+    {
+        const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x);
+#pragma unroll
+        for (int j = 0; j < kNXV; ++j)
+        {
+            const int k = (tid + j * 256) * 8;
+            xv[j] = make_uint4(0, 0, 0, 0);
+            gv[j] = make_uint4(0, 0, 0, 0);
+            if (k < K)
+            {
+                xv[j] = *reinterpret_cast<const uint4*>(xg + k);
+                if (do_norm)
+                    gv[j] = *reinterpret_cast<const uint4*>(gam + k);
+            }
+        }
+    }
+    // 2. request the first weight tile of this wave
+    const int g0 = blockIdx.x * 4 + wid;
+    const char* rowptr[R];
+    uint4 wv[U][R];
+    rows_of_group(g0 < a.ngroups ? g0 : 0, rowptr);
+    load_tile(rowptr, 0, wv);
+
+    // 3. build pro(x) in LDS
+    if (reg_path)
+    {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+        {
+            if (m >= p.M)
+                continue;
+            if (m > 0)
+            {
+                const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * p.ldx;
+#pragma unroll
+                for (int j = 0; j < kNXV; ++j)
+                {
+                    const int k = (tid + j * 256) * 8;
+                    xv[j] = (k < K) ? *reinterpret_cast<const uint4*>(xg + k) : make_uint4(0, 0, 0, 0);
+                }
+            }
+            float inv = 1.f;
+            if (do_norm)
+            {
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < kNXV; ++j)
+                {
+                    const uint32_t ws[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                    {
+                        const h2_t h = u32_as_h2(ws[q]);
+                        const float f0 = (float) h.x, f1 = (float) h.y;
+                        ss += f0 * f0 + f1 * f1;
+                    }
+                }
+                ss = wave_sum(ss);
+                if (lane == 0)
+                    red[m * 4 + wid] = ss;
+                __syncthreads();
+                ss = red[m * 4] + red[m * 4 + 1] + red[m * 4 + 2] + red[m * 4 + 3];
+                inv = 1.0f / sqrtf(ss / (float) K + p.eps);
+            }
+            float amax = 0.f;
+            if (do_norm || q_dyn)
+            {
+#pragma unroll
+                for (int j = 0; j < kNXV; ++j)
+                {
+                    uint32_t xs4[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+                    const uint32_t gs4[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                    {
+                        h2_t h = u32_as_h2(xs4[q]);
+                        if (do_norm)
+                        {
+                            const h2_t gg = u32_as_h2(gs4[q]);
+                            const float n0 = h2f(f2h((float) h.x * inv)), n1 = h2f(f2h((float) h.y * inv));
+                            h.x = (_Float16) (n0 * (float) gg.x);
+                            h.y = (_Float16) (n1 * (float) gg.y);
+                            xs4[q] = h2_as_u32(h);
+                        }
+                        amax = fmaxf(amax, fmaxf(fabsf((float) h.x), fabsf((float) h.y)));
+                    }
+                    xv[j] = make_uint4(xs4[0], xs4[1], xs4[2], xs4[3]);
+                }
+            }
+            float qs = 1.f;
+            if (SQ && q_dyn)
+            {
+                amax = wave_max(amax);
+                if (lane == 0)
+                    red[32 + m * 4 + wid] = amax;
+                __syncthreads();
+                amax = fmaxf(fmaxf(red[32 + m * 4], red[32 + m * 4 + 1]), fmaxf(red[32 + m * 4 + 2], red[32 + m * 4 + 3]));
+                amax = fmaxf(amax, h2f(f2h(1e-6f))); // T localMax = 1e-6f (K/quantization.cu:101)
+                qs = 127.f / amax;
+                row_scale[m] = amax / 127.f;
+                if (blockIdx.x == 0 && tid == 0 && p.dyn_scale_out)
+                    p.dyn_scale_out[m] = amax / 127.f;
+            }
+            else if (SQ && q_static)
+                qs = p.act_scale[0];
+#pragma unroll
+            for (int j = 0; j < kNXV; ++j)
+            {
+                const int k = (tid + j * 256) * 8;
+                if (k < Kp)
+                {
+                    if (SQ)
+                    {
+                        const uint32_t ws[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+                        uint32_t o[2] = {0, 0};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                        {
+                            const h2_t h = u32_as_h2(ws[q]);
+                            const uint32_t b0 = (uint8_t) f2i8_rni_sat((float) h.x * qs);
+                            const uint32_t b1 = (uint8_t) f2i8_rni_sat((float) h.y * qs);
+                            o[q >> 1] |= (b0 | (b1 << 8)) << (16 * (q & 1));
+                        }
+                        *reinterpret_cast<uint2*>(xq + (size_t) m * Kp + k) = make_uint2(o[0], o[1]);
+                    }
+                    else
+                        *reinterpret_cast<uint4*>(xh + (size_t) m * Kp + k) = xv[j];
+                }
+            }
+        }
+    }
+    else
+    {
+        // generic path (unaligned / very long x): through LDS, scalar passes
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+        {
+            if (m >= p.M)
+                continue;
+            if (x_is_half)
+            {
+                const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * p.ldx;
+                uint16_t* xs = xh + (size_t) m * Kp;
+                float ss = 0.f;
                 for (int k = tid; k < Kp; k += 256)
                 {
                     const uint16_t b = k < K ? xg[k] : (uint16_t) 0;
@@ -203,275 +375,270 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
                     const float f = h2f(b);
                     ss += f * f;
                 }
-            }
-            float amax = 0.f;
-            if (do_norm)
-            {
-                ss = block_sum(ss, red);
-                const float inv = 1.0f / sqrtf(ss / (float) K + p.eps);
-                const uint16_t* g = reinterpret_cast<const uint16_t*>(p.gamma);
-                for (int k = tid; k < K; k += 256)
+                float amax = 0.f;
+                if (do_norm)
                 {
-                    const float n16 = h2f(f2h(h2f(xs[k]) * inv));
-                    const uint16_t yb = f2h(n16 * h2f(g[k]));
-                    xs[k] = yb;
-                    amax = fmaxf(amax, fabsf(h2f(yb)));
+                    ss = block_sum(ss, red);
+                    const float inv = 1.0f / sqrtf(ss / (float) K + p.eps);
+                    for (int k = tid; k < K; k += 256)
+                    {
+                        const float n16 = h2f(f2h(h2f(xs[k]) * inv));
+                        const uint16_t yb = f2h(n16 * h2f(gam[k]));
+                        xs[k] = yb;
+                        amax = fmaxf(amax, fabsf(h2f(yb)));
+                    }
                 }
-            }
-            else
-            {
-                __syncthreads();
-                if (q_dyn)
+                else if (q_dyn)
                     for (int k = tid; k < K; k += 256)
                         amax = fmaxf(amax, fabsf(h2f(xs[k])));
-            }
-            if (SQ && (q_static || q_dyn))
-            {
-                float qs;
-                if (q_dyn)
+                if (SQ && (q_static || q_dyn))
                 {
-                    amax = block_max(amax, red);
-                    amax = fmaxf(amax, h2f(f2h(1e-6f))); // T localMax = 1e-6f (K/quantization.cu:101)
-                    qs = 127.f / amax;
-                    row_scale[m] = amax / 127.f;
-                    if (blockIdx.x == 0 && tid == 0 && p.dyn_scale_out)
-                        p.dyn_scale_out[m] = amax / 127.f;
+                    float qs;
+                    if (q_dyn)
+                    {
+                        amax = block_max(amax, red);
+                        amax = fmaxf(amax, h2f(f2h(1e-6f)));
+                        qs = 127.f / amax;
+                        row_scale[m] = amax / 127.f;
+                        if (blockIdx.x == 0 && tid == 0 && p.dyn_scale_out)
+                            p.dyn_scale_out[m] = amax / 127.f;
+                    }
+                    else
+                        qs = p.act_scale[0];
+                    int8_t* qd = xq + (size_t) m * Kp;
+                    for (int k = tid; k < Kp; k += 256)
+                        qd[k] = k < K ? f2i8_rni_sat(h2f(xs[k]) * qs) : (int8_t) 0;
                 }
-                else
-                {
-                    __syncthreads();
-                    qs = p.act_scale[0];
-                }
-                int8_t* qd = xq + (size_t) m * Kp;
-                for (int k = tid; k < Kp; k += 256)
-                    qd[k] = k < K ? f2i8_rni_sat(h2f(xs[k]) * qs) : (int8_t) 0;
-            }
-            if (blockIdx.x == 0 && p.x_pro_out && p.pro != PRO_NONE)
-            {
                 __syncthreads();
-                if (SQ)
-                {
-                    int8_t* o = reinterpret_cast<int8_t*>(p.x_pro_out) + (int64_t) m * K;
-                    const int8_t* qd = xq + (size_t) m * Kp;
-                    for (int k = tid; k < K; k += 256)
-                        o[k] = qd[k];
-                }
-                else
-                {
-                    uint16_t* o = reinterpret_cast<uint16_t*>(p.x_pro_out) + (int64_t) m * K;
-                    for (int k = tid; k < K; k += 256)
-                        o[k] = xs[k];
-                }
-            }
-        }
-        else
-        {
-            // raw s8 activations (SmoothQuantGemm plugin input 0)
-            const int8_t* xg = reinterpret_cast<const int8_t*>(p.x) + (int64_t) m * p.ldx;
-            int8_t* qd = xq + (size_t) m * Kp;
-            const bool vec_ok = ((K & 15) == 0) && ((p.ldx & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
-            if (vec_ok)
-            {
-                for (int k = tid * 16; k < Kp; k += 256 * 16)
-                    *reinterpret_cast<uint4*>(qd + k) = *reinterpret_cast<const uint4*>(xg + k);
             }
             else
             {
-                for (int k = tid; k < Kp; k += 256)
-                    qd[k] = k < K ? xg[k] : (int8_t) 0;
+                // raw s8 activations (SmoothQuantGemm plugin input 0)
+                const int8_t* xg = reinterpret_cast<const int8_t*>(p.x) + (int64_t) m * p.ldx;
+                int8_t* qd = xq + (size_t) m * Kp;
+                const bool vec_ok = ((K & 15) == 0) && ((p.ldx & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+                if (vec_ok)
+                {
+                    for (int k = tid * 16; k < Kp; k += 256 * 16)
+                        *reinterpret_cast<uint4*>(qd + k) = *reinterpret_cast<const uint4*>(xg + k);
+                }
+                else
+                {
+                    for (int k = tid; k < Kp; k += 256)
+                        qd[k] = k < K ? xg[k] : (int8_t) 0;
+                }
             }
         }
     }
     __syncthreads();
-
-    // ------------------------------------------------------------------ main loop over row groups
-    const bool swiglu = p.epi == EPI_SWIGLU || p.epi == EPI_SWIGLU_QSTATIC;
-    constexpr int OUTS = R; // outputs per group when !swiglu; R/2 when swiglu
-    const char* wbase = reinterpret_cast<const char*>(p.w);
-    const int lane_kbyte = lane * 16; // byte offset of this lane's vector inside a chunk row
-
-    for (int g = blockIdx.x * 4 + wid; g < a.ngroups; g += gridDim.x * 4)
+    if (blockIdx.x == 0 && p.x_pro_out && p.pro != PRO_NONE)
     {
-        // weight rows of this group
-        int64_t rowoff[R];
-        bool rvalid[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r)
+        for (int m = 0; m < MB && m < p.M; ++m)
         {
-            int row;
-            if (swiglu)
+            if (SQ)
             {
-                const int o = g * (R / 2) + (r % (R / 2 > 0 ? R / 2 : 1));
-                rvalid[r] = o < p.N;
-                row = (r < R / 2) ? o : p.N + o;
+                int8_t* o = reinterpret_cast<int8_t*>(p.x_pro_out) + (int64_t) m * K;
+                for (int k = tid; k < K; k += 256)
+                    o[k] = xq[(size_t) m * Kp + k];
             }
             else
             {
-                row = g * R + r;
-                rvalid[r] = row < p.N;
+                uint16_t* o = reinterpret_cast<uint16_t*>(p.x_pro_out) + (int64_t) m * K;
+                for (int k = tid; k < K; k += 256)
+                    o[k] = xh[(size_t) m * Kp + k];
             }
-            rowoff[r] = rvalid[r] ? (int64_t) row * p.ldw : 0;
         }
+    }
 
-        acc_t acc[R][MB];
+    // ------------------------------------------------------------------ main loop
+    // Persistent waves: wave w of workgroup b owns row groups g0, g0 + stride, ...; its tiles (U chunks x R rows,
+    // 16-byte loads) are double-buffered: while tile t is being reduced, tile t+1 is in flight, and the epilogue
+    // operands (scales, residual) of t are requested BEFORE t+1 so that waiting for them never drains the stream.
+    const int gstride = gridDim.x * 4;
+    const int tiles_per_group = (a.nchunks + U - 1) / U;
+    const int ngroups_mine = g0 < a.ngroups ? (a.ngroups - g0 + gstride - 1) / gstride : 0;
+    const int ntiles = ngroups_mine * tiles_per_group;
+    const int nouts = swiglu ? R / 2 : R;
+    const int my_o = lane / MB, my_m = lane % MB; // the (output, row) this lane finishes
+    const bool my_active = my_o < nouts && my_m < p.M;
+    float my_row_scale = 1.f;
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-                acc[r][m] = 0;
+    for (int m = 0; m < MB; ++m)
+        if (m == my_m)
+            my_row_scale = row_scale[m];
+    if constexpr (SQ)
+    {
+        if (!q_dyn && my_active)
+            my_row_scale = p.per_token ? p.scale_row[my_m] : p.scale_row[0];
+    }
 
-        for (int c = 0; c < a.nchunks; c += U)
+    acc_t acc[R][MB];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            acc[r][m] = 0;
+
+    uint4 wv2[U][R];
+    int t_issue = 1, gi_i = 0, ci_i = 1; // tile 0 is already in flight in `wv`
+    if (ci_i == tiles_per_group)
+    {
+        ci_i = 0;
+        gi_i = 1;
+    }
+    int gi_p = 0, ci_p = 0;
+
+    auto step = [&](uint4 (&cur)[U][R], uint4 (&nxt)[U][R]) {
+        const bool last = ci_p == tiles_per_group - 1;
+        const int g = g0 + gi_p * gstride;
+        const int n = swiglu ? g * (R / 2) + my_o : g * R + my_o;
+        const bool fin = last && my_active && n < p.N;
+        // (1) epilogue operands of this group
+        float s0 = 1.f, s1 = 1.f, resv = 0.f;
+        const int64_t oidx = (int64_t) my_m * p.ldy + n;
+        if (fin)
         {
-            uint4 wv[U][R];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
+            if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
             {
-                const int kv = (c + u) * 64 + lane; // vector index along k
-                const bool ok = kv * VEC < Kp;
-#pragma unroll
-                for (int r = 0; r < R; ++r)
+                const uint16_t* sc = reinterpret_cast<const uint16_t*>(p.scale_col);
+                s0 = h2f(sc[n]);
+                if (swiglu)
+                    s1 = p.scale_col_up ? h2f(reinterpret_cast<const uint16_t*>(p.scale_col_up)[n]) : h2f(sc[p.N + n]);
+            }
+            else if constexpr (SQ)
+            {
+                const float* sc = reinterpret_cast<const float*>(p.scale_col);
+                s0 = (p.per_channel ? sc[n] : sc[0]) * my_row_scale;
+                if (swiglu)
                 {
-                    wv[u][r] = make_uint4(0, 0, 0, 0);
-                    if (ok)
-                        wv[u][r] = ld_nt16(wbase + rowoff[r] + (int64_t) (c + u) * 1024 + lane_kbyte);
+                    const float* su = reinterpret_cast<const float*>(p.scale_col_up);
+                    const float sru = (!q_dyn && p.scale_row_up) ? p.scale_row_up[0] : my_row_scale;
+                    s1 = (su ? (p.per_channel ? su[n] : su[0]) : (p.per_channel ? sc[p.N + n] : sc[0])) * sru;
                 }
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
+            if (p.epi == EPI_RESIDUAL)
+                resv = h2f(reinterpret_cast<const uint16_t*>(p.residual)[oidx]);
+        }
+        // (2) next tile into the other buffer
+        if (t_issue < ntiles)
+        {
+            if (ci_i == 0)
+                rows_of_group(g0 + gi_i * gstride, rowptr);
+            load_tile(rowptr, ci_i * U, nxt);
+            ++t_issue;
+            if (++ci_i == tiles_per_group)
             {
-                const int k0 = ((c + u) * 64 + lane) * VEC;
-                if (k0 < Kp)
+                ci_i = 0;
+                ++gi_i;
+            }
+        }
+        // (3) dot products of the current tile
+        const int c = ci_p * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+        {
+            const int k0 = ((c + u) * 64 + lane) * VEC;
+            if (k0 < Kp)
+            {
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
                 {
-#pragma unroll
-                    for (int m = 0; m < MB; ++m)
+                    if constexpr (WT == W_FP16)
                     {
-                        if constexpr (WT == W_FP16)
-                        {
-                            const uint4 xv = *reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0);
+                        const uint4 xa = *reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0);
 #pragma unroll
-                            for (int r = 0; r < R; ++r)
-                                acc[r][m] = dot_fp16(wv[u][r], xv, acc[r][m]);
-                        }
-                        else if constexpr (WT == W_INT8_WOQ)
-                        {
-                            const uint4 xa = *reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0);
-                            const uint4 xb = *reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0 + 8);
+                        for (int r = 0; r < R; ++r)
+                            acc[r][m] = dot_fp16(cur[u][r], xa, acc[r][m]);
+                    }
+                    else if constexpr (WT == W_INT8_WOQ)
+                    {
+                        const uint4 xa = *reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0);
+                        const uint4 xb = *reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0 + 8);
 #pragma unroll
-                            for (int r = 0; r < R; ++r)
-                                acc[r][m] = dot_woq8(wv[u][r], xa, xb, acc[r][m]);
-                        }
-                        else if constexpr (WT == W_INT4_WOQ)
-                        {
-                            const uint4* xp = reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0);
-                            const uint4 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+                        for (int r = 0; r < R; ++r)
+                            acc[r][m] = dot_woq8(cur[u][r], xa, xb, acc[r][m]);
+                    }
+                    else if constexpr (WT == W_INT4_WOQ)
+                    {
+                        const uint4* xp = reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0);
+                        const uint4 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
 #pragma unroll
-                            for (int r = 0; r < R; ++r)
-                            {
-                                float t = acc[r][m];
-                                t = dot_u4x8(wv[u][r].x, x0, t);
-                                t = dot_u4x8(wv[u][r].y, x1, t);
-                                t = dot_u4x8(wv[u][r].z, x2, t);
-                                t = dot_u4x8(wv[u][r].w, x3, t);
-                                acc[r][m] = t;
-                            }
-                        }
-                        else
+                        for (int r = 0; r < R; ++r)
                         {
-                            const uint4 xv = *reinterpret_cast<const uint4*>(xq + (size_t) m * Kp + k0);
-#pragma unroll
-                            for (int r = 0; r < R; ++r)
-                                acc[r][m] = dot_sq(wv[u][r], xv, acc[r][m]);
+                            float tt = acc[r][m];
+                            tt = dot_u4x8(cur[u][r].x, x0, tt);
+                            tt = dot_u4x8(cur[u][r].y, x1, tt);
+                            tt = dot_u4x8(cur[u][r].z, x2, tt);
+                            tt = dot_u4x8(cur[u][r].w, x3, tt);
+                            acc[r][m] = tt;
                         }
+                    }
+                    else
+                    {
+                        const uint4 xa = *reinterpret_cast<const uint4*>(xq + (size_t) m * Kp + k0);
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            acc[r][m] = dot_sq(cur[u][r], xa, acc[r][m]);
                     }
                 }
             }
         }
-
-        // ---- cross-lane reduction: every lane ends with every total
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-                acc[r][m] = wave_sum(acc[r][m]);
-
-        // ---- epilogue: lane (o * MB + m) finishes output o of row m
-        const int nouts = swiglu ? R / 2 : OUTS;
-        float v0 = 0.f, v1 = 0.f; // scaled accumulators picked by this lane (v1: the "up" row for swiglu)
+        if (!last)
+        {
+            ++ci_p;
+            return;
+        }
+        ci_p = 0;
+        ++gi_p;
+        // (4) cross-lane reduction (every lane gets every total), then lane (o * MB + m) finishes output o of row m
+        float v0 = 0.f, v1 = 0.f;
         int ai = 0;
-        int my_o = -1, my_m = 0;
 #pragma unroll
-        for (int o = 0; o < R; ++o)
-        {
+        for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int m = 0; m < MB; ++m)
             {
-                if (o < nouts && lane == o * MB + m)
+                const acc_t tot = wave_sum(acc[r][m]);
+                acc[r][m] = 0;
+                if (r < nouts && lane == r * MB + m)
                 {
-                    my_o = o;
-                    my_m = m;
-                    ai = (int) acc[o][m];
-                    v0 = (float) acc[o][m];
-                    if (swiglu)
-                        v1 = (float) acc[(o + R / 2) % R][m];
+                    ai = (int) tot;
+                    v0 = (float) tot;
                 }
+                if (swiglu && r >= R / 2 && lane == (r - R / 2) * MB + m)
+                    v1 = (float) tot;
             }
-        }
-        if (my_o >= 0 && my_m < p.M)
+        if (!fin)
+            return;
+        const float r0 = v0 * s0;
+        if (p.epi == EPI_NONE)
         {
-            const int n = swiglu ? g * (R / 2) + my_o : g * R + my_o;
-            if (n < p.N)
-            {
-                // column / row scales
-                float s0 = 1.f, s1 = 1.f;
-                if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
-                {
-                    const uint16_t* sc = reinterpret_cast<const uint16_t*>(p.scale_col);
-                    s0 = h2f(sc[n]);
-                    if (swiglu)
-                        s1 = h2f(sc[p.N + n]);
-                }
-                else if constexpr (SQ)
-                {
-                    const float* sc = reinterpret_cast<const float*>(p.scale_col);
-                    const float sr = q_dyn ? row_scale[0] : (p.per_token ? p.scale_row[my_m] : p.scale_row[0]);
-                    float srm = sr;
-                    if (q_dyn)
-                    {
-#pragma unroll
-                        for (int m = 0; m < MB; ++m)
-                            if (m == my_m)
-                                srm = row_scale[m];
-                    }
-                    s0 = (p.per_channel ? sc[n] : sc[0]) * srm;
-                    if (swiglu)
-                        s1 = (p.per_channel ? sc[p.N + n] : sc[0]) * srm;
-                }
-                const float r0 = v0 * s0;
-                const int64_t oidx = (int64_t) my_m * p.ldy + n;
-                if (p.epi == EPI_NONE)
-                {
-                    if (p.out_dtype == DT_HALF)
-                        reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(r0);
-                    else if (p.out_dtype == DT_FLOAT)
-                        reinterpret_cast<float*>(p.y)[oidx] = r0;
-                    else
-                        reinterpret_cast<int32_t*>(p.y)[oidx] = SQ ? ai : (int32_t) r0;
-                }
-                else if (p.epi == EPI_RESIDUAL)
-                {
-                    const float res = h2f(reinterpret_cast<const uint16_t*>(p.residual)[oidx]);
-                    reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(h2f(f2h(r0)) + res);
-                }
-                else
-                {
-                    const float o16 = silu_mul_fp16(r0, v1 * s1);
-                    if (p.epi == EPI_SWIGLU)
-                        reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(o16);
-                    else
-                        reinterpret_cast<int8_t*>(p.y)[oidx] = f2i8_rni_sat(o16 * p.epi_scale[0]);
-                }
-            }
+            if (p.out_dtype == DT_HALF)
+                reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(r0);
+            else if (p.out_dtype == DT_FLOAT)
+                reinterpret_cast<float*>(p.y)[oidx] = r0;
+            else
+                reinterpret_cast<int32_t*>(p.y)[oidx] = SQ ? ai : (int32_t) r0;
         }
+        else if (p.epi == EPI_RESIDUAL)
+            reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(h2f(f2h(r0)) + resv);
+        else
+        {
+            const float o16 = silu_mul_fp16(r0, v1 * s1);
+            if (p.epi == EPI_SWIGLU)
+                reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(o16);
+            else
+                reinterpret_cast<int8_t*>(p.y)[oidx] = f2i8_rni_sat(o16 * p.epi_scale[0]);
+        }
+    };
+
+    for (int t = 0; t < ntiles;)
+    {
+        step(wv, wv2);
+        if (++t >= ntiles)
+            break;
+        step(wv2, wv);
+        ++t;
     }
 }
 
@@ -488,6 +655,32 @@ int launch_inst(const GemvArgs& a, int blocks, size_t smem, hipStream_t stream)
             attr_done = true;
         }
     }
+    // persistent grid: no more workgroups than the chip holds at once
+    static int cus = 0;
+    static std::map<size_t, int> occ_cache;
+    if (!cus)
+    {
+        int dev = 0;
+        (void) hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    auto it = occ_cache.find(smem);
+    if (it == occ_cache.end())
+    {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 256, smem) != hipSuccess || nb < 1)
+            nb = 2;
+        it = occ_cache.emplace(smem, nb > 8 ? 8 : nb).first;
+    }
+    const int max_blocks = cus * (gemv_tune_blocks_per_cu > 0 ? gemv_tune_blocks_per_cu : it->second);
+    if (blocks > max_blocks)
+    {
+        // every wave gets the same number of row groups (a ragged last round costs a whole extra tile time)
+        const int waves = max_blocks * 4;
+        const int groups_per_wave = (a.ngroups + waves - 1) / waves;
+        blocks = (a.ngroups + 4 * groups_per_wave - 1) / (4 * groups_per_wave);
+    }
     hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), smem, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -503,17 +696,16 @@ int launch_mb(const GemvArgs& a, int blocks, size_t smem_per_m, hipStream_t stre
 {
     const int M = a.p.M;
     if (M <= 1)
-        return launch_inst<WT, R, U, 1>(a, blocks, 128 + smem_per_m, stream);
+        return launch_inst<WT, R, U, 1>(a, blocks, kRedBytes + smem_per_m, stream);
     if (M <= 2)
-        return launch_inst<WT, R, U, 2>(a, blocks, 128 + 2 * smem_per_m, stream);
+        return launch_inst<WT, R, U, 2>(a, blocks, kRedBytes + 2 * smem_per_m, stream);
     if (M <= 4)
-        return launch_inst<WT, R, U, 4>(a, blocks, 128 + 4 * smem_per_m, stream);
-    return launch_inst<WT, R, U, 8>(a, blocks, 128 + 8 * smem_per_m, stream);
+        return launch_inst<WT, R, U, 4>(a, blocks, kRedBytes + 4 * smem_per_m, stream);
+    return launch_inst<WT, R, U, 8>(a, blocks, kRedBytes + 8 * smem_per_m, stream);
 }
 
 } // namespace
 
-int gemv_tune_r = 0; // test/bench override: rows per wave (0 = heuristic)
 
 int launch_gemv(const GemvParams& p, hipStream_t stream)
 {
@@ -561,7 +753,7 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     a.xh_bytes = x_is_half ? a.Kp * 2 : 0;
     const size_t smem_per_m = (size_t) a.xh_bytes + (sq ? (size_t) a.Kp : 0);
     const int mb = p.M <= 1 ? 1 : (p.M <= 2 ? 2 : (p.M <= 4 ? 4 : 8));
-    if (128 + mb * smem_per_m > 160 * 1024)
+    if (kRedBytes + mb * smem_per_m > 160 * 1024)
     {
         set_error("gemv: K=%d x M=%d does not fit LDS", p.K, p.M);
         return -1;
@@ -580,7 +772,7 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     const int outs_per_group = swiglu ? R / 2 : R;
     a.ngroups = (p.N + outs_per_group - 1) / outs_per_group;
     int blocks = (a.ngroups + 3) / 4;
-    const int max_blocks = 256 * 8;
+    const int max_blocks = 256 * 16;
     if (blocks > max_blocks)
         blocks = max_blocks;
 

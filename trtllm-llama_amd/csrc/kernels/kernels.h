@@ -64,7 +64,10 @@ struct GemvParams
     int64_t ldx = 0;             // elements
     const void* w = nullptr;
     int64_t ldw = 0;                  // bytes per weight row, multiple of 16
-    const void* scale_col = nullptr;  // WOQ: fp16 [N(*2 for swiglu)]; SQ: f32 [N] or [1]
+    const void* w_up = nullptr;       // SWIGLU: the "up" matrix (mlp.gate) [N, ldw]; null => rows [N, 2N) of w
+    const void* scale_col = nullptr;  // WOQ: fp16 [N]; SQ: f32 [N] or [1]
+    const void* scale_col_up = nullptr; // SWIGLU: scales of w_up; null => scale_col + N (per-channel) / scale_col
+    const float* scale_row_up = nullptr; // SWIGLU + SQ static: act_scale of the up GEMM [1]; null => scale_row
     const float* scale_row = nullptr; // SQ: f32 [M] or [1] (ignored when the prologue quantises per token)
     int32_t per_channel = 0, per_token = 0;
     const void* gamma = nullptr; // fp16 [K]
@@ -143,6 +146,9 @@ struct MmhaParams
 };
 size_t mmha_workspace_size(int32_t batch, int32_t num_heads, int32_t head_size, int32_t max_seq_len);
 int launch_mmha(const MmhaParams& p, hipStream_t stream);
+// The split-merge tickets at the head of the workspace must be zero before the FIRST launch on it (every launch
+// re-arms them): plugins call this per enqueue, the session once per setup.
+int mmha_reset_workspace(void* workspace, int32_t batch, int32_t num_heads, hipStream_t stream);
 
 // RoPE table builder (host -> device buffer owned by caller): cos/sin(pos / 10000^(2j/rot)) in fp32,
 // formula of K/decoderMaskedMultiheadAttentionUtils.h:1511-1515.

@@ -1,11 +1,15 @@
 // Decode-step masked multi-head attention for gfx950.
 //
 // Reference: masked_multihead_attention_kernel, MM/decoderMaskedMultiheadAttentionTemplate.h:1195-2183
-// (one CTA per (head, batch); 32 CTAs at B=1 cannot feed 256 CUs).  Here the KV range of every (batch, head)
-// is split over workgroups of 4 waves (grid = splits x H x B); each wave keeps 8 K rows and 8 V rows per
-// lane-group in flight as 16-byte (fp16) / 8-byte (int8) loads issued up front, computes the scores with
-// v_dot2_f32_f16 + intra-group shuffles, an online softmax per wave, P.V from registers, and the wave / block /
-// split partials {max, sum, out[Dh]} are merged by a tiny second kernel (flash-decoding).
+// (one CTA per (head, batch); 32 CTAs at B=1 cannot feed 256 CUs; its multi-block mode, :2019-2181, splits the
+// KV range over gridDim.z CTAs and lets the last CTA to arrive — an atomic counter — rescale and reduce).
+// Here the KV range of every (batch, head) is always split over workgroups of 4 waves (grid = splits x H x B).
+// A group of Dh/8 lanes owns one cache row per load instruction (16 B per lane for fp16, 8 B for int8) and
+// keeps NIT rows of K and of V in flight, all requested before anything else is computed; scores with
+// v_dot2_f32_f16 + a DPP sum inside the lane group; an independent softmax partial {max, sum, out[Dh]} per lane
+// group (no cross-group shuffles), merged per workgroup through LDS, published per split, and the last
+// workgroup of a (batch, head) to arrive (agent-scope release / atomic ticket / acquire) merges the splits
+// (flash-decoding) and writes the fp16 context.
 //
 // Numerics follow SURVEY Appendix A.1: RoPE in fp32 -> fp16; int8 cache store = sat(rni(float(k16) * s)),
 // load = fp16(float(q8) * s^-1); q.k products fp32-accumulated, * inv_sqrt_dh in fp32; masked positions are
@@ -28,15 +32,15 @@ using namespace dev;
 namespace
 {
 
-constexpr int kRowsPerLane = 8; // cache rows each lane-group keeps in flight per wave
+constexpr int kWaves = 4; // 256-thread workgroups
 
-template <int DH>
+template <int DH, int NIT>
 struct MmhaGeom
 {
-    static constexpr int LPR = DH / 8;         // lanes per cache row (8 elements per lane)
-    static constexpr int RPW = 64 / LPR;       // rows per wave instruction
-    static constexpr int WAVE_ROWS = RPW * kRowsPerLane;
-    static constexpr int TCHUNK = 4 * WAVE_ROWS; // timesteps per workgroup
+    static constexpr int LPR = DH / 8;        // lanes per cache row (8 elements per lane)
+    static constexpr int RPW = 64 / LPR;      // rows per wave instruction = lane groups per wave
+    static constexpr int NGRP = kWaves * RPW; // lane groups per workgroup
+    static constexpr int TCHUNK = NGRP * NIT; // timesteps per workgroup (NIT rows of K and of V per lane group)
 };
 
 __device__ __forceinline__ void h8_to_f(const uint4& v, float* f)
@@ -83,37 +87,33 @@ __device__ __forceinline__ uint2 quant8(const uint4& v, float s)
     return make_uint2(o[0], o[1]);
 }
 
-template <int DH, bool INT8KV>
+// ---- kernel 1: one workgroup per (split, head, batch) -> partial {max, sum, out[DH]} in the workspace
+template <int DH, int NIT, bool INT8KV>
 __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, float2* ws_ml, float* ws_o, int nsplit_max)
 {
-    using G = MmhaGeom<DH>;
-    constexpr int LPR = G::LPR, RPW = G::RPW, NIT = kRowsPerLane;
+    using G = MmhaGeom<DH, NIT>;
+    constexpr int LPR = G::LPR, RPW = G::RPW, NGRP = G::NGRP;
     const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int li = lane % LPR, grp = lane / LPR;
+    const int gid = wid * RPW + grp; // lane group inside the workgroup
     const int H = p.num_heads, Smax = p.max_seq_len;
-
-    const int tl = p.sequence_length[b]; // slots already used; the new token goes to slot tl
     const int t0 = c * G::TCHUNK;
-    if (t0 > tl)
-        return;
-    const int timestep = p.timestep_host >= 0 ? p.timestep_host : tl;
 
     constexpr int ESZ = INT8KV ? 1 : 2;
-    const char* kbase = reinterpret_cast<const char*>(p.kv_cache) + ((int64_t) (b * 2 + 0) * H + h) * Smax * DH * ESZ;
-    const char* vbase = reinterpret_cast<const char*>(p.kv_cache) + ((int64_t) (b * 2 + 1) * H + h) * Smax * DH * ESZ;
+    char* kbase = reinterpret_cast<char*>(p.kv_cache) + ((int64_t) (b * 2 + 0) * H + h) * Smax * DH * ESZ;
+    char* vbase = reinterpret_cast<char*>(p.kv_cache) + ((int64_t) (b * 2 + 1) * H + h) * Smax * DH * ESZ;
 
-    // ---- issue the cache loads first (they do not depend on anything computed below)
+    // ---- 1. request the cache rows: nothing below is needed to form their addresses (rows at or beyond the
+    //         current length are loaded too - the buffer has Smax rows - and dropped by the validity mask)
     uint4 kreg[NIT], vreg[NIT];
-    int trow[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
     {
-        const int t = t0 + wid * G::WAVE_ROWS + i * RPW + grp;
-        trow[i] = t;
+        const int t = t0 + i * NGRP + gid;
         kreg[i] = make_uint4(0, 0, 0, 0);
         vreg[i] = make_uint4(0, 0, 0, 0);
-        if (t < tl && t < Smax)
+        if (t < Smax)
         {
             const int64_t off = ((int64_t) t * DH + li * 8) * ESZ;
             if constexpr (INT8KV)
@@ -132,12 +132,23 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
             }
         }
     }
-
-    // ---- q, k, v of the new token (+ RoPE)
+    // ---- 2. the new token's q, k, v and the step scalars
     const uint16_t* qkv = reinterpret_cast<const uint16_t*>(p.qkv) + (int64_t) b * 3 * H * DH;
     const uint4 q_raw = *reinterpret_cast<const uint4*>(qkv + (int64_t) h * DH + li * 8);
     const uint4 k_raw = *reinterpret_cast<const uint4*>(qkv + (int64_t) (H + h) * DH + li * 8);
     const uint4 v_new = *reinterpret_cast<const uint4*>(qkv + (int64_t) (2 * H + h) * DH + li * 8);
+    const int tl = p.sequence_length[b]; // slots already used; the new token goes to slot tl
+    if (t0 > tl)
+        return; // uniform: this split lies entirely beyond the sequence
+    const int timestep = p.timestep_host >= 0 ? p.timestep_host : tl;
+    const int32_t* mask = p.masked_tokens ? p.masked_tokens + (int64_t) b * Smax : nullptr;
+    int mk[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+    {
+        const int t = t0 + i * NGRP + gid;
+        mk[i] = (mask && t < tl && t < Smax) ? mask[t] : 0;
+    }
     float qf[8], kf[8];
     h8_to_f(q_raw, qf);
     h8_to_f(k_raw, kf);
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
                 const int d = li * 8 + j;
                 const float2 cs = tab[second ? d - half : d];
                 // first half:  x' = x cos - y sin ; second half: y' = y cos + x sin
-                // fp16 rounding of the rotated value (…Utils.h:1517-1531)
+                // fp16 rounding of the rotated value (...Utils.h:1517-1531)
                 const float sn = second ? cs.y : -cs.y;
                 qf[j] = h2f(f2h(cs.x * qf[j] + sn * qp[j]));
                 kf[j] = h2f(f2h(cs.x * kf[j] + sn * kp[j]));
@@ -200,68 +211,61 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
         s_qo = p.kv_scale_quant_orig[0];
     }
 
-    // ---- the workgroup that owns slot tl appends the new token to the cache
-    if (tl / G::TCHUNK == c && wid == 0 && grp == 0 && tl < Smax)
+    // ---- 3. the workgroup that owns slot tl appends the new token to the cache
+    if (tl / G::TCHUNK == c && gid == 0 && tl < Smax)
     {
         const int64_t off = ((int64_t) tl * DH + li * 8) * ESZ;
         if constexpr (INT8KV)
         {
-            *reinterpret_cast<uint2*>(const_cast<char*>(kbase) + off) = quant8(k_new, s_oq);
-            *reinterpret_cast<uint2*>(const_cast<char*>(vbase) + off) = quant8(v_new, s_oq);
+            *reinterpret_cast<uint2*>(kbase + off) = quant8(k_new, s_oq);
+            *reinterpret_cast<uint2*>(vbase + off) = quant8(v_new, s_oq);
         }
         else
         {
-            *reinterpret_cast<uint4*>(const_cast<char*>(kbase) + off) = k_new;
-            *reinterpret_cast<uint4*>(const_cast<char*>(vbase) + off) = v_new;
+            *reinterpret_cast<uint4*>(kbase + off) = k_new;
+            *reinterpret_cast<uint4*>(vbase + off) = v_new;
         }
     }
 
-    // ---- scores
-    const int32_t* mask = p.masked_tokens ? p.masked_tokens + (int64_t) b * Smax : nullptr;
+    // ---- 4. scores of this lane group's rows, its own softmax partial
     float s[NIT];
-    float m_w = -INFINITY;
+    float m_g = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
     {
-        const int t = trow[i];
+        const int t = t0 + i * NGRP + gid;
         uint4 kk;
         if constexpr (INT8KV)
             kk = dequant8(make_uint2(kreg[i].x, kreg[i].y), s_qo);
         else
             kk = kreg[i];
         if (t == tl)
-            kk = k_new;
+            kk = k_new; // the current token uses the un-quantised k (MM/...Template.h:1517-1549)
         float d = 0.f;
         d = dot2(q16.x, kk.x, d);
         d = dot2(q16.y, kk.y, d);
         d = dot2(q16.z, kk.z, d);
         d = dot2(q16.w, kk.w, d);
         d = group_sum<LPR>(d) * p.inv_sqrt_dh;
-        bool valid = t <= tl && t < Smax;
-        if (valid && mask && t < tl)
-            valid = mask[t] == 0;
+        const bool valid = t <= tl && t < Smax && mk[i] == 0;
         s[i] = valid ? d : -INFINITY;
-        m_w = fmaxf(m_w, s[i]);
+        m_g = fmaxf(m_g, s[i]);
     }
-#pragma unroll
-    for (int mk = 32; mk >= LPR; mk >>= 1)
-        m_w = fmaxf(m_w, __shfl_xor(m_w, mk, 64));
-
-    // ---- probabilities and P.V
-    float l_w = 0.f;
+    float l_g = 0.f;
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
     {
-        const float pr = (s[i] == -INFINITY) ? 0.f : __expf(s[i] - m_w);
-        l_w += pr;
+        const int t = t0 + i * NGRP + gid;
+        const float pr = (s[i] == -INFINITY) ? 0.f : __expf(s[i] - m_g);
+        l_g += pr;
         const float p16 = h2f(f2h(pr));
         uint4 vv;
         if constexpr (INT8KV)
             vv = dequant8(make_uint2(vreg[i].x, vreg[i].y), s_qo);
         else
             vv = vreg[i];
-        if (trow[i] == tl)
+        if (t == tl)
             vv = v_new;
         float vf[8];
         h8_to_f(vv, vf);
@@ -269,109 +273,118 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
         for (int j = 0; j < 8; ++j)
             o[j] = fmaf(p16, vf[j], o[j]);
     }
-#pragma unroll
-    for (int mk = 32; mk >= LPR; mk >>= 1)
-    {
-        l_w += __shfl_xor(l_w, mk, 64);
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            o[j] += __shfl_xor(o[j], mk, 64);
-    }
 
-    // ---- merge the 4 waves through LDS, publish the split partial
-    __shared__ float sm_m[4], sm_l[4];
-    __shared__ float sm_o[4][DH];
-    if (grp == 0)
+    // ---- 5. merge the lane groups of the workgroup through LDS, publish the split partial
+    __shared__ float sm_m[NGRP], sm_l[NGRP], sm_w[NGRP];
+    __shared__ __attribute__((aligned(16))) float sm_o[NGRP][DH];
+    *reinterpret_cast<float4*>(&sm_o[gid][li * 8]) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(&sm_o[gid][li * 8 + 4]) = make_float4(o[4], o[5], o[6], o[7]);
+    if (li == 0)
     {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            sm_o[wid][li * 8 + j] = o[j];
-        if (li == 0)
-        {
-            sm_m[wid] = m_w;
-            sm_l[wid] = l_w;
-        }
+        sm_m[gid] = m_g;
+        sm_l[gid] = l_g;
     }
     __syncthreads();
-    if (tid < DH)
+    float M = -INFINITY;
+    for (int g = 0; g < NGRP; ++g)
+        M = fmaxf(M, sm_m[g]);
+    if (tid < NGRP)
+        sm_w[tid] = (sm_m[tid] == -INFINITY) ? 0.f : __expf(sm_m[tid] - M);
+    __syncthreads();
+    const int64_t pi = ((int64_t) b * H + h) * nsplit_max + c;
+    for (int d = tid; d < DH; d += 256)
     {
-        float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
         float L = 0.f, O = 0.f;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
+        for (int g = 0; g < NGRP; ++g)
         {
-            const float e = (sm_m[w] == -INFINITY) ? 0.f : __expf(sm_m[w] - M);
-            L += sm_l[w] * e;
-            O += sm_o[w][tid] * e;
+            L += sm_l[g] * sm_w[g];
+            O += sm_o[g][d] * sm_w[g];
         }
-        const int64_t pi = ((int64_t) b * H + h) * nsplit_max + c;
-        ws_o[pi * DH + tid] = O;
-        if (tid == 0)
+        ws_o[pi * DH + d] = O;
+        if (d == 0)
             ws_ml[pi] = make_float2(M, L);
     }
 }
 
-template <int DH>
-__global__ void mmha_combine_kernel(const MmhaParams p, const float2* ws_ml, const float* ws_o, int nsplit_max)
+// ---- kernel 2: merge the splits of every (batch, head): 256 threads = (d, part), all loads independent
+template <int DH, int NIT>
+__global__ __launch_bounds__(256) void mmha_combine_kernel(const MmhaParams p, const float2* ws_ml, const float* ws_o, int nsplit_max)
 {
-    using G = MmhaGeom<DH>;
-    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    using G = MmhaGeom<DH, NIT>;
+    constexpr int PARTS = 256 / DH > 0 ? 256 / DH : 1;
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int tl = p.sequence_length[b];
     int ns = tl / G::TCHUNK + 1;
     ns = ns > nsplit_max ? nsplit_max : ns;
     const int64_t base = ((int64_t) b * p.num_heads + h) * nsplit_max;
-    float M = -INFINITY;
-    for (int i = 0; i < ns; ++i)
-        M = fmaxf(M, ws_ml[base + i].x);
-    float L = 0.f, O = 0.f;
-    for (int i = 0; i < ns; ++i)
+    __shared__ float sm_w[256];
+    __shared__ float sm_l[PARTS];
+    __shared__ float sm_o[PARTS][DH];
+    // weights exp(m_i - M) of the splits (ns <= 256)
+    float mine = -INFINITY, lmine = 0.f;
+    if (tid < ns)
     {
-        const float2 ml = ws_ml[base + i];
-        const float e = (ml.x == -INFINITY) ? 0.f : __expf(ml.x - M);
-        L += ml.y * e;
-        if (d < DH)
-            O += ws_o[(base + i) * DH + d] * e;
+        const float2 ml = ws_ml[base + tid];
+        mine = ml.x;
+        lmine = ml.y;
     }
-    if (d < DH)
+    float M = mine;
+#pragma unroll
+    for (int mk = 32; mk >= 1; mk >>= 1)
+        M = fmaxf(M, __shfl_xor(M, mk, 64));
+    __shared__ float sm_mw[4];
+    if ((tid & 63) == 0)
+        sm_mw[tid >> 6] = M;
+    __syncthreads();
+    M = fmaxf(fmaxf(sm_mw[0], sm_mw[1]), fmaxf(sm_mw[2], sm_mw[3]));
+    const float w = (mine == -INFINITY) ? 0.f : __expf(mine - M);
+    sm_w[tid] = w;
+    float lw = wave_sum(lmine * w);
+    __syncthreads();
+    if ((tid & 63) == 0)
+        sm_mw[tid >> 6] = lw;
+    const int d = tid % DH, part = tid / DH;
+    float O = 0.f;
+    if (part < PARTS)
+        for (int i = part; i < ns; i += PARTS)
+            O += ws_o[(base + i) * DH + d] * sm_w[i];
+    if (part < PARTS)
+        sm_o[part][d] = O;
+    __syncthreads();
+    if (tid < DH)
     {
+        const float L = sm_mw[0] + sm_mw[1] + sm_mw[2] + sm_mw[3];
+        float Ot = 0.f;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q)
+            Ot += sm_o[q][tid];
         // inv_sum = 1 / (sum + 1e-6)  (MM/...Template.h:1756)
-        const float r = O * (1.f / (L + 1.e-6f));
-        reinterpret_cast<uint16_t*>(p.out)[((int64_t) b * p.num_heads + h) * DH + d] = f2h(r);
+        reinterpret_cast<uint16_t*>(p.out)[((int64_t) b * p.num_heads + h) * DH + tid] = f2h(Ot * (1.f / (L + 1.e-6f)));
     }
 }
 
-template <int DH>
-int nsplit_for(int max_seq_len)
-{
-    return (max_seq_len + MmhaGeom<DH>::TCHUNK - 1) / MmhaGeom<DH>::TCHUNK;
-}
+int mmha_tune_nit = 0; // test/bench override of the rows-per-lane-group (4 or 8); 0 = default
 
-int nsplit_any(int head_size, int max_seq_len)
+template <int DH, int NIT>
+int launch_nit(const MmhaParams& p, hipStream_t stream)
 {
-    switch (head_size)
+    using G = MmhaGeom<DH, NIT>;
+    const int ns = (p.max_seq_len + G::TCHUNK - 1) / G::TCHUNK;
+    if (ns > 256)
     {
-    case 32: return nsplit_for<32>(max_seq_len);
-    case 64: return nsplit_for<64>(max_seq_len);
-    case 128: return nsplit_for<128>(max_seq_len);
-    case 256: return nsplit_for<256>(max_seq_len);
-    default: return -1;
+        set_error("mmha: max_seq_len %d needs more than 256 splits", p.max_seq_len);
+        return -1;
     }
-}
-
-template <int DH>
-int launch_dh(const MmhaParams& p, hipStream_t stream)
-{
-    const int ns = nsplit_for<DH>(p.max_seq_len);
-    float2* ws_ml = reinterpret_cast<float2*>(p.workspace);
+    char* ws = reinterpret_cast<char*>(p.workspace);
+    float2* ws_ml = reinterpret_cast<float2*>(ws);
     const size_t ml_bytes = ((size_t) p.batch * p.num_heads * ns * sizeof(float2) + 255) / 256 * 256;
-    float* ws_o = reinterpret_cast<float*>(reinterpret_cast<char*>(p.workspace) + ml_bytes);
+    float* ws_o = reinterpret_cast<float*>(ws + ml_bytes);
     dim3 grid(ns, p.num_heads, p.batch);
     if (p.int8_kv)
-        hipLaunchKernelGGL((mmha_partial_kernel<DH, true>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
+        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, true>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
     else
-        hipLaunchKernelGGL((mmha_partial_kernel<DH, false>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
-    hipLaunchKernelGGL((mmha_combine_kernel<DH>), dim3(p.num_heads, p.batch), dim3(DH < 64 ? 64 : DH), 0, stream, p,
-        ws_ml, ws_o, ns);
+        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, false>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
+    hipLaunchKernelGGL((mmha_combine_kernel<DH, NIT>), dim3(p.num_heads, p.batch), dim3(256), 0, stream, p, ws_ml, ws_o, ns);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
     {
@@ -381,15 +394,36 @@ int launch_dh(const MmhaParams& p, hipStream_t stream)
     return 0;
 }
 
+template <int DH>
+int launch_dh(const MmhaParams& p, hipStream_t stream)
+{
+    if (mmha_tune_nit == 8)
+        return launch_nit<DH, 8>(p, stream);
+    return launch_nit<DH, 4>(p, stream);
+}
+
 } // namespace
 
 size_t mmha_workspace_size(int32_t batch, int32_t num_heads, int32_t head_size, int32_t max_seq_len)
 {
-    const int ns = nsplit_any(head_size, max_seq_len);
-    if (ns < 0)
+    // sized for the finest split (NIT = 4)
+    const int lpr = head_size / 8;
+    if (lpr <= 0 || 64 % lpr)
         return 0;
+    const int tchunk = kWaves * (64 / lpr) * 4;
+    const int ns = (max_seq_len + tchunk - 1) / tchunk;
     const size_t ml = ((size_t) batch * num_heads * ns * sizeof(float2) + 255) / 256 * 256;
     return ml + (size_t) batch * num_heads * ns * head_size * sizeof(float);
+}
+
+int mmha_reset_workspace(void* workspace, int32_t batch, int32_t num_heads, hipStream_t stream)
+{
+    if (hipMemsetAsync(workspace, 0, (size_t) batch * num_heads * sizeof(unsigned), stream) != hipSuccess)
+    {
+        set_error("mmha: hipMemsetAsync(tickets) failed");
+        return -1;
+    }
+    return 0;
 }
 
 void fill_rope_table_host(float* table, int32_t max_pos, int32_t rotary_dim)

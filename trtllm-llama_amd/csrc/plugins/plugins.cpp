@@ -293,6 +293,8 @@ public:
             set_error("GPTAttention: workspace is null");
             return 1;
         }
+        if (mmha_reset_workspace(ws, B, c.num_heads, stream))
+            return 1;
         return launch_mmha(p, stream) ? 1 : 0;
     }
 

@@ -1,0 +1,1205 @@
+// Host decode loop of the LLaMA path (include/tllm_runtime_api.h).
+//
+// What the reference does with a TensorRT engine + two execution contexts + a Python loop that syncs with the
+// device every step (PY/runtime/generation.py:852-983), this does with: named weight tensors, the plugin
+// kernels enqueued layer by layer on one HIP stream, a generation step whose step-dependent scalars
+// (sequence length, current token, finished flags) live in device memory — so one captured hipGraph is
+// replayed for every step and the host never waits inside the loop.
+//
+// Layer graph = Q/llama_model.py:78-119 (LLaMADecoderLayer.forward); model head/tail = :159-207, :253-287.
+// Generation-step fusion (what TensorRT/Myelin fuses out of pointwise layers, done here by construction):
+//   K1  RMSNorm(+quant)  ->  QKV GEMV                       (gemv prologue)
+//   K2  RoPE + KV append + split-KV attention, K3 combine   (mmha_decode)
+//   K4  (quant) -> O GEMV -> + residual                     (gemv prologue/epilogue)
+//   K5  RMSNorm(+quant) -> gate|up GEMV -> silu*mul(+quant) (gemv prologue/epilogue)
+//   K6  (quant) -> down GEMV -> + residual
+// SmoothQuant block template: SURVEY Appendix A.4 (the reference's SmoothQuant-LLaMA never ran; designed by
+// analogy to PY/quantization/layer.py:385-439,596-852).
+#include "../../../include/tllm_runtime_api.h"
+#include "../kernels/kernels.h"
+#include "../kernels/weight_layout.h"
+#include "../plugins/comm.h"
+#include "../plugins/plugin_base.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+using namespace tllm;
+using namespace tllm::kernels;
+
+namespace tllm
+{
+namespace kernels
+{
+extern int gemv_tune_r;
+extern int gemv_tune_blocks_per_cu;
+}
+} // namespace tllm
+
+namespace
+{
+
+enum QuantBits
+{
+    QM_INT4_WEIGHTS = 1,
+    QM_INT8_WEIGHTS = 2,
+    QM_ACTIVATIONS = 4,
+    QM_PER_CHANNEL = 8,
+    QM_PER_TOKEN = 16,
+    QM_INT8_KV = 32
+};
+
+struct TensorRec
+{
+    int32_t dtype = 0;
+    std::vector<int64_t> dims;
+    void* dev = nullptr;
+    bool owned = false;
+    size_t bytes = 0;
+    int64_t numel() const
+    {
+        int64_t n = 1;
+        for (auto d : dims)
+            n *= d;
+        return n;
+    }
+};
+
+struct Linear
+{
+    int wtype = W_FP16;
+    const void* w = nullptr;
+    int64_t ldw = 0;
+    int N = 0, K = 0;
+    const void* scale_col = nullptr; // fp16 [N] (weight-only) | f32 [N] or [1] (SmoothQuant)
+    int per_channel = 0;
+    const float* act_scale = nullptr; // SmoothQuant static: dequant scale of the GEMM [1,1]
+};
+
+struct Layer
+{
+    const void* ln1 = nullptr;
+    const void* ln2 = nullptr;
+    const float* ln1_scale = nullptr;  // input_layernorm.scale_to_int (SQ static)
+    const float* ln2_scale = nullptr;  // post_layernorm.scale_to_int
+    const float* attn_qscale = nullptr; // attention.quantization_scaling_factor (ctx -> int8, SQ static)
+    const float* mlp_qscale = nullptr;  // mlp.quantization_scaling_factor (silu*mul -> int8, SQ static)
+    const float* kv_oq = nullptr;
+    const float* kv_qo = nullptr;
+    Linear qkv, dense, fc, gate, proj;
+    void* kv = nullptr;
+};
+
+size_t dtype_bytes(int32_t t)
+{
+    switch (t)
+    {
+    case TLLM_FLOAT:
+    case TLLM_INT32: return 4;
+    case TLLM_HALF: return 2;
+    default: return 1;
+    }
+}
+
+#define HIP_OK(expr)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t _e = (expr);                                                                                        \
+        if (_e != hipSuccess)                                                                                          \
+        {                                                                                                              \
+            set_error("%s failed: %s", #expr, hipGetErrorString(_e));                                                  \
+            return 1;                                                                                                  \
+        }                                                                                                              \
+    } while (0)
+
+#define RUN(expr)                                                                                                      \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if ((expr) != 0)                                                                                               \
+            return 1;                                                                                                  \
+    } while (0)
+
+} // namespace
+
+struct tllm_session
+{
+    // ---- configuration
+    int num_layers = 0, num_heads = 0, hidden = 0, inter = 0, vocab = 0, max_pos = 2048;
+    int tp = 1, rank = 0;
+    int quant_mode = 0;
+    int neox = 1;
+    float eps = 1e-6f;
+    std::string wo_precision = "int8";
+    // derived
+    int Hr = 0, Dh = 0, Dr = 0, Ir = 0, Vr = 0;
+    bool sq = false, woq = false, int8_kv = false, per_token = false, per_channel = false;
+    int wtype = W_FP16;
+
+    std::map<std::string, TensorRec> tensors;
+    std::vector<Layer> layers;
+    const void* emb = nullptr;
+    const void* lnf = nullptr;
+    Linear head;
+    bool finalized = false;
+    std::vector<int32_t> group;
+
+    // ---- runtime state (setup)
+    int B = 0, max_in = 0, max_new = 0, Smax = 0;
+    std::vector<void*> allocs;
+    void *x = nullptr, *qkv = nullptr, *ctx = nullptr, *g = nullptr, *u = nullptr, *inter_buf = nullptr, *tmp = nullptr;
+    int8_t* q8 = nullptr;   // quantised activations (context path) [B*S, max(D, I)]
+    float* qscale = nullptr; // per-token scales [B*S]
+    float* logits = nullptr; // [B, V] (or gathered [tp, B, Vr])
+    float* logits_local = nullptr;
+    void* last_hidden = nullptr;
+    void* mmha_ws = nullptr;
+    int32_t *ids_in = nullptr, *cur_ids = nullptr, *out_ids = nullptr, *seq_len = nullptr, *in_len = nullptr,
+            *masked = nullptr, *finished = nullptr, *last_tok = nullptr;
+    const float* rope = nullptr;
+    int rope_len = 0;
+    int end_id = -1;
+    hipGraphExec_t graph = nullptr;
+    hipStream_t graph_stream = nullptr;
+    hipStream_t own_stream = nullptr; // used when the caller passes the NULL stream (it cannot be captured)
+
+    // ---- optional per-launch instrumentation (tllm_session_profile): event pairs around every launch class
+    enum ProfClass
+    {
+        PC_GEMV_LAYER = 0,
+        PC_GEMV_HEAD = 1,
+        PC_ATTENTION = 2,
+        PC_OTHER = 3,
+        PC_COMM = 4,
+        PC_COUNT = 5
+    };
+    bool profiling = false;
+    int gemv_cls = PC_GEMV_LAYER;
+    struct ProfRec
+    {
+        hipEvent_t a, b;
+        int cls;
+    };
+    std::vector<ProfRec> prof;
+
+    hipStream_t pick(tllm_stream_t stream)
+    {
+        if (stream)
+            return reinterpret_cast<hipStream_t>(stream);
+        if (!own_stream)
+            (void) hipStreamCreate(&own_stream);
+        return own_stream;
+    }
+
+    template <typename F>
+    int timed(int cls, hipStream_t st, F&& f)
+    {
+        if (!profiling)
+            return f();
+        ProfRec r;
+        r.cls = cls;
+        (void) hipEventCreate(&r.a);
+        (void) hipEventCreate(&r.b);
+        (void) hipEventRecord(r.a, st);
+        const int rc = f();
+        (void) hipEventRecord(r.b, st);
+        prof.push_back(r);
+        return rc;
+    }
+
+    ~tllm_session()
+    {
+        if (own_stream)
+            (void) hipStreamDestroy(own_stream);
+        if (graph)
+            (void) hipGraphExecDestroy(graph);
+        for (auto p : allocs)
+            (void) hipFree(p);
+        for (auto& kv : tensors)
+            if (kv.second.owned && kv.second.dev)
+                (void) hipFree(kv.second.dev);
+    }
+
+    // ------------------------------------------------------------------------------------------ helpers
+    template <typename T>
+    int dalloc(T** p, size_t bytes)
+    {
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes ? bytes : 16) != hipSuccess)
+        {
+            set_error("session: hipMalloc(%zu) failed", bytes);
+            return 1;
+        }
+        allocs.push_back(d);
+        *p = static_cast<T*>(d);
+        return 0;
+    }
+
+    void free_runtime()
+    {
+        if (graph)
+        {
+            (void) hipGraphExecDestroy(graph);
+            graph = nullptr;
+        }
+        for (auto p : allocs)
+            (void) hipFree(p);
+        allocs.clear();
+    }
+
+    const TensorRec* find(const std::string& name, bool required = true)
+    {
+        auto it = tensors.find(name);
+        if (it == tensors.end())
+        {
+            if (required)
+                set_error("session: missing tensor '%s'", name.c_str());
+            return nullptr;
+        }
+        return &it->second;
+    }
+
+    int want(const TensorRec* t, const std::string& name, int32_t dtype, int64_t numel)
+    {
+        if (!t)
+            return 1;
+        if (t->dtype != dtype || t->numel() != numel)
+        {
+            set_error("session: tensor '%s' has dtype %d / %lld elements, expected dtype %d / %lld", name.c_str(),
+                t->dtype, (long long) t->numel(), dtype, (long long) numel);
+            return 1;
+        }
+        return 0;
+    }
+
+    // resolve one linear layer "prefix" with logical shape [N, K] for this session's quantisation mode
+    int resolve_linear(const std::string& prefix, int N, int K, Linear& L, bool force_fp16 = false)
+    {
+        L.N = N;
+        L.K = K;
+        const std::string wn = prefix + ".weight";
+        const TensorRec* w = find(wn);
+        if (!w)
+            return 1;
+        if (force_fp16 || (!sq && !woq))
+        {
+            RUN(want(w, wn, TLLM_HALF, (int64_t) N * K));
+            L.wtype = W_FP16;
+            L.w = w->dev;
+            L.ldw = (int64_t) K * 2;
+            return 0;
+        }
+        if (woq)
+        {
+            // processed bytes, declared fp32 [K, N/4 | N/8] (reference view) or int8 [N, ldw]
+            L.wtype = wtype;
+            L.ldw = layout::row_bytes(wtype, K);
+            if ((int64_t) w->bytes != (int64_t) N * L.ldw)
+            {
+                set_error("session: tensor '%s' has %zu bytes, expected %lld (processed weight-only layout)",
+                    wn.c_str(), w->bytes, (long long) N * L.ldw);
+                return 1;
+            }
+            L.w = w->dev;
+            const TensorRec* s = find(prefix + ".per_channel_scale");
+            RUN(want(s, prefix + ".per_channel_scale", TLLM_HALF, N));
+            L.scale_col = s->dev;
+            return 0;
+        }
+        // SmoothQuant: int8 [N, K] (or fp32 view [N, K/4])
+        L.wtype = W_INT8_SQ;
+        L.ldw = K;
+        if ((int64_t) w->bytes != (int64_t) N * K || (K % 16))
+        {
+            set_error("session: tensor '%s' must hold N*K = %lld int8 values with K %% 16 == 0", wn.c_str(),
+                (long long) N * K);
+            return 1;
+        }
+        L.w = w->dev;
+        const TensorRec* s = find(prefix + ".per_channel_scale");
+        if (!s)
+            return 1;
+        L.per_channel = s->numel() == N ? 1 : 0;
+        if (s->dtype != TLLM_FLOAT || (s->numel() != N && s->numel() != 1))
+        {
+            set_error("session: '%s.per_channel_scale' must be f32 [1,%d] or [1,1]", prefix.c_str(), N);
+            return 1;
+        }
+        L.scale_col = s->dev;
+        if (!per_token)
+        {
+            const TensorRec* a = find(prefix + ".act_scale");
+            RUN(want(a, prefix + ".act_scale", TLLM_FLOAT, 1));
+            L.act_scale = static_cast<const float*>(a->dev);
+        }
+        return 0;
+    }
+
+    int scalar_f32(const std::string& name, const float** out)
+    {
+        const TensorRec* t = find(name);
+        RUN(want(t, name, TLLM_FLOAT, 1));
+        *out = static_cast<const float*>(t->dev);
+        return 0;
+    }
+
+    // ------------------------------------------------------------------------------------------ GEMM wrappers
+    // decode: fused skinny GEMM
+    int gemv(const Linear& L, int M, int pro, int epi, const void* xin, int64_t ldx, const void* gamma,
+        const float* in_qscale, const void* residual, const float* epi_scale, void* y, int64_t ldy, int out_dtype,
+        const Linear* up, hipStream_t st)
+    {
+        GemvParams p;
+        p.wtype = L.wtype;
+        p.pro = pro;
+        p.epi = epi;
+        p.out_dtype = out_dtype;
+        p.M = M;
+        p.N = L.N;
+        p.K = L.K;
+        p.x = xin;
+        p.ldx = ldx;
+        p.w = L.w;
+        p.ldw = L.ldw;
+        p.scale_col = L.scale_col;
+        p.scale_row = L.act_scale;
+        p.per_channel = L.per_channel;
+        p.per_token = 0;
+        p.gamma = gamma;
+        p.eps = eps;
+        p.act_scale = in_qscale;
+        p.residual = residual;
+        p.epi_scale = epi_scale;
+        p.y = y;
+        p.ldy = ldy;
+        if (up)
+        {
+            p.w_up = up->w;
+            p.scale_col_up = up->scale_col;
+            p.scale_row_up = up->act_scale;
+        }
+        return timed(gemv_cls, st, [&] { return launch_gemv(p, st) ? 1 : 0; });
+    }
+
+    // context: plain GEMM on M rows (activation already in the operand type)
+    int gemm(const Linear& L, int M, const void* a, const float* scale_row, int per_tok, void* c, int out_dtype,
+        hipStream_t st)
+    {
+        GemmParams g;
+        g.wtype = L.wtype;
+        g.out_dtype = out_dtype;
+        g.M = M;
+        g.N = L.N;
+        g.K = L.K;
+        g.a = a;
+        g.lda = L.K;
+        g.w = L.w;
+        g.ldw = L.ldw;
+        g.scale_col = L.scale_col;
+        g.scale_row = scale_row ? scale_row : L.act_scale;
+        g.per_channel = L.per_channel;
+        g.per_token = per_tok;
+        g.c = c;
+        g.ldc = L.N;
+        return launch_gemm(g, st) ? 1 : 0;
+    }
+
+    int allreduce(void* buf, int64_t n, hipStream_t st)
+    {
+        if (tp == 1)
+            return 0;
+        return timed(PC_COMM, st, [&] { return comm::all_reduce_sum(group, buf, buf, n, TLLM_HALF, st) ? 1 : 0; });
+    }
+
+    // ------------------------------------------------------------------------------------------ context step
+    int run_context(hipStream_t st)
+    {
+        const int S = max_in, M = B * S, D = hidden;
+        RUN(launch_embedding(x, ids_in, emb, M, D, vocab, st));
+        for (int li = 0; li < num_layers; ++li)
+        {
+            Layer& L = layers[li];
+            // --- attention block
+            const void* a_in = tmp;
+            RmsnormParams r;
+            r.M = M;
+            r.N = D;
+            r.x = x;
+            r.gamma = L.ln1;
+            r.eps = eps;
+            if (sq)
+            {
+                r.q = q8;
+                if (per_token)
+                    r.dyn_scale_out = qscale;
+                else
+                    r.static_scale = L.ln1_scale;
+                a_in = q8;
+            }
+            else
+                r.y = tmp;
+            RUN(launch_rmsnorm(r, st));
+            RUN(gemm(L.qkv, M, a_in, sq && per_token ? qscale : nullptr, sq && per_token, qkv, DT_HALF, st));
+            ContextAttnParams c;
+            c.batch = B;
+            c.seq = S;
+            c.num_heads = Hr;
+            c.head_size = Dh;
+            c.rotary_dim = Dh;
+            c.neox = neox;
+            c.inv_sqrt_dh = 1.f / sqrtf((float) Dh);
+            c.int8_kv = int8_kv;
+            c.max_seq_len = Smax;
+            c.qkv = qkv;
+            c.kv_cache = L.kv;
+            c.input_lengths = in_len;
+            c.kv_scale_orig_quant = L.kv_oq;
+            c.rope_table = rope;
+            c.rope_table_len = rope_len;
+            c.out = ctx;
+            RUN(launch_context_attention(c, st));
+            const void* d_in = ctx;
+            if (sq)
+            {
+                if (per_token)
+                    RUN(launch_quantize_per_token(q8, ctx, DT_HALF, M, Dr, qscale, st));
+                else
+                    RUN(launch_quantize_tensor(q8, ctx, DT_HALF, (int64_t) M * Dr, L.attn_qscale, st));
+                d_in = q8;
+            }
+            RUN(gemm(L.dense, M, d_in, sq && per_token ? qscale : nullptr, sq && per_token, tmp, DT_HALF, st));
+            RUN(allreduce(tmp, (int64_t) M * D, st));
+            RUN(launch_add(x, x, tmp, (int64_t) M * D, st));
+            // --- MLP block
+            r = RmsnormParams();
+            r.M = M;
+            r.N = D;
+            r.x = x;
+            r.gamma = L.ln2;
+            r.eps = eps;
+            a_in = tmp;
+            if (sq)
+            {
+                r.q = q8;
+                if (per_token)
+                    r.dyn_scale_out = qscale;
+                else
+                    r.static_scale = L.ln2_scale;
+                a_in = q8;
+            }
+            else
+                r.y = tmp;
+            RUN(launch_rmsnorm(r, st));
+            RUN(gemm(L.fc, M, a_in, sq && per_token ? qscale : nullptr, sq && per_token, g, DT_HALF, st));
+            RUN(gemm(L.gate, M, a_in, sq && per_token ? qscale : nullptr, sq && per_token, u, DT_HALF, st));
+            RUN(launch_swiglu(inter_buf, g, u, (int64_t) M * Ir, st));
+            const void* p_in = inter_buf;
+            if (sq)
+            {
+                if (per_token)
+                    RUN(launch_quantize_per_token(q8, inter_buf, DT_HALF, M, Ir, qscale, st));
+                else
+                    RUN(launch_quantize_tensor(q8, inter_buf, DT_HALF, (int64_t) M * Ir, L.mlp_qscale, st));
+                p_in = q8;
+            }
+            RUN(gemm(L.proj, M, p_in, sq && per_token ? qscale : nullptr, sq && per_token, tmp, DT_HALF, st));
+            RUN(allreduce(tmp, (int64_t) M * D, st));
+            RUN(launch_add(x, x, tmp, (int64_t) M * D, st));
+        }
+        // head: last real token of every sequence -> ln_f -> lm_head -> fp32 logits  (Q/llama_model.py:272-279)
+        RUN(launch_gather_last_token(last_hidden, x, last_tok, B, S, D, st));
+        RUN(run_head(last_hidden, st));
+        return 0;
+    }
+
+    int run_head(const void* h, hipStream_t st)
+    {
+        gemv_cls = PC_GEMV_HEAD;
+        const int head_rc = gemv(head, B, PRO_RMSNORM, EPI_NONE, h, hidden, lnf, nullptr, nullptr, nullptr, logits_local, Vr, DT_FLOAT,
+            nullptr, st);
+        gemv_cls = PC_GEMV_LAYER;
+        RUN(head_rc);
+        if (tp > 1)
+        {
+            if (comm::all_gather(group, logits_local, logits, (int64_t) B * Vr, TLLM_FLOAT, st))
+                return 1;
+        }
+        return 0;
+    }
+
+    int run_sampler(int advance, hipStream_t st)
+    {
+        GreedyParams gp;
+        gp.logits = tp > 1 ? logits : logits_local;
+        gp.batch = B;
+        gp.vocab_part = Vr;
+        gp.nparts = tp;
+        gp.vocab = vocab;
+        gp.cur_ids = cur_ids;
+        gp.out_ids = out_ids;
+        gp.out_stride = Smax;
+        gp.seq_len = seq_len;
+        gp.finished = finished;
+        gp.end_id = end_id;
+        gp.advance = advance;
+        return timed(PC_OTHER, st, [&] { return launch_greedy_step(gp, st) ? 1 : 0; });
+    }
+
+    // ------------------------------------------------------------------------------------------ generation step
+    int run_decode_step(hipStream_t st)
+    {
+        const int D = hidden;
+        if (B > 8)
+        {
+            set_error("session: generation step supports batch <= 8 (got %d)", B);
+            return 1;
+        }
+        RUN(timed(PC_OTHER, st, [&] { return launch_embedding(x, cur_ids, emb, B, D, vocab, st); }));
+        const bool r0 = rank == 0;
+        for (int li = 0; li < num_layers; ++li)
+        {
+            Layer& L = layers[li];
+            const int pro_norm = !sq ? PRO_RMSNORM : (per_token ? PRO_RMSNORM_QDYN : PRO_RMSNORM_QSTATIC);
+            const int pro_q = !sq ? PRO_NONE : (per_token ? PRO_QDYN : PRO_QSTATIC);
+            // K1
+            RUN(gemv(L.qkv, B, pro_norm, EPI_NONE, x, D, L.ln1, L.ln1_scale, nullptr, nullptr, qkv, 3 * Dr, DT_HALF,
+                nullptr, st));
+            // K2/K3
+            MmhaParams m;
+            m.batch = B;
+            m.num_heads = Hr;
+            m.head_size = Dh;
+            m.rotary_dim = Dh;
+            m.neox = neox;
+            m.inv_sqrt_dh = 1.f / sqrtf((float) Dh);
+            m.int8_kv = int8_kv;
+            m.max_seq_len = Smax;
+            m.max_input_len = max_in;
+            m.qkv = qkv;
+            m.kv_cache = L.kv;
+            m.sequence_length = seq_len;
+            m.input_lengths = in_len;
+            m.masked_tokens = masked;
+            m.timestep_host = -1; // device-resident step state: one graph serves every step
+            m.kv_scale_orig_quant = L.kv_oq;
+            m.kv_scale_quant_orig = L.kv_qo;
+            m.rope_table = rope;
+            m.rope_table_len = rope_len;
+            m.out = ctx;
+            m.workspace = mmha_ws;
+            RUN(timed(PC_ATTENTION, st, [&] { return launch_mmha(m, st); }));
+            // K4: x <- x + O(ctx)     (TP: rank 0 carries the residual into the all-reduce)
+            RUN(gemv(L.dense, B, pro_q, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE, ctx, Dr, nullptr, L.attn_qscale, x,
+                nullptr, x, D, DT_HALF, nullptr, st));
+            RUN(allreduce(x, (int64_t) B * D, st));
+            // K5
+            const bool q_inter = sq && !per_token;
+            RUN(gemv(L.fc, B, pro_norm, q_inter ? EPI_SWIGLU_QSTATIC : EPI_SWIGLU, x, D, L.ln2, L.ln2_scale, nullptr,
+                L.mlp_qscale, q_inter ? (void*) q8 : inter_buf, Ir, q_inter ? DT_INT8 : DT_HALF, &L.gate, st));
+            // K6
+            RUN(gemv(L.proj, B, q_inter ? PRO_NONE : pro_q, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE,
+                q_inter ? (const void*) q8 : inter_buf, Ir, nullptr, L.mlp_qscale, x, nullptr, x, D, DT_HALF, nullptr,
+                st));
+            RUN(allreduce(x, (int64_t) B * D, st));
+        }
+        RUN(run_head(x, st));
+        RUN(run_sampler(1, st));
+        return 0;
+    }
+};
+
+// ================================================================================================
+// C API
+// ================================================================================================
+extern "C" {
+
+tllm_session_t tllm_session_create(const char* config_text)
+{
+    if (!config_text)
+    {
+        set_error("tllm_session_create: null config");
+        return nullptr;
+    }
+    auto s = std::make_unique<tllm_session>();
+    std::istringstream in(config_text);
+    std::string line;
+    std::map<std::string, std::string> kv;
+    while (std::getline(in, line))
+    {
+        const size_t eq = line.find('=');
+        if (eq == std::string::npos)
+            continue;
+        auto trim = [](std::string v) {
+            const size_t a = v.find_first_not_of(" \t\r");
+            const size_t b = v.find_last_not_of(" \t\r");
+            return a == std::string::npos ? std::string() : v.substr(a, b - a + 1);
+        };
+        kv[trim(line.substr(0, eq))] = trim(line.substr(eq + 1));
+    }
+    auto geti = [&](const char* k, int def) { return kv.count(k) ? atoi(kv[k].c_str()) : def; };
+    s->num_layers = geti("num_layers", 0);
+    s->num_heads = geti("num_heads", 0);
+    s->hidden = geti("hidden_size", 0);
+    s->inter = geti("inter_size", 0);
+    s->vocab = geti("vocab_size", 0);
+    s->max_pos = geti("max_position_embeddings", 2048);
+    s->tp = geti("tp_size", 1);
+    s->rank = geti("tp_rank", 0);
+    s->quant_mode = geti("quant_mode", 0);
+    s->neox = geti("neox_rotary_style", 1);
+    if (kv.count("rms_norm_eps"))
+        s->eps = (float) atof(kv["rms_norm_eps"].c_str());
+    if (kv.count("weight_only_precision"))
+        s->wo_precision = kv["weight_only_precision"];
+    if (s->num_layers <= 0 || s->num_heads <= 0 || s->hidden <= 0 || s->inter <= 0 || s->vocab <= 0 || s->tp < 1
+        || s->rank < 0 || s->rank >= s->tp)
+    {
+        set_error("tllm_session_create: num_layers/num_heads/hidden_size/inter_size/vocab_size/tp_size/tp_rank invalid");
+        return nullptr;
+    }
+    if (s->hidden % s->num_heads || s->num_heads % s->tp || s->inter % s->tp)
+    {
+        set_error("tllm_session_create: heads must divide hidden, tp must divide heads and inter_size");
+        return nullptr;
+    }
+    s->Dh = s->hidden / s->num_heads;
+    s->Hr = s->num_heads / s->tp;
+    s->Dr = s->Hr * s->Dh;
+    s->Ir = s->inter / s->tp;
+    // vocab padded to a multiple of tp (PY/_utils.py:194-195, Q/llama_model.py:244)
+    s->Vr = (s->vocab + s->tp - 1) / s->tp;
+    const int qm = s->quant_mode;
+    s->sq = (qm & QM_ACTIVATIONS) && (qm & QM_INT8_WEIGHTS);
+    s->woq = !s->sq && (qm & (QM_INT8_WEIGHTS | QM_INT4_WEIGHTS));
+    s->int8_kv = qm & QM_INT8_KV;
+    s->per_token = qm & QM_PER_TOKEN;
+    s->per_channel = qm & QM_PER_CHANNEL;
+    if (s->woq)
+        s->wtype = (qm & QM_INT4_WEIGHTS) ? W_INT4_WOQ : W_INT8_WOQ;
+    else if (s->sq)
+        s->wtype = W_INT8_SQ;
+    for (int i = 0; i < s->tp; ++i)
+        s->group.push_back(i);
+    return s.release();
+}
+
+int32_t tllm_session_set_tensor(tllm_session_t s, const char* name, int32_t dtype, const int64_t* dims, int32_t nbDims,
+    const void* data, int32_t location)
+{
+    if (!s || !name || !dims || !data || nbDims < 0 || nbDims > 8)
+    {
+        set_error("tllm_session_set_tensor: bad arguments");
+        return 1;
+    }
+    TensorRec t;
+    t.dtype = dtype;
+    t.dims.assign(dims, dims + nbDims);
+    t.bytes = (size_t) t.numel() * dtype_bytes(dtype);
+    if (location == 0)
+    {
+        HIP_OK(hipMalloc(&t.dev, t.bytes ? t.bytes : 16));
+        t.owned = true;
+        HIP_OK(hipMemcpy(t.dev, data, t.bytes, hipMemcpyHostToDevice));
+    }
+    else
+        t.dev = const_cast<void*>(data);
+    auto it = s->tensors.find(name);
+    if (it != s->tensors.end() && it->second.owned && it->second.dev)
+        (void) hipFree(it->second.dev);
+    s->tensors[name] = t;
+    s->finalized = false;
+    return 0;
+}
+
+int32_t tllm_session_finalize(tllm_session_t s)
+{
+    if (!s)
+        return 1;
+    const int D = s->hidden;
+    {
+        const TensorRec* t = s->find("vocab_embedding.weight");
+        RUN(s->want(t, "vocab_embedding.weight", TLLM_HALF, (int64_t) s->vocab * D));
+        s->emb = t->dev;
+        t = s->find("ln_f.weight");
+        RUN(s->want(t, "ln_f.weight", TLLM_HALF, D));
+        s->lnf = t->dev;
+        // lm_head stays fp16 in every quantisation mode (Q/quant.py:58)
+        RUN(s->resolve_linear("lm_head", s->Vr, D, s->head, true));
+    }
+    s->layers.assign(s->num_layers, Layer());
+    for (int i = 0; i < s->num_layers; ++i)
+    {
+        Layer& L = s->layers[i];
+        const std::string p = "layers." + std::to_string(i) + ".";
+        const TensorRec* t = s->find(p + "input_layernorm.weight");
+        RUN(s->want(t, p + "input_layernorm.weight", TLLM_HALF, D));
+        L.ln1 = t->dev;
+        t = s->find(p + "post_layernorm.weight");
+        RUN(s->want(t, p + "post_layernorm.weight", TLLM_HALF, D));
+        L.ln2 = t->dev;
+        RUN(s->resolve_linear(p + "attention.qkv", 3 * s->Dr, D, L.qkv));
+        RUN(s->resolve_linear(p + "attention.dense", D, s->Dr, L.dense));
+        RUN(s->resolve_linear(p + "mlp.fc", s->Ir, D, L.fc));
+        RUN(s->resolve_linear(p + "mlp.gate", s->Ir, D, L.gate));
+        RUN(s->resolve_linear(p + "mlp.proj", D, s->Ir, L.proj));
+        if (s->sq && !s->per_token)
+        {
+            RUN(s->scalar_f32(p + "input_layernorm.scale_to_int", &L.ln1_scale));
+            RUN(s->scalar_f32(p + "post_layernorm.scale_to_int", &L.ln2_scale));
+            RUN(s->scalar_f32(p + "attention.quantization_scaling_factor", &L.attn_qscale));
+            RUN(s->scalar_f32(p + "mlp.quantization_scaling_factor", &L.mlp_qscale));
+        }
+        if (s->int8_kv)
+        {
+            RUN(s->scalar_f32(p + "attention.kv_orig_quant_scale", &L.kv_oq));
+            RUN(s->scalar_f32(p + "attention.kv_quant_orig_scale", &L.kv_qo));
+        }
+    }
+    if (s->tp > 1 && !comm::has_comm(s->group))
+    {
+        set_error("session: tp_size=%d but no communicator registered (tllm_comm_init_rank)", s->tp);
+        return 1;
+    }
+    s->finalized = true;
+    return 0;
+}
+
+tllm_session_t tllm_session_load_engine(const void* engine, size_t nbytes)
+{
+    const char* p = static_cast<const char*>(engine);
+    auto fail = [](const char* why) {
+        set_error("tllm_session_load_engine: %s", why);
+        return (tllm_session_t) nullptr;
+    };
+    if (!p || nbytes < 24 || std::memcmp(p, "TLLMENG1", 8) != 0)
+        return fail("not a TLLMENG1 engine");
+    size_t off = 8;
+    auto rd64 = [&](uint64_t* v) {
+        if (off + 8 > nbytes)
+            return false;
+        std::memcpy(v, p + off, 8);
+        off += 8;
+        return true;
+    };
+    uint64_t hlen = 0, nt = 0;
+    if (!rd64(&hlen) || off + hlen > nbytes)
+        return fail("truncated header");
+    std::string cfg(p + off, p + off + hlen);
+    off += hlen;
+    if (!rd64(&nt))
+        return fail("truncated tensor table");
+    struct Ent
+    {
+        std::string name;
+        int32_t dtype, nd;
+        int64_t dims[8];
+        uint64_t nbytes, offset;
+    };
+    std::vector<Ent> ents(nt);
+    for (auto& e : ents)
+    {
+        uint32_t nl = 0;
+        if (off + 4 > nbytes)
+            return fail("truncated tensor table");
+        std::memcpy(&nl, p + off, 4);
+        off += 4;
+        if (off + nl + 8 > nbytes)
+            return fail("truncated tensor table");
+        e.name.assign(p + off, p + off + nl);
+        off += nl;
+        std::memcpy(&e.dtype, p + off, 4);
+        std::memcpy(&e.nd, p + off + 4, 4);
+        off += 8;
+        if (e.nd < 0 || e.nd > 8 || off + 8 * (size_t) e.nd + 16 > nbytes)
+            return fail("bad tensor entry");
+        std::memcpy(e.dims, p + off, 8 * (size_t) e.nd);
+        off += 8 * (size_t) e.nd;
+        std::memcpy(&e.nbytes, p + off, 8);
+        std::memcpy(&e.offset, p + off + 8, 8);
+        off += 16;
+    }
+    const size_t data0 = (off + 63) / 64 * 64;
+    tllm_session_t s = tllm_session_create(cfg.c_str());
+    if (!s)
+        return nullptr;
+    for (auto& e : ents)
+    {
+        if (data0 + e.offset + e.nbytes > nbytes)
+        {
+            tllm_session_destroy(s);
+            return fail("tensor data out of range");
+        }
+        if (tllm_session_set_tensor(s, e.name.c_str(), e.dtype, e.dims, e.nd, p + data0 + e.offset, 0))
+        {
+            tllm_session_destroy(s);
+            return nullptr;
+        }
+    }
+    if (tllm_session_finalize(s))
+    {
+        tllm_session_destroy(s);
+        return nullptr;
+    }
+    return s;
+}
+
+int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_input_len, int32_t max_new_tokens)
+{
+    if (!s || !s->finalized)
+    {
+        set_error("tllm_session_setup: session not finalized");
+        return 1;
+    }
+    if (batch_size < 1 || max_input_len < 1 || max_new_tokens < 0)
+    {
+        set_error("tllm_session_setup: bad sizes");
+        return 1;
+    }
+    s->free_runtime();
+    s->B = batch_size;
+    s->max_in = max_input_len;
+    s->max_new = max_new_tokens;
+    s->Smax = max_input_len + max_new_tokens; // generation.py:450-461
+    const int B = s->B, S = s->max_in, D = s->hidden, Smax = s->Smax;
+    const size_t M = (size_t) B * S;
+    const size_t kv_bytes = (size_t) B * 2 * s->Hr * Smax * s->Dh * (s->int8_kv ? 1 : 2);
+    for (auto& L : s->layers)
+    {
+        RUN(s->dalloc(&L.kv, kv_bytes));
+        HIP_OK(hipMemset(L.kv, 0, kv_bytes));
+    }
+    RUN(s->dalloc(&s->x, M * D * 2));
+    RUN(s->dalloc(&s->tmp, M * D * 2));
+    RUN(s->dalloc(&s->qkv, M * 3 * s->Dr * 2));
+    RUN(s->dalloc(&s->ctx, M * s->Dr * 2));
+    RUN(s->dalloc(&s->g, M * s->Ir * 2));
+    RUN(s->dalloc(&s->u, M * s->Ir * 2));
+    RUN(s->dalloc(&s->inter_buf, M * s->Ir * 2));
+    RUN(s->dalloc(&s->q8, M * (size_t) std::max(D, s->Ir)));
+    RUN(s->dalloc(&s->qscale, M * 4));
+    RUN(s->dalloc(&s->logits_local, (size_t) B * s->Vr * 4));
+    RUN(s->dalloc(&s->logits, (size_t) B * s->Vr * s->tp * 4));
+    RUN(s->dalloc(&s->last_hidden, (size_t) B * D * 2));
+    RUN(s->dalloc(&s->mmha_ws, mmha_workspace_size(B, s->Hr, s->Dh, Smax) + 256));
+    HIP_OK(hipMemset(s->mmha_ws, 0, mmha_workspace_size(B, s->Hr, s->Dh, Smax) + 256));
+    RUN(s->dalloc(&s->ids_in, M * 4));
+    RUN(s->dalloc(&s->cur_ids, (size_t) B * 4));
+    RUN(s->dalloc(&s->out_ids, (size_t) B * Smax * 4));
+    RUN(s->dalloc(&s->seq_len, (size_t) B * 4));
+    RUN(s->dalloc(&s->in_len, (size_t) B * 4));
+    RUN(s->dalloc(&s->last_tok, (size_t) B * 4));
+    RUN(s->dalloc(&s->finished, (size_t) B * 4));
+    RUN(s->dalloc(&s->masked, (size_t) B * Smax * 4));
+    s->rope = plugins::rope_table(s->Dh, Smax > s->max_pos ? Smax : s->max_pos, &s->rope_len);
+    if (!s->rope)
+        return 1;
+    return 0;
+}
+
+static int upload_prompt(tllm_session_t s, const int32_t* input_ids, const int32_t* input_lengths, hipStream_t st)
+{
+    const int B = s->B, S = s->max_in, Smax = s->Smax;
+    std::vector<int32_t> lens(input_lengths, input_lengths + B), seq(B, S), zeros(B, 0);
+    std::vector<int32_t> mask((size_t) B * Smax, 0), out((size_t) B * Smax, 0);
+    for (int b = 0; b < B; ++b)
+    {
+        if (lens[b] < 1 || lens[b] > S)
+        {
+            set_error("session: input_lengths[%d]=%d out of range [1, %d]", b, lens[b], S);
+            return 1;
+        }
+        // masked_tokens[b, len_b:max_in] = 1 (generation.py:812-821)
+        for (int t = lens[b]; t < S; ++t)
+            mask[(size_t) b * Smax + t] = 1;
+        for (int t = 0; t < S; ++t)
+            out[(size_t) b * Smax + t] = input_ids[(size_t) b * S + t];
+    }
+    HIP_OK(hipMemcpyAsync(s->ids_in, input_ids, (size_t) B * S * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(s->in_len, lens.data(), B * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(s->last_tok, lens.data(), B * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(s->seq_len, seq.data(), B * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(s->finished, zeros.data(), B * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(s->masked, mask.data(), mask.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(s->out_ids, out.data(), out.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipStreamSynchronize(st)); // the host vectors above go out of scope
+    return 0;
+}
+
+int32_t tllm_session_context(tllm_session_t s, const int32_t* input_ids, const int32_t* input_lengths,
+    tllm_stream_t stream)
+{
+    if (!s || !s->B)
+    {
+        set_error("tllm_session_context: call tllm_session_setup first");
+        return 1;
+    }
+    hipStream_t st = s->pick(stream);
+    RUN(upload_prompt(s, input_ids, input_lengths, st));
+    RUN(s->run_context(st));
+    RUN(s->run_sampler(0, st));
+    return 0;
+}
+
+int32_t tllm_session_step(tllm_session_t s, int32_t n_steps, int32_t use_graph, tllm_stream_t stream)
+{
+    if (!s || !s->B)
+    {
+        set_error("tllm_session_step: call tllm_session_setup first");
+        return 1;
+    }
+    hipStream_t st = s->pick(stream);
+    if (use_graph && (!s->graph || s->graph_stream != st))
+    {
+        if (s->graph)
+        {
+            (void) hipGraphExecDestroy(s->graph);
+            s->graph = nullptr;
+        }
+        hipGraph_t g = nullptr;
+        HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        const int rc = s->run_decode_step(st);
+        const hipError_t ce = hipStreamEndCapture(st, &g);
+        if (rc || ce != hipSuccess || !g)
+        {
+            if (!rc)
+                set_error("session: hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+            return 1;
+        }
+        const hipError_t ie = hipGraphInstantiate(&s->graph, g, nullptr, nullptr, 0);
+        (void) hipGraphDestroy(g);
+        if (ie != hipSuccess)
+        {
+            set_error("session: hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+            s->graph = nullptr;
+            return 1;
+        }
+        s->graph_stream = st;
+    }
+    for (int i = 0; i < n_steps; ++i)
+    {
+        if (use_graph)
+            HIP_OK(hipGraphLaunch(s->graph, st));
+        else
+            RUN(s->run_decode_step(st));
+    }
+    return 0;
+}
+
+int32_t tllm_session_fake_context(tllm_session_t s, int32_t length, uint32_t seed, tllm_stream_t stream)
+{
+    if (!s || !s->B || length < 1 || length > s->max_in)
+    {
+        set_error("tllm_session_fake_context: bad length");
+        return 1;
+    }
+    hipStream_t st = s->pick(stream);
+    const int B = s->B, S = s->max_in;
+    std::vector<int32_t> ids((size_t) B * S, 3), lens(B, length);
+    // a padded prompt of `length` real tokens: slots [length, max_in) are masked
+    RUN(upload_prompt(s, ids.data(), lens.data(), st));
+    const size_t kv_elems = (size_t) B * 2 * s->Hr * s->Smax * s->Dh;
+    for (int i = 0; i < s->num_layers; ++i)
+        RUN(launch_fill_random(s->layers[i].kv, s->int8_kv ? DT_INT8 : DT_HALF, kv_elems, seed + 7919u * i, 1.0f, st));
+    RUN(launch_fill_i32(s->cur_ids, 3, B, st));
+    return 0;
+}
+
+int32_t tllm_session_generate(tllm_session_t s, const int32_t* input_ids, const int32_t* input_lengths,
+    int32_t max_new_tokens, int32_t end_id, int32_t pad_id, int32_t* output_ids, tllm_stream_t stream)
+{
+    (void) pad_id;
+    if (!s || !s->B || !input_ids || !input_lengths || !output_ids)
+    {
+        set_error("tllm_session_generate: bad arguments / setup not called");
+        return 1;
+    }
+    if (max_new_tokens > s->max_new)
+    {
+        set_error("tllm_session_generate: max_new_tokens %d exceeds setup's %d", max_new_tokens, s->max_new);
+        return 1;
+    }
+    hipStream_t st = s->pick(stream);
+    s->end_id = end_id;
+    if (s->graph)
+    {
+        // end_id is baked into the captured sampler node
+        (void) hipGraphExecDestroy(s->graph);
+        s->graph = nullptr;
+    }
+    RUN(tllm_session_context(s, input_ids, input_lengths, stream));
+    if (max_new_tokens > 1)
+    {
+        // first generation step eagerly (also warms lazily-initialised state), the rest from the graph
+        RUN(tllm_session_step(s, 1, 0, stream));
+        if (max_new_tokens > 2)
+        {
+            const int chunk = 32; // poll the finished flags every `chunk` steps instead of every step
+            int done = 2;
+            std::vector<int32_t> fin(s->B);
+            while (done < max_new_tokens)
+            {
+                const int n = std::min(chunk, max_new_tokens - done);
+                RUN(tllm_session_step(s, n, 1, stream));
+                done += n;
+                if (end_id >= 0 && done < max_new_tokens)
+                {
+                    HIP_OK(hipMemcpyAsync(fin.data(), s->finished, s->B * 4, hipMemcpyDeviceToHost, st));
+                    HIP_OK(hipStreamSynchronize(st));
+                    bool all = true;
+                    for (auto f : fin)
+                        all = all && f;
+                    if (all)
+                        break;
+                }
+            }
+        }
+    }
+    return tllm_session_get_output_ids(s, output_ids, stream);
+}
+
+int32_t tllm_session_get_logits(tllm_session_t s, float* logits, tllm_stream_t stream)
+{
+    if (!s || !s->B || !logits)
+        return 1;
+    hipStream_t st = s->pick(stream);
+    if (s->tp == 1)
+    {
+        HIP_OK(hipMemcpyAsync(logits, s->logits_local, (size_t) s->B * s->vocab * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        return 0;
+    }
+    std::vector<float> g((size_t) s->tp * s->B * s->Vr);
+    HIP_OK(hipMemcpyAsync(g.data(), s->logits, g.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    for (int b = 0; b < s->B; ++b)
+        for (int v = 0; v < s->vocab; ++v)
+            logits[(size_t) b * s->vocab + v] = g[((size_t) (v / s->Vr) * s->B + b) * s->Vr + v % s->Vr];
+    return 0;
+}
+
+int32_t tllm_session_get_output_ids(tllm_session_t s, int32_t* ids, tllm_stream_t stream)
+{
+    if (!s || !s->B || !ids)
+        return 1;
+    hipStream_t st = s->pick(stream);
+    HIP_OK(hipMemcpyAsync(ids, s->out_ids, (size_t) s->B * s->Smax * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;
+}
+
+void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer)
+{
+    if (!s || layer < 0 || layer >= (int) s->layers.size())
+        return nullptr;
+    return s->layers[layer].kv;
+}
+
+int64_t tllm_session_step_bytes(tllm_session_t s, int32_t context_len)
+{
+    if (!s)
+        return 0;
+    // weights once + KV read of `context_len` positions + KV write of one position, per rank
+    auto lin = [&](const Linear& L) {
+        int64_t b = (int64_t) L.N * L.ldw;
+        if (L.wtype == W_INT8_WOQ || L.wtype == W_INT4_WOQ)
+            b += (int64_t) L.N * 2;
+        else if (L.wtype == W_INT8_SQ && L.per_channel)
+            b += (int64_t) L.N * 4;
+        return b;
+    };
+    int64_t bytes = lin(s->head);
+    const int64_t kv_row = (int64_t) 2 * s->Hr * s->Dh * (s->int8_kv ? 1 : 2);
+    for (auto& L : s->layers)
+        bytes += lin(L.qkv) + lin(L.dense) + lin(L.fc) + lin(L.gate) + lin(L.proj) + kv_row * s->B * (context_len + 1);
+    return bytes;
+}
+
+int32_t tllm_session_profile(tllm_session_t s, int32_t n_steps, float* ms_per_class, int64_t* launches_per_class,
+    tllm_stream_t stream)
+{
+    if (!s || !s->B || n_steps < 1 || !ms_per_class || !launches_per_class)
+    {
+        set_error("tllm_session_profile: bad arguments / setup not called");
+        return 1;
+    }
+    hipStream_t st = s->pick(stream);
+    s->profiling = true;
+    s->prof.clear();
+    int rc = 0;
+    for (int i = 0; i < n_steps && !rc; ++i)
+        rc = s->run_decode_step(st);
+    s->profiling = false;
+    (void) hipStreamSynchronize(st);
+    for (int c = 0; c < tllm_session::PC_COUNT; ++c)
+    {
+        ms_per_class[c] = 0.f;
+        launches_per_class[c] = 0;
+    }
+    for (auto& r : s->prof)
+    {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess)
+        {
+            ms_per_class[r.cls] += ms;
+            launches_per_class[r.cls] += 1;
+        }
+        (void) hipEventDestroy(r.a);
+        (void) hipEventDestroy(r.b);
+    }
+    s->prof.clear();
+    return rc;
+}
+
+void tllm_session_destroy(tllm_session_t s)
+{
+    delete s;
+}
+
+int32_t tllm_gemv(const tllm_gemv_params_t* q, tllm_stream_t stream)
+{
+    if (!q)
+        return 1;
+    GemvParams p;
+    p.wtype = q->wtype;
+    p.pro = q->pro;
+    p.epi = q->epi;
+    p.out_dtype = q->out_dtype;
+    p.M = q->M;
+    p.N = q->N;
+    p.K = q->K;
+    p.x = q->x;
+    p.ldx = q->ldx;
+    p.w = q->w;
+    p.ldw = q->ldw;
+    p.scale_col = q->scale_col;
+    p.scale_row = q->scale_row;
+    p.per_channel = q->per_channel;
+    p.per_token = q->per_token;
+    p.gamma = q->gamma;
+    p.eps = q->eps;
+    p.act_scale = q->act_scale;
+    p.dyn_scale_out = q->dyn_scale_out;
+    p.x_pro_out = q->x_pro_out;
+    p.residual = q->residual;
+    p.epi_scale = q->epi_scale;
+    p.y = q->y;
+    p.ldy = q->ldy;
+    return launch_gemv(p, reinterpret_cast<hipStream_t>(stream)) ? 1 : 0;
+}
+
+void tllm_gemv_set_rows_per_wave(int32_t r)
+{
+    tllm::kernels::gemv_tune_r = r;
+}
+
+void tllm_gemv_set_blocks_per_cu(int32_t n)
+{
+    tllm::kernels::gemv_tune_blocks_per_cu = n;
+}
+
+} // extern "C"

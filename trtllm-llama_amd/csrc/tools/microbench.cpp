@@ -1,0 +1,136 @@
+// Kernel sweep harness (GPU box only): times the fused skinny GEMM of the generation step on the LLaMA-7B shapes
+// through the C ABI, rotating over enough weight copies to defeat the 256 MiB Infinity Cache.
+//   build/microbench [rows_per_wave]
+#include "../../../include/tllm_runtime_api.h"
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+#define CK(x)                                                                                                          \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e = (x);                                                                                            \
+        if (e != hipSuccess)                                                                                           \
+        {                                                                                                              \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__);                               \
+            exit(1);                                                                                                   \
+        }                                                                                                              \
+    } while (0)
+
+struct Case
+{
+    const char* name;
+    int wtype, pro, epi, out_dtype, N, K;
+};
+
+int main(int argc, char** argv)
+{
+    if (argc > 1)
+        tllm_gemv_set_rows_per_wave(atoi(argv[1]));
+    if (argc > 2)
+        tllm_gemv_set_blocks_per_cu(atoi(argv[2]));
+    const char* only = argc > 3 ? argv[3] : nullptr;
+    initLibNvInferPlugins(nullptr, "tensorrt_llm");
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    const int D = 4096, I = 11008, V = 32000;
+    // wtype: 0 fp16 1 woq8 2 woq4 3 sq ; pro: 0 none 1 rms 2 rms+qs 4 qs ; epi: 0 none 1 res 2 swiglu 3 swiglu+q
+    std::vector<Case> cases = {
+        {"sq   qkv    rms+q      ", 3, 2, 0, 1, 3 * D, D},
+        {"sq   o      q  +res    ", 3, 4, 1, 1, D, D},
+        {"sq   gateup rms+q swi+q", 3, 2, 3, 2, I, D},
+        {"sq   down   none +res  ", 3, 0, 1, 1, D, I},
+        {"woq8 qkv    rms        ", 1, 1, 0, 1, 3 * D, D},
+        {"woq8 o      +res       ", 1, 0, 1, 1, D, D},
+        {"woq8 gateup rms swi    ", 1, 1, 2, 1, I, D},
+        {"woq8 down   +res       ", 1, 0, 1, 1, D, I},
+        {"woq4 qkv    rms        ", 2, 1, 0, 1, 3 * D, D},
+        {"woq4 gateup rms swi    ", 2, 1, 2, 1, I, D},
+        {"woq4 down   +res       ", 2, 0, 1, 1, D, I},
+        {"fp16 qkv    rms        ", 0, 1, 0, 1, 3 * D, D},
+        {"fp16 o      +res       ", 0, 0, 1, 1, D, D},
+        {"fp16 gateup rms swi    ", 0, 1, 2, 1, I, D},
+        {"fp16 down   +res       ", 0, 0, 1, 1, D, I},
+        {"fp16 head   rms f32out ", 0, 1, 0, 0, V, D},
+    };
+    void *x, *gamma, *res, *y, *scales, *fs;
+    CK(hipMalloc(&x, 65536));
+    CK(hipMalloc(&gamma, 65536));
+    CK(hipMalloc(&res, 1 << 20));
+    CK(hipMalloc(&y, 1 << 20));
+    CK(hipMalloc(&scales, 1 << 20));
+    CK(hipMalloc(&fs, 256));
+    CK(hipMemset(x, 0x11, 65536));
+    CK(hipMemset(gamma, 0x3c, 65536));
+    CK(hipMemset(res, 0, 1 << 20));
+    CK(hipMemset(scales, 0x11, 1 << 20));
+    float one[4] = {1.f, 1.f, 1.f, 1.f};
+    CK(hipMemcpy(fs, one, 16, hipMemcpyHostToDevice));
+    const size_t pool_bytes = (size_t) 1200 << 20;
+    char* pool;
+    CK(hipMalloc(&pool, pool_bytes));
+    CK(hipMemset(pool, 0x37, pool_bytes));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    printf("%-26s %8s %9s %9s %8s\n", "case", "MB", "us", "GB/s", "frac8T");
+    for (auto& c : cases)
+    {
+        if (only && !strstr(c.name, only))
+            continue;
+        const bool swi = c.epi >= 2;
+        const int64_t ldw = c.wtype == 0 ? (int64_t) c.K * 2 : (c.wtype == 2 ? c.K / 2 : c.K);
+        const int64_t rows = swi ? 2 * c.N : c.N;
+        const size_t wbytes = (size_t) rows * ldw;
+        int ncopy = (int) (pool_bytes / wbytes);
+        if (getenv("MB_NCOPY"))
+            ncopy = std::min(ncopy, atoi(getenv("MB_NCOPY")));
+        tllm_gemv_params_t p;
+        memset(&p, 0, sizeof(p));
+        p.wtype = c.wtype;
+        p.pro = c.pro;
+        p.epi = c.epi;
+        p.out_dtype = c.out_dtype;
+        p.M = 1;
+        p.N = c.N;
+        p.K = c.K;
+        p.x = x;
+        p.ldx = c.K;
+        p.ldw = ldw;
+        p.scale_col = scales;
+        p.scale_row = (const float*) fs;
+        p.per_channel = 1;
+        p.gamma = gamma;
+        p.eps = 1e-6f;
+        p.act_scale = (const float*) fs;
+        p.residual = res;
+        p.epi_scale = (const float*) fs;
+        p.y = y;
+        p.ldy = c.N;
+        const int iters = 60;
+        for (int rep = 0; rep < 2; ++rep)
+        {
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i)
+            {
+                p.w = pool + (size_t) (i % ncopy) * wbytes;
+                if (tllm_gemv(&p, (tllm_stream_t) st))
+                {
+                    printf("%s: %s\n", c.name, tllm_last_error());
+                    return 1;
+                }
+            }
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+        }
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / iters;
+        const double gbs = wbytes / us / 1e3;
+        printf("%-26s %8.1f %9.2f %9.1f %8.3f\n", c.name, wbytes / 1048576.0, us, gbs, gbs / 8000.0);
+    }
+    return 0;
+}
