@@ -121,6 +121,26 @@ void tllm_gemv_set_rows_per_wave(int32_t r);
 /* Test/bench knob: persistent workgroups per CU (0 = occupancy query). */
 void tllm_gemv_set_blocks_per_cu(int32_t n);
 
+/* Kernel-level entry for the prefill GEMMs (kernels/gemm_mfma.hip; M <= 8 goes to the skinny GEMM):
+ * C[m,n] = epi(sum_k A[m,k] W[n,k]); wtype / layouts / scales as tllm_gemv_params_t.  Used by the MFMA-utilisation
+ * report (SmoothQuant GEMM at M = 1024) and by parity tests. */
+typedef struct
+{
+    int32_t wtype, out_dtype;
+    int32_t M, N, K;
+    const void* a;
+    int64_t lda;
+    const void* w;
+    int64_t ldw;
+    const void* scale_col;
+    const float* scale_row;
+    int32_t per_channel, per_token;
+    void* c;
+    int64_t ldc;
+} tllm_gemm_params_t;
+
+int32_t tllm_gemm(const tllm_gemm_params_t* p, tllm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1192,6 +1192,29 @@ int32_t tllm_gemv(const tllm_gemv_params_t* q, tllm_stream_t stream)
     return launch_gemv(p, reinterpret_cast<hipStream_t>(stream)) ? 1 : 0;
 }
 
+int32_t tllm_gemm(const tllm_gemm_params_t* q, tllm_stream_t stream)
+{
+    if (!q)
+        return 1;
+    GemmParams g;
+    g.wtype = q->wtype;
+    g.out_dtype = q->out_dtype;
+    g.M = q->M;
+    g.N = q->N;
+    g.K = q->K;
+    g.a = q->a;
+    g.lda = q->lda;
+    g.w = q->w;
+    g.ldw = q->ldw;
+    g.scale_col = q->scale_col;
+    g.scale_row = q->scale_row;
+    g.per_channel = q->per_channel;
+    g.per_token = q->per_token;
+    g.c = q->c;
+    g.ldc = q->ldc;
+    return launch_gemm(g, reinterpret_cast<hipStream_t>(stream)) ? 1 : 0;
+}
+
 void tllm_gemv_set_rows_per_wave(int32_t r)
 {
     tllm::kernels::gemv_tune_r = r;

@@ -69,13 +69,66 @@ int main(int argc, char** argv)
     CK(hipMemset(scales, 0x11, 1 << 20));
     float one[4] = {1.f, 1.f, 1.f, 1.f};
     CK(hipMemcpy(fs, one, 16, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
     const size_t pool_bytes = (size_t) 1200 << 20;
     char* pool;
     CK(hipMalloc(&pool, pool_bytes));
     CK(hipMemset(pool, 0x37, pool_bytes));
-    hipEvent_t e0, e1;
-    CK(hipEventCreate(&e0));
-    CK(hipEventCreate(&e1));
+    if (only && !strcmp(only, "gemm"))
+    {
+        // prefill-shaped GEMMs: M = 1024, the four LLaMA-7B layer shapes
+        struct GC { const char* name; int wtype, N, K; };
+        std::vector<GC> gcs = {{"sq   qkv ", 3, 3 * D, D}, {"sq   o   ", 3, D, D}, {"sq   fc  ", 3, I, D}, {"sq   down", 3, D, I},
+                               {"fp16 qkv ", 0, 3 * D, D}, {"fp16 fc  ", 0, I, D}, {"fp16 down", 0, D, I},
+                               {"woq8 qkv ", 1, 3 * D, D}, {"woq4 qkv ", 2, 3 * D, D}};
+        const int Mg = argc > 4 ? atoi(argv[4]) : 1024;
+        void *a, *c;
+        CK(hipMalloc(&a, (size_t) Mg * I * 2));
+        CK(hipMemset(a, 0x3c, (size_t) Mg * I * 2));
+        CK(hipMalloc(&c, (size_t) Mg * 3 * D * 4));
+        printf("%-12s %6s %9s %10s %9s\n", "gemm", "M", "us", "TOP/s", "frac_peak");
+        for (auto& g : gcs)
+        {
+            tllm_gemm_params_t q;
+            memset(&q, 0, sizeof(q));
+            q.wtype = g.wtype;
+            q.out_dtype = 1;
+            q.M = Mg;
+            q.N = g.N;
+            q.K = g.K;
+            q.a = a;
+            q.lda = g.K;
+            q.w = pool;
+            q.ldw = g.wtype == 0 ? (int64_t) g.K * 2 : (g.wtype == 2 ? g.K / 2 : g.K);
+            q.scale_col = scales;
+            q.scale_row = (const float*) fs;
+            q.per_channel = 1;
+            q.c = c;
+            q.ldc = g.N;
+            const int iters = 20;
+            for (int rep = 0; rep < 2; ++rep)
+            {
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < iters; ++i)
+                    if (tllm_gemm(&q, (tllm_stream_t) st))
+                    {
+                        printf("%s: %s\n", g.name, tllm_last_error());
+                        return 1;
+                    }
+                CK(hipEventRecord(e1, st));
+                CK(hipEventSynchronize(e1));
+            }
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = ms * 1e3 / iters;
+            const double tops = 2.0 * Mg * g.N * g.K / us / 1e6;
+            const double peak = g.wtype == 3 ? 5000.0 : 2500.0; // dense int8 / fp16 MFMA peaks, TOP/s (MI355X_MICROARCH.md)
+            printf("%-12s %6d %9.2f %10.1f %9.3f\n", g.name, Mg, us, tops, tops / peak);
+        }
+        return 0;
+    }
     printf("%-26s %8s %9s %9s %8s\n", "case", "MB", "us", "GB/s", "frac8T");
     for (auto& c : cases)
     {
