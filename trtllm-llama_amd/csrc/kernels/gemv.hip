@@ -246,6 +246,55 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     uint4 wv[U][R];
     rows_of_group(g0 < a.ngroups ? g0 : 0, rowptr);
     load_tile(rowptr, 0, wv);
+    // 2b. ... and everything else that does not depend on x: the epilogue operands (scales, residual) of this
+    //     wave's first row group and the launch-constant scales.  (Requested after the tile so that waiting for x
+    //     does not wait for them; consumed after the dot products.)
+    const int gstride = gridDim.x * 4;
+    const int nouts = swiglu ? R / 2 : R;
+    const int my_o = lane / MB, my_m = lane % MB; // the (output, row) this lane finishes
+    const bool my_active = my_o < nouts && my_m < p.M;
+    struct EpiOps
+    {
+        float s0, s1, res;
+    };
+    auto load_ops = [&](int g) {
+        EpiOps e = {1.f, 1.f, 0.f};
+        const int n = swiglu ? g * (R / 2) + my_o : g * R + my_o;
+        if (!(my_active && g < a.ngroups && n < p.N))
+            return e;
+        if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
+        {
+            const uint16_t* sc = reinterpret_cast<const uint16_t*>(p.scale_col);
+            e.s0 = h2f(sc[n]);
+            if (swiglu)
+                e.s1 = p.scale_col_up ? h2f(reinterpret_cast<const uint16_t*>(p.scale_col_up)[n]) : h2f(sc[p.N + n]);
+        }
+        else if constexpr (SQ)
+        {
+            const float* sc = reinterpret_cast<const float*>(p.scale_col);
+            e.s0 = p.per_channel ? sc[n] : sc[0];
+            if (swiglu)
+            {
+                const float* su = reinterpret_cast<const float*>(p.scale_col_up);
+                e.s1 = su ? (p.per_channel ? su[n] : su[0]) : (p.per_channel ? sc[p.N + n] : sc[0]);
+            }
+        }
+        if (p.epi == EPI_RESIDUAL)
+            e.res = h2f(reinterpret_cast<const uint16_t*>(p.residual)[(int64_t) my_m * p.ldy + n]);
+        return e;
+    };
+    EpiOps ops_cur = load_ops(g0);
+    float static_row_scale = 1.f, static_row_scale_up = 1.f, epi_q = 1.f, pro_q = 1.f;
+    if constexpr (SQ)
+    {
+        if (!q_dyn && p.scale_row)
+            static_row_scale = (p.per_token && my_active) ? p.scale_row[my_m] : p.scale_row[0];
+        static_row_scale_up = (!q_dyn && p.scale_row_up) ? p.scale_row_up[0] : static_row_scale;
+        if (q_static)
+            pro_q = p.act_scale[0];
+    }
+    if (p.epi == EPI_SWIGLU_QSTATIC)
+        epi_q = p.epi_scale[0];
 
     // 3. build pro(x) in LDS
     if (reg_path)
@@ -328,7 +377,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
                     p.dyn_scale_out[m] = amax / 127.f;
             }
             else if (SQ && q_static)
-                qs = p.act_scale[0];
+                qs = pro_q;
 #pragma unroll
             for (int j = 0; j < kNXV; ++j)
             {
@@ -454,22 +503,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     // Persistent waves: wave w of workgroup b owns row groups g0, g0 + stride, ...; its tiles (U chunks x R rows,
     // 16-byte loads) are double-buffered: while tile t is being reduced, tile t+1 is in flight, and the epilogue
     // operands (scales, residual) of t are requested BEFORE t+1 so that waiting for them never drains the stream.
-    const int gstride = gridDim.x * 4;
     const int tiles_per_group = (a.nchunks + U - 1) / U;
     const int ngroups_mine = g0 < a.ngroups ? (a.ngroups - g0 + gstride - 1) / gstride : 0;
     const int ntiles = ngroups_mine * tiles_per_group;
-    const int nouts = swiglu ? R / 2 : R;
-    const int my_o = lane / MB, my_m = lane % MB; // the (output, row) this lane finishes
-    const bool my_active = my_o < nouts && my_m < p.M;
-    float my_row_scale = 1.f;
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-        if (m == my_m)
-            my_row_scale = row_scale[m];
-    if constexpr (SQ)
+    float my_row_scale = static_row_scale, my_row_scale_up = static_row_scale_up;
+    if (q_dyn)
     {
-        if (!q_dyn && my_active)
-            my_row_scale = p.per_token ? p.scale_row[my_m] : p.scale_row[0];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            if (m == my_m)
+                my_row_scale = my_row_scale_up = row_scale[m];
     }
 
     acc_t acc[R][MB];
@@ -493,32 +536,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         const int g = g0 + gi_p * gstride;
         const int n = swiglu ? g * (R / 2) + my_o : g * R + my_o;
         const bool fin = last && my_active && n < p.N;
-        // (1) epilogue operands of this group
-        float s0 = 1.f, s1 = 1.f, resv = 0.f;
+        // (1) epilogue operands: this group's were requested one group ahead (ops_cur); request the next group's
         const int64_t oidx = (int64_t) my_m * p.ldy + n;
-        if (fin)
-        {
-            if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
-            {
-                const uint16_t* sc = reinterpret_cast<const uint16_t*>(p.scale_col);
-                s0 = h2f(sc[n]);
-                if (swiglu)
-                    s1 = p.scale_col_up ? h2f(reinterpret_cast<const uint16_t*>(p.scale_col_up)[n]) : h2f(sc[p.N + n]);
-            }
-            else if constexpr (SQ)
-            {
-                const float* sc = reinterpret_cast<const float*>(p.scale_col);
-                s0 = (p.per_channel ? sc[n] : sc[0]) * my_row_scale;
-                if (swiglu)
-                {
-                    const float* su = reinterpret_cast<const float*>(p.scale_col_up);
-                    const float sru = (!q_dyn && p.scale_row_up) ? p.scale_row_up[0] : my_row_scale;
-                    s1 = (su ? (p.per_channel ? su[n] : su[0]) : (p.per_channel ? sc[p.N + n] : sc[0])) * sru;
-                }
-            }
-            if (p.epi == EPI_RESIDUAL)
-                resv = h2f(reinterpret_cast<const uint16_t*>(p.residual)[oidx]);
-        }
+        EpiOps ops_nxt = ops_cur;
+        if (last)
+            ops_nxt = load_ops(g + gstride);
         // (2) next tile into the other buffer
         if (t_issue < ntiles)
         {
@@ -608,8 +630,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
                 if (swiglu && r >= R / 2 && lane == (r - R / 2) * MB + m)
                     v1 = (float) tot;
             }
+        const EpiOps e = ops_cur;
+        ops_cur = ops_nxt;
         if (!fin)
             return;
+        const float s0 = e.s0 * my_row_scale, s1 = e.s1 * my_row_scale_up, resv = e.res;
         const float r0 = v0 * s0;
         if (p.epi == EPI_NONE)
         {
@@ -628,7 +653,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
             if (p.epi == EPI_SWIGLU)
                 reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(o16);
             else
-                reinterpret_cast<int8_t*>(p.y)[oidx] = f2i8_rni_sat(o16 * p.epi_scale[0]);
+                reinterpret_cast<int8_t*>(p.y)[oidx] = f2i8_rni_sat(o16 * epi_q);
         }
     };
 

@@ -251,9 +251,44 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const GreedyParams p)
     for (int part = 0; part < p.nparts; ++part)
     {
         const float* l = p.logits + ((int64_t) part * p.batch + b) * p.vocab_part;
+        const int base_id = part * p.vocab_part;
+        if ((p.vocab_part & 3) == 0 && (reinterpret_cast<uintptr_t>(l) & 15) == 0)
+        {
+            // 16-byte loads, all of a thread's requests in flight before the compares (latency-bound otherwise)
+            constexpr int UNR = 8;
+            const int nvec = p.vocab_part >> 2;
+            for (int v0 = threadIdx.x; v0 < nvec; v0 += blockDim.x * UNR)
+            {
+                float4 vals[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                {
+                    const int vi = v0 + u * blockDim.x;
+                    vals[u] = vi < nvec ? reinterpret_cast<const float4*>(l)[vi]
+                                        : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                {
+                    const int id0 = base_id + (v0 + u * blockDim.x) * 4;
+                    const float f[4] = {vals[u].x, vals[u].y, vals[u].z, vals[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                    {
+                        const int id = id0 + e;
+                        if (id < p.vocab && (f[e] > best || (f[e] == best && id < bi)))
+                        {
+                            best = f[e];
+                            bi = id;
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         for (int i = threadIdx.x; i < p.vocab_part; i += blockDim.x)
         {
-            const int id = part * p.vocab_part + i;
+            const int id = base_id + i;
             if (id >= p.vocab)
                 break;
             const float v = l[i];

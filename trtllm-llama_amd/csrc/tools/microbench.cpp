@@ -55,6 +55,21 @@ int main(int argc, char** argv)
         {"fp16 gateup rms swi    ", 0, 1, 2, 1, I, D},
         {"fp16 down   +res       ", 0, 0, 1, 1, D, I},
         {"fp16 head   rms f32out ", 0, 1, 0, 0, V, D},
+        {"x sq N65536 K4096 rmsq ", 3, 2, 0, 1, 65536, D},
+        {"x sq N6144  K8192 rmsq ", 3, 2, 0, 1, 6144, 8192},
+        {"x sq N12288 K4096 none ", 3, 0, 0, 1, 3 * D, D},
+        {"x sq N22016 K4096 rmsq ", 3, 2, 0, 1, 2 * I, D},
+        {"x sq N2048  K4096 rmsq ", 3, 2, 0, 1, 2048, D},
+        {"x sq N256   K4096 rmsq ", 3, 2, 0, 1, 256, D},
+        {"y sq  N256 none none   ", 3, 0, 0, 1, 256, D},
+        {"y sq  N264 rmsq none   ", 3, 2, 0, 1, 264, D},
+        {"y sq  N272 q    res    ", 3, 4, 1, 1, 272, D},
+        {"y fp  N280 none none   ", 0, 0, 0, 1, 280, D},
+        {"y fp  N288 rms  none   ", 0, 1, 0, 1, 288, D},
+        {"y fp  N296 rms  res    ", 0, 1, 1, 1, 296, D},
+        {"y w8  N304 rms  none   ", 1, 1, 0, 1, 304, D},
+        {"x fp N12288 K4096 rms  ", 0, 1, 0, 1, 3 * D, D},
+        {"x fp N6144  K4096 rms  ", 0, 1, 0, 1, 6144, D},
     };
     void *x, *gamma, *res, *y, *scales, *fs;
     CK(hipMalloc(&x, 65536));
