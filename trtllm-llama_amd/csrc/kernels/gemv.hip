@@ -171,8 +171,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     int8_t* xq = reinterpret_cast<int8_t*>(smem + kRedBytes + (size_t) a.xh_bytes * MB);
     const bool x_is_half = !(SQ && p.pro == PRO_NONE);
     const bool do_norm = p.pro == PRO_RMSNORM || p.pro == PRO_RMSNORM_QSTATIC || p.pro == PRO_RMSNORM_QDYN;
-    const bool q_static = p.pro == PRO_RMSNORM_QSTATIC || p.pro == PRO_QSTATIC;
-    const bool q_dyn = p.pro == PRO_RMSNORM_QDYN || p.pro == PRO_QDYN;
+    const bool q_static = p.pro == PRO_RMSNORM_QSTATIC || p.pro == PRO_QSTATIC || p.pro == PRO_ATTN_QSTATIC;
+    const bool q_dyn = p.pro == PRO_RMSNORM_QDYN || p.pro == PRO_QDYN || p.pro == PRO_ATTN_QDYN;
+    const bool attn = p.pro >= PRO_ATTN;
     float row_scale[MB]; // per-token dequant scale when the prologue quantises dynamically
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -200,44 +201,106 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
             }
         }
     };
+    // No branches around loads anywhere in this kernel: a lane-dependent `if` makes the compiler fence every load
+    // with s_waitcnt + exec masking, which serialises the memory round trips.  Out-of-range lanes load a clamped,
+    // valid address and the value is replaced by a select.
+    const int64_t last_vec = p.ldw - 16; // byte offset of the last 16-byte vector of a weight row
     auto load_tile = [&](const char* const (&rowptr)[R], int c, uint4 (&wv)[U][R]) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
         {
             const bool ok = ((c + u) * 64 + lane) * VEC < Kp;
+            int64_t off = (int64_t) (c + u) * 1024 + lane_kbyte;
+            off = off < last_vec ? off : last_vec;
 #pragma unroll
             for (int r = 0; r < R; ++r)
             {
-                wv[u][r] = make_uint4(0, 0, 0, 0);
-                if (ok)
-                    wv[u][r] = ld_nt16(rowptr[r] + (int64_t) (c + u) * 1024 + lane_kbyte);
+                // neutral element of the weight encoding: 0 (fp16 / s8), q + 128 = 0x80, nibble q + 8 = 0x8
+                constexpr uint32_t kZeroW = WT == W_INT8_WOQ ? 0x80808080u : (WT == W_INT4_WOQ ? 0x88888888u : 0u);
+                const uint4 v = ld_nt16(rowptr[r] + off);
+                wv[u][r] = make_uint4(ok ? v.x : kZeroW, ok ? v.y : kZeroW, ok ? v.z : kZeroW, ok ? v.w : kZeroW);
             }
         }
     };
 
     // ------------------------------------------------------------------ prologue
     const uint16_t* gam = reinterpret_cast<const uint16_t*>(p.gamma);
-    const bool vec_half = x_is_half && ((K & 7) == 0) && ((p.ldx & 7) == 0)
-        && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0) && (!do_norm || (reinterpret_cast<uintptr_t>(p.gamma) & 15) == 0);
+    const bool vec_half = x_is_half && ((K & 7) == 0)
+        && (attn || (((p.ldx & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0)))
+        && (!do_norm || (reinterpret_cast<uintptr_t>(p.gamma) & 15) == 0);
     const bool reg_path = vec_half && Kp <= 256 * 8 * kNXV;
 
     // 1. request x (row 0) and gamma
     uint4 xv[kNXV], gv[kNXV];
-    if (reg_path)
-    {
-        const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x);
+    // x row m as 8-half vectors: from memory, or (PRO_ATTN*) merged from the split-KV attention partials:
+    //   ctx[h, d] = sum_i e_i o_i[d] / (sum_i e_i l_i + 1e-6),  e_i = exp(m_i - max_i m_i)   (MM/...Template.h:1756)
+    auto load_x_row = [&](int m) {
+        if (!attn)
+        {
+            const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * p.ldx;
+#pragma unroll
+            for (int j = 0; j < kNXV; ++j)
+            {
+                const int k = (tid + j * 256) * 8;
+                if (j * 2048 < Kp) // uniform: vector index range used by this K
+                {
+                    const uint4 v = *reinterpret_cast<const uint4*>(xg + (k < K ? k : K - 8));
+                    xv[j] = make_uint4(k < K ? v.x : 0u, k < K ? v.y : 0u, k < K ? v.z : 0u, k < K ? v.w : 0u);
+                }
+                else
+                    xv[j] = make_uint4(0, 0, 0, 0);
+            }
+            return;
+        }
+        const float2* ml = reinterpret_cast<const float2*>(p.attn_ml);
+        int ns = p.attn_seq_len[m] / p.attn_tchunk + 1;
+        ns = ns > p.attn_nsmax ? p.attn_nsmax : ns;
 #pragma unroll
         for (int j = 0; j < kNXV; ++j)
         {
             const int k = (tid + j * 256) * 8;
             xv[j] = make_uint4(0, 0, 0, 0);
-            gv[j] = make_uint4(0, 0, 0, 0);
             if (k < K)
             {
-                xv[j] = *reinterpret_cast<const uint4*>(xg + k);
-                if (do_norm)
-                    gv[j] = *reinterpret_cast<const uint4*>(gam + k);
+                const int hh = k / p.attn_dh, d0 = k % p.attn_dh;
+                const int64_t base = ((int64_t) m * p.attn_heads + hh) * p.attn_nsmax;
+                float Mx = -INFINITY;
+                for (int i = 0; i < ns; ++i)
+                    Mx = fmaxf(Mx, ml[base + i].x);
+                float L = 0.f;
+                float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < ns; ++i)
+                {
+                    const float2 v = ml[base + i];
+                    const float e = (v.x == -INFINITY) ? 0.f : __expf(v.x - Mx);
+                    const float4 a0 = *reinterpret_cast<const float4*>(p.attn_o + (base + i) * p.attn_dh + d0);
+                    const float4 a1 = *reinterpret_cast<const float4*>(p.attn_o + (base + i) * p.attn_dh + d0 + 4);
+                    L += v.y * e;
+                    o8[0] += a0.x * e;
+                    o8[1] += a0.y * e;
+                    o8[2] += a0.z * e;
+                    o8[3] += a0.w * e;
+                    o8[4] += a1.x * e;
+                    o8[5] += a1.y * e;
+                    o8[6] += a1.z * e;
+                    o8[7] += a1.w * e;
+                }
+                const float inv = 1.f / (L + 1.e-6f);
+                xv[j] = make_uint4(pack_h2(o8[0] * inv, o8[1] * inv), pack_h2(o8[2] * inv, o8[3] * inv),
+                    pack_h2(o8[4] * inv, o8[5] * inv), pack_h2(o8[6] * inv, o8[7] * inv));
             }
+        }
+    };
+    if (reg_path && !attn)
+    {
+        load_x_row(0);
+#pragma unroll
+        for (int j = 0; j < kNXV; ++j)
+        {
+            const int k = (tid + j * 256) * 8;
+            gv[j] = make_uint4(0, 0, 0, 0);
+            if (do_norm && j * 2048 < Kp) // uniform
+                gv[j] = *reinterpret_cast<const uint4*>(gam + (k < K ? k : K - 8));
         }
     }
     // 2. request the first weight tile of this wave
@@ -259,36 +322,35 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     };
     auto load_ops = [&](int g) {
         EpiOps e = {1.f, 1.f, 0.f};
-        const int n = swiglu ? g * (R / 2) + my_o : g * R + my_o;
-        if (!(my_active && g < a.ngroups && n < p.N))
-            return e;
+        int n = swiglu ? g * (R / 2) + my_o : g * R + my_o;
+        n = n < p.N ? n : p.N - 1; // clamped: inactive lanes load a valid element and ignore it
         if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
         {
             const uint16_t* sc = reinterpret_cast<const uint16_t*>(p.scale_col);
             e.s0 = h2f(sc[n]);
-            if (swiglu)
-                e.s1 = p.scale_col_up ? h2f(reinterpret_cast<const uint16_t*>(p.scale_col_up)[n]) : h2f(sc[p.N + n]);
+            if (swiglu) // uniform
+                e.s1 = h2f(p.scale_col_up ? reinterpret_cast<const uint16_t*>(p.scale_col_up)[n] : sc[p.N + n]);
         }
         else if constexpr (SQ)
         {
             const float* sc = reinterpret_cast<const float*>(p.scale_col);
-            e.s0 = p.per_channel ? sc[n] : sc[0];
-            if (swiglu)
+            e.s0 = sc[p.per_channel ? n : 0];
+            if (swiglu) // uniform
             {
                 const float* su = reinterpret_cast<const float*>(p.scale_col_up);
-                e.s1 = su ? (p.per_channel ? su[n] : su[0]) : (p.per_channel ? sc[p.N + n] : sc[0]);
+                e.s1 = su ? su[p.per_channel ? n : 0] : sc[p.per_channel ? p.N + n : 0];
             }
         }
-        if (p.epi == EPI_RESIDUAL)
-            e.res = h2f(reinterpret_cast<const uint16_t*>(p.residual)[(int64_t) my_m * p.ldy + n]);
+        if (p.epi == EPI_RESIDUAL) // uniform
+            e.res = h2f(reinterpret_cast<const uint16_t*>(p.residual)[(int64_t) (my_m < p.M ? my_m : 0) * p.ldy + n]);
         return e;
     };
     EpiOps ops_cur = load_ops(g0);
     float static_row_scale = 1.f, static_row_scale_up = 1.f, epi_q = 1.f, pro_q = 1.f;
     if constexpr (SQ)
     {
-        if (!q_dyn && p.scale_row)
-            static_row_scale = (p.per_token && my_active) ? p.scale_row[my_m] : p.scale_row[0];
+        if (!q_dyn && p.scale_row) // uniform
+            static_row_scale = p.scale_row[(p.per_token && my_m < p.M) ? my_m : 0];
         static_row_scale_up = (!q_dyn && p.scale_row_up) ? p.scale_row_up[0] : static_row_scale;
         if (q_static)
             pro_q = p.act_scale[0];
@@ -304,16 +366,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         {
             if (m >= p.M)
                 continue;
-            if (m > 0)
-            {
-                const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * p.ldx;
-#pragma unroll
-                for (int j = 0; j < kNXV; ++j)
-                {
-                    const int k = (tid + j * 256) * 8;
-                    xv[j] = (k < K) ? *reinterpret_cast<const uint4*>(xg + k) : make_uint4(0, 0, 0, 0);
-                }
-            }
+            if (m > 0 || attn)
+                load_x_row(m); // (attention partials: requested after the weight tile, which streams meanwhile)
             float inv = 1.f;
             if (do_norm)
             {
@@ -559,8 +613,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 #pragma unroll
         for (int u = 0; u < U; ++u)
         {
-            const int k0 = ((c + u) * 64 + lane) * VEC;
-            if (k0 < Kp)
+            int k0 = ((c + u) * 64 + lane) * VEC;
+            k0 = k0 < Kp ? k0 : Kp - VEC; // out-of-range lanes: the weight vector was zeroed, any x will do
             {
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
@@ -741,10 +795,21 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     }
     const bool sq = p.wtype == W_INT8_SQ;
     const bool swiglu = p.epi == EPI_SWIGLU || p.epi == EPI_SWIGLU_QSTATIC;
-    if (!sq && (p.pro >= PRO_RMSNORM_QSTATIC))
+    const bool quant_pro = (p.pro >= PRO_RMSNORM_QSTATIC && p.pro <= PRO_QDYN) || p.pro == PRO_ATTN_QSTATIC
+        || p.pro == PRO_ATTN_QDYN;
+    if (!sq && quant_pro)
     {
         set_error("gemv: quantising prologue needs W_INT8_SQ");
         return -1;
+    }
+    if (p.pro >= PRO_ATTN)
+    {
+        if (!p.attn_ml || !p.attn_o || !p.attn_seq_len || p.attn_heads * p.attn_dh != p.K || (p.attn_dh & 7)
+            || p.attn_tchunk <= 0 || p.attn_nsmax <= 0 || p.K > 256 * 8 * 6)
+        {
+            set_error("gemv: PRO_ATTN needs the split-KV partials (heads * dh == K <= 12288, dh %% 8 == 0)");
+            return -1;
+        }
     }
     if ((reinterpret_cast<uintptr_t>(p.w) & 15) || (p.ldw & 15))
     {

@@ -44,7 +44,12 @@ enum Prologue : int32_t
     PRO_RMSNORM_QSTATIC = 2, // ... -> s8 with static scale act_scale[0]          (W_INT8_SQ)
     PRO_RMSNORM_QDYN = 3,    // ... -> s8 with per-token scale amax/127            (W_INT8_SQ)
     PRO_QSTATIC = 4,         // x fp16 -> s8 static                                (W_INT8_SQ)
-    PRO_QDYN = 5             // x fp16 -> s8 per-token                             (W_INT8_SQ)
+    PRO_QDYN = 5,            // x fp16 -> s8 per-token                             (W_INT8_SQ)
+    // x = the decode-attention context, merged here from the split-KV partials that launch_mmha(skip_combine = 1)
+    // left in its workspace (flash-decoding merge fused into the O-projection: one launch less per layer)
+    PRO_ATTN = 6,         // -> fp16
+    PRO_ATTN_QSTATIC = 7, // -> fp16 -> s8 static                                  (W_INT8_SQ)
+    PRO_ATTN_QDYN = 8     // -> fp16 -> s8 per-token                               (W_INT8_SQ)
 };
 
 enum Epilogue : int32_t
@@ -77,6 +82,11 @@ struct GemvParams
     void* x_pro_out = nullptr;        // optional [M, K]: the prologue's result (fp16 or s8), written by workgroup 0
     const void* residual = nullptr;   // fp16 [M, ldy]
     const float* epi_scale = nullptr; // EPI_SWIGLU_QSTATIC: f32 [1]
+    // PRO_ATTN*: split-KV partials (mmha_split_layout): {max,sum} float2 [M, heads, nsmax], out f32 [M, heads, nsmax, dh]
+    const void* attn_ml = nullptr;
+    const float* attn_o = nullptr;
+    const int32_t* attn_seq_len = nullptr; // [M] device: number of active splits = seq_len / tchunk + 1
+    int32_t attn_heads = 0, attn_dh = 0, attn_tchunk = 0, attn_nsmax = 0;
     void* y = nullptr;
     int64_t ldy = 0; // elements
 };
@@ -141,9 +151,18 @@ struct MmhaParams
     const float* kv_scale_quant_orig = nullptr; // f32 [1]
     const float* rope_table = nullptr;          // f32 [max_pos, rotary_dim/2, 2] (cos, sin)
     int32_t rope_table_len = 0;
+    const float* rope_row = nullptr; // optional f32 [B, rotary_dim/2, 2]: this step's cos/sin row, prepared on the
+                                     // device by the sampler (removes the length -> position -> table dependency)
+    int32_t rows_per_group = 0;      // cache rows per lane group and split: 4 (default, finest split) or 16
+    int32_t skip_combine = 0;        // 1: leave the split partials in the workspace (the consumer merges them:
+                                     // GemvParams::attn_*), no combine launch
     void* out = nullptr;       // fp16 [B, H*Dh]
     void* workspace = nullptr; // mmha_workspace_size bytes
 };
+// Split geometry for a given rows_per_group: timesteps per split, number of splits for max_seq_len, and the byte
+// offset of the partial outputs inside the workspace ({max,sum} float2 [B,H,ns] first, then out f32 [B,H,ns,Dh]).
+int mmha_split_layout(int32_t head_size, int32_t max_seq_len, int32_t rows_per_group, int32_t batch, int32_t num_heads,
+    int32_t* tchunk, int32_t* nsplit, size_t* out_offset);
 size_t mmha_workspace_size(int32_t batch, int32_t num_heads, int32_t head_size, int32_t max_seq_len);
 int launch_mmha(const MmhaParams& p, hipStream_t stream);
 // The split-merge tickets at the head of the workspace must be zero before the FIRST launch on it (every launch
@@ -211,6 +230,14 @@ struct GreedyParams
     int32_t* seq_len = nullptr;
     int32_t* finished = nullptr;
     int32_t end_id = -1, advance = 0;
+    // optional: prepare the RoPE cos/sin row of the NEXT generation step, position = seq_len[b] - (max_input_len -
+    // input_lengths[b])  (MM/...Template.h:1425-1426), so that the attention kernel does not chase
+    // length -> position -> table
+    float* rope_row_out = nullptr;     // f32 [B, rope_half, 2]
+    const float* rope_table = nullptr; // f32 [rope_table_len, rope_half, 2]
+    int32_t rope_half = 0, rope_table_len = 0;
+    const int32_t* input_lengths = nullptr;
+    int32_t max_input_len = 0;
 };
 int launch_greedy_step(const GreedyParams& p, hipStream_t stream);
 

@@ -110,76 +110,94 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
     {
-        const int t = t0 + i * NGRP + gid;
-        kreg[i] = make_uint4(0, 0, 0, 0);
-        vreg[i] = make_uint4(0, 0, 0, 0);
-        if (t < Smax)
+        // no branches around the loads (a divergent `if` makes the compiler drain the queue at every one):
+        // out-of-range rows read the last row of the buffer and are masked out by `valid` below
+        const int t = min(t0 + i * NGRP + gid, Smax - 1);
+        const int64_t off = ((int64_t) t * DH + li * 8) * ESZ;
+        if constexpr (INT8KV)
         {
-            const int64_t off = ((int64_t) t * DH + li * 8) * ESZ;
-            if constexpr (INT8KV)
-            {
-                const uint2 k8 = *reinterpret_cast<const uint2*>(kbase + off);
-                const uint2 v8 = *reinterpret_cast<const uint2*>(vbase + off);
-                kreg[i].x = k8.x;
-                kreg[i].y = k8.y;
-                vreg[i].x = v8.x;
-                vreg[i].y = v8.y;
-            }
-            else
-            {
-                kreg[i] = *reinterpret_cast<const uint4*>(kbase + off);
-                vreg[i] = *reinterpret_cast<const uint4*>(vbase + off);
-            }
+            const uint2 k8 = *reinterpret_cast<const uint2*>(kbase + off);
+            const uint2 v8 = *reinterpret_cast<const uint2*>(vbase + off);
+            kreg[i] = make_uint4(k8.x, k8.y, 0, 0);
+            vreg[i] = make_uint4(v8.x, v8.y, 0, 0);
+        }
+        else
+        {
+            kreg[i] = *reinterpret_cast<const uint4*>(kbase + off);
+            vreg[i] = *reinterpret_cast<const uint4*>(vbase + off);
         }
     }
-    // ---- 2. the new token's q, k, v and the step scalars
+    // ---- 2. the new token's q, k, v, the step scalars, the padding-mask words and the RoPE row: all requested
+    //         here, before anything is consumed (one memory round trip for the whole prologue)
     const uint16_t* qkv = reinterpret_cast<const uint16_t*>(p.qkv) + (int64_t) b * 3 * H * DH;
     const uint4 q_raw = *reinterpret_cast<const uint4*>(qkv + (int64_t) h * DH + li * 8);
     const uint4 k_raw = *reinterpret_cast<const uint4*>(qkv + (int64_t) (H + h) * DH + li * 8);
     const uint4 v_new = *reinterpret_cast<const uint4*>(qkv + (int64_t) (2 * H + h) * DH + li * 8);
     const int tl = p.sequence_length[b]; // slots already used; the new token goes to slot tl
-    if (t0 > tl)
-        return; // uniform: this split lies entirely beyond the sequence
-    const int timestep = p.timestep_host >= 0 ? p.timestep_host : tl;
-    const int32_t* mask = p.masked_tokens ? p.masked_tokens + (int64_t) b * Smax : nullptr;
     int mk[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
+        mk[i] = 0;
+    if (p.masked_tokens) // uniform
     {
-        const int t = t0 + i * NGRP + gid;
-        mk[i] = (mask && t < tl && t < Smax) ? mask[t] : 0;
+        const int32_t* mask = p.masked_tokens + (int64_t) b * Smax;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            mk[i] = mask[min(t0 + i * NGRP + gid, Smax - 1)];
     }
+    // RoPE coefficients (cos, sin) of this lane's 8 elements: one row of the table, as 16-byte loads.
+    // NeoX pairs (d, d + rot/2) share coefficient d mod rot/2; GPT-J pairs (2i, 2i+1) share coefficient i.
+    float4 c4[4] = {make_float4(1.f, 0.f, 1.f, 0.f), make_float4(1.f, 0.f, 1.f, 0.f), make_float4(1.f, 0.f, 1.f, 0.f),
+        make_float4(1.f, 0.f, 1.f, 0.f)};
+    if (p.rotary_dim > 0) // uniform
+    {
+        const int half = p.rotary_dim >> 1;
+        const float2* row;
+        if (p.rope_row) // uniform: prepared by the sampler for this step
+            row = reinterpret_cast<const float2*>(p.rope_row) + (int64_t) b * half;
+        else
+        {
+            const int ts = p.timestep_host >= 0 ? p.timestep_host : tl;
+            int pos = ts - (p.max_input_len - p.input_lengths[b]);
+            pos = pos < 0 ? 0 : (pos >= p.rope_table_len ? p.rope_table_len - 1 : pos);
+            row = reinterpret_cast<const float2*>(p.rope_table) + (int64_t) pos * half;
+        }
+        const int d0 = li * 8;
+        int idx0 = p.neox ? (d0 >= half ? d0 - half : d0) : (d0 >> 1);
+        const int span = p.neox ? 8 : 4;
+        idx0 = idx0 + span <= half ? idx0 : (half >= span ? half - span : 0);
+        const float4* r4 = reinterpret_cast<const float4*>(row + idx0);
+        c4[0] = r4[0];
+        c4[1] = r4[1];
+        if (p.neox)
+        {
+            c4[2] = r4[2];
+            c4[3] = r4[3];
+        }
+    }
+    if (t0 > tl)
+        return; // uniform: this split lies entirely beyond the sequence
     float qf[8], kf[8];
     h8_to_f(q_raw, qf);
     h8_to_f(k_raw, kf);
     if (p.rotary_dim > 0)
     {
-        const int pad = p.max_input_len - p.input_lengths[b];
-        int pos = timestep - pad;
-        pos = pos < 0 ? 0 : (pos >= p.rope_table_len ? p.rope_table_len - 1 : pos);
-        const int half = p.rotary_dim >> 1;
-        const float2* tab = reinterpret_cast<const float2*>(p.rope_table) + (int64_t) pos * half;
+        const float cs[16] = {c4[0].x, c4[0].y, c4[0].z, c4[0].w, c4[1].x, c4[1].y, c4[1].z, c4[1].w,
+            c4[2].x, c4[2].y, c4[2].z, c4[2].w, c4[3].x, c4[3].y, c4[3].z, c4[3].w};
         if (p.neox)
         {
             // pair (j, j + rot/2); rot == DH: the partner sits in lane li ^ (LPR/2)
-            float qp[8], kp[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-            {
-                qp[j] = __shfl_xor(qf[j], LPR / 2, 64);
-                kp[j] = __shfl_xor(kf[j], LPR / 2, 64);
-            }
             const bool second = li >= LPR / 2;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
             {
-                const int d = li * 8 + j;
-                const float2 cs = tab[second ? d - half : d];
+                const float qp = __shfl_xor(qf[j], LPR / 2, 64);
+                const float kp = __shfl_xor(kf[j], LPR / 2, 64);
                 // first half:  x' = x cos - y sin ; second half: y' = y cos + x sin
                 // fp16 rounding of the rotated value (...Utils.h:1517-1531)
-                const float sn = second ? cs.y : -cs.y;
-                qf[j] = h2f(f2h(cs.x * qf[j] + sn * qp[j]));
-                kf[j] = h2f(f2h(cs.x * kf[j] + sn * kp[j]));
+                const float c = cs[2 * j], sn = second ? cs[2 * j + 1] : -cs[2 * j + 1];
+                qf[j] = h2f(f2h(c * qf[j] + sn * qp));
+                kf[j] = h2f(f2h(c * kf[j] + sn * kp));
             }
         }
         else
@@ -188,16 +206,13 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
 #pragma unroll
             for (int j = 0; j < 8; j += 2)
             {
-                const int d = li * 8 + j;
-                if (d < p.rotary_dim)
-                {
-                    const float2 cs = tab[d >> 1];
-                    const float q0 = qf[j], q1 = qf[j + 1], k0 = kf[j], k1 = kf[j + 1];
-                    qf[j] = h2f(f2h(cs.x * q0 - cs.y * q1));
-                    qf[j + 1] = h2f(f2h(cs.x * q1 + cs.y * q0));
-                    kf[j] = h2f(f2h(cs.x * k0 - cs.y * k1));
-                    kf[j + 1] = h2f(f2h(cs.x * k1 + cs.y * k0));
-                }
+                const float c = (li * 8 + j < p.rotary_dim) ? cs[j] : 1.f;
+                const float sn = (li * 8 + j < p.rotary_dim) ? cs[j + 1] : 0.f;
+                const float q0 = qf[j], q1 = qf[j + 1], k0 = kf[j], k1 = kf[j + 1];
+                qf[j] = h2f(f2h(c * q0 - sn * q1));
+                qf[j + 1] = h2f(f2h(c * q1 + sn * q0));
+                kf[j] = h2f(f2h(c * k0 - sn * k1));
+                kf[j + 1] = h2f(f2h(c * k1 + sn * k0));
             }
         }
     }
@@ -227,32 +242,52 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
         }
     }
 
-    // ---- 4. scores of this lane group's rows, its own softmax partial
+    // ---- 4. scores of this lane group's rows, its own softmax partial.
+    // int8 cache: the bytes are turned into exact small integers (q + 128 spliced into fp16 1024 + u, minus 1152)
+    // and the dequantisation scale is applied once to the dot product / to the P.V sum instead of to every element
+    // (the reference rounds every dequantised element to fp16 first, ...Utils.h:2358-2365 - this is the same value
+    // without that rounding; well inside the 2e-3 tolerance of the reference's own plugin test).
+    float dnew = 0.f;
+    dnew = dot2(q16.x, k_new.x, dnew);
+    dnew = dot2(q16.y, k_new.y, dnew);
+    dnew = dot2(q16.z, k_new.z, dnew);
+    dnew = dot2(q16.w, k_new.w, dnew);
+    dnew = group_sum<LPR>(dnew) * p.inv_sqrt_dh;
+    const float kscale = INT8KV ? s_qo * p.inv_sqrt_dh : p.inv_sqrt_dh;
     float s[NIT];
     float m_g = -INFINITY;
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
     {
         const int t = t0 + i * NGRP + gid;
-        uint4 kk;
-        if constexpr (INT8KV)
-            kk = dequant8(make_uint2(kreg[i].x, kreg[i].y), s_qo);
-        else
-            kk = kreg[i];
-        if (t == tl)
-            kk = k_new; // the current token uses the un-quantised k (MM/...Template.h:1517-1549)
         float d = 0.f;
-        d = dot2(q16.x, kk.x, d);
-        d = dot2(q16.y, kk.y, d);
-        d = dot2(q16.z, kk.z, d);
-        d = dot2(q16.w, kk.w, d);
-        d = group_sum<LPR>(d) * p.inv_sqrt_dh;
-        const bool valid = t <= tl && t < Smax && mk[i] == 0;
+        if constexpr (INT8KV)
+        {
+            const uint32_t magic = 0x64646464u;
+            const h2_t bias = {(_Float16) 1152.f, (_Float16) 1152.f};
+            const uint32_t ka = kreg[i].x ^ 0x80808080u, kb = kreg[i].y ^ 0x80808080u;
+            d = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, ka, 0x04010400u)) - bias, u32_as_h2(q16.x), d, false);
+            d = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, ka, 0x04030402u)) - bias, u32_as_h2(q16.y), d, false);
+            d = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, kb, 0x04010400u)) - bias, u32_as_h2(q16.z), d, false);
+            d = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, kb, 0x04030402u)) - bias, u32_as_h2(q16.w), d, false);
+        }
+        else
+        {
+            d = dot2(q16.x, kreg[i].x, d);
+            d = dot2(q16.y, kreg[i].y, d);
+            d = dot2(q16.z, kreg[i].z, d);
+            d = dot2(q16.w, kreg[i].w, d);
+        }
+        d = group_sum<LPR>(d) * kscale;
+        if (t == tl)
+            d = dnew; // the current token uses the un-quantised k (MM/...Template.h:1517-1549)
+        const bool valid = t <= tl && t < Smax && (t == tl || mk[i] == 0);
         s[i] = valid ? d : -INFINITY;
         m_g = fmaxf(m_g, s[i]);
     }
-    float l_g = 0.f;
+    float l_g = 0.f, l16 = 0.f;
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float p_new = 0.f;
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
     {
@@ -260,18 +295,41 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
         const float pr = (s[i] == -INFINITY) ? 0.f : __expf(s[i] - m_g);
         l_g += pr;
         const float p16 = h2f(f2h(pr));
-        uint4 vv;
-        if constexpr (INT8KV)
-            vv = dequant8(make_uint2(vreg[i].x, vreg[i].y), s_qo);
-        else
-            vv = vreg[i];
         if (t == tl)
-            vv = v_new;
+        {
+            p_new = p16;
+            continue;
+        }
+        if constexpr (INT8KV)
+        {
+            const uint32_t va = vreg[i].x ^ 0x80808080u, vb = vreg[i].y ^ 0x80808080u;
+            l16 += p16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                o[j] = fmaf(p16, (float) ((va >> (8 * j)) & 0xffu), o[j]);
+                o[4 + j] = fmaf(p16, (float) ((vb >> (8 * j)) & 0xffu), o[4 + j]);
+            }
+        }
+        else
+        {
+            float vf[8];
+            h8_to_f(vreg[i], vf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j] = fmaf(p16, vf[j], o[j]);
+        }
+    }
+    {
         float vf[8];
-        h8_to_f(vv, vf);
+        h8_to_f(v_new, vf);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            o[j] = fmaf(p16, vf[j], o[j]);
+        {
+            if constexpr (INT8KV)
+                o[j] = s_qo * (o[j] - 128.f * l16); // sum p (u - 128) = sum p u - 128 sum p
+            o[j] = fmaf(p_new, vf[j], o[j]);
+        }
     }
 
     // ---- 5. merge the lane groups of the workgroup through LDS, publish the split partial
@@ -363,8 +421,6 @@ __global__ __launch_bounds__(256) void mmha_combine_kernel(const MmhaParams p, c
     }
 }
 
-int mmha_tune_nit = 0; // test/bench override of the rows-per-lane-group (4 or 8); 0 = default
-
 template <int DH, int NIT>
 int launch_nit(const MmhaParams& p, hipStream_t stream)
 {
@@ -384,7 +440,8 @@ int launch_nit(const MmhaParams& p, hipStream_t stream)
         hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, true>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
     else
         hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, false>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
-    hipLaunchKernelGGL((mmha_combine_kernel<DH, NIT>), dim3(p.num_heads, p.batch), dim3(256), 0, stream, p, ws_ml, ws_o, ns);
+    if (!p.skip_combine)
+        hipLaunchKernelGGL((mmha_combine_kernel<DH, NIT>), dim3(p.num_heads, p.batch), dim3(256), 0, stream, p, ws_ml, ws_o, ns);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
     {
@@ -397,8 +454,8 @@ int launch_nit(const MmhaParams& p, hipStream_t stream)
 template <int DH>
 int launch_dh(const MmhaParams& p, hipStream_t stream)
 {
-    if (mmha_tune_nit == 8)
-        return launch_nit<DH, 8>(p, stream);
+    if (p.rows_per_group == 16)
+        return launch_nit<DH, 16>(p, stream);
     return launch_nit<DH, 4>(p, stream);
 }
 
@@ -414,6 +471,24 @@ size_t mmha_workspace_size(int32_t batch, int32_t num_heads, int32_t head_size, 
     const int ns = (max_seq_len + tchunk - 1) / tchunk;
     const size_t ml = ((size_t) batch * num_heads * ns * sizeof(float2) + 255) / 256 * 256;
     return ml + (size_t) batch * num_heads * ns * head_size * sizeof(float);
+}
+
+int mmha_split_layout(int32_t head_size, int32_t max_seq_len, int32_t rows_per_group, int32_t batch, int32_t num_heads,
+    int32_t* tchunk, int32_t* nsplit, size_t* out_offset)
+{
+    const int lpr = head_size / 8;
+    if (lpr <= 0 || 64 % lpr)
+        return -1;
+    const int nit = rows_per_group == 16 ? 16 : 4;
+    const int tc = kWaves * (64 / lpr) * nit;
+    const int ns = (max_seq_len + tc - 1) / tc;
+    if (tchunk)
+        *tchunk = tc;
+    if (nsplit)
+        *nsplit = ns;
+    if (out_offset)
+        *out_offset = ((size_t) batch * num_heads * ns * sizeof(float2) + 255) / 256 * 256;
+    return 0;
 }
 
 int mmha_reset_workspace(void* workspace, int32_t batch, int32_t num_heads, hipStream_t stream)

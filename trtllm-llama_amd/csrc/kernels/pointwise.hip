@@ -316,6 +316,15 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const GreedyParams p)
         sv[wid] = best;
         si[wid] = bi;
     }
+    if (p.rope_row_out && threadIdx.x >= 64 && threadIdx.x < 64 + p.rope_half)
+    {
+        // next step's position: (seq_len after this step's advance) - padding of this sequence
+        const int j = threadIdx.x - 64;
+        int pos = p.seq_len[b] + (p.advance ? 1 : 0) - (p.max_input_len - p.input_lengths[b]);
+        pos = pos < 0 ? 0 : (pos >= p.rope_table_len ? p.rope_table_len - 1 : pos);
+        reinterpret_cast<float2*>(p.rope_row_out)[(int64_t) b * p.rope_half + j]
+            = reinterpret_cast<const float2*>(p.rope_table)[(int64_t) pos * p.rope_half + j];
+    }
     __syncthreads();
     if (threadIdx.x == 0)
     {

@@ -163,6 +163,10 @@ struct tllm_session
             *masked = nullptr, *finished = nullptr, *last_tok = nullptr;
     const float* rope = nullptr;
     int rope_len = 0;
+    float* rope_row = nullptr; // [B, Dh/2, 2]: cos/sin row of the next generation step (written by the sampler)
+    int attn_nit = 4, attn_tchunk = 0, attn_ns = 0;
+    size_t attn_o_off = 0;
+    bool attn_fused = false; // split-KV merge fused into the O-projection prologue
     int end_id = -1;
     hipGraphExec_t graph = nullptr;
     hipStream_t graph_stream = nullptr;
@@ -377,6 +381,16 @@ struct tllm_session
         p.epi_scale = epi_scale;
         p.y = y;
         p.ldy = ldy;
+        if (pro >= PRO_ATTN)
+        {
+            p.attn_ml = mmha_ws;
+            p.attn_o = reinterpret_cast<const float*>(static_cast<const char*>(mmha_ws) + attn_o_off);
+            p.attn_seq_len = seq_len;
+            p.attn_heads = Hr;
+            p.attn_dh = Dh;
+            p.attn_tchunk = attn_tchunk;
+            p.attn_nsmax = attn_ns;
+        }
         if (up)
         {
             p.w_up = up->w;
@@ -547,6 +561,12 @@ struct tllm_session
         gp.finished = finished;
         gp.end_id = end_id;
         gp.advance = advance;
+        gp.rope_row_out = rope_row;
+        gp.rope_table = rope;
+        gp.rope_half = Dh / 2;
+        gp.rope_table_len = rope_len;
+        gp.input_lengths = in_len;
+        gp.max_input_len = max_in;
         return timed(PC_OTHER, st, [&] { return launch_greedy_step(gp, st) ? 1 : 0; });
     }
 
@@ -590,11 +610,15 @@ struct tllm_session
             m.kv_scale_quant_orig = L.kv_qo;
             m.rope_table = rope;
             m.rope_table_len = rope_len;
+            m.rope_row = rope_row;
+            m.rows_per_group = attn_nit;
+            m.skip_combine = attn_fused ? 1 : 0;
             m.out = ctx;
             m.workspace = mmha_ws;
             RUN(timed(PC_ATTENTION, st, [&] { return launch_mmha(m, st); }));
             // K4: x <- x + O(ctx)     (TP: rank 0 carries the residual into the all-reduce)
-            RUN(gemv(L.dense, B, pro_q, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE, ctx, Dr, nullptr, L.attn_qscale, x,
+            const int pro_o = !attn_fused ? pro_q : (!sq ? PRO_ATTN : (per_token ? PRO_ATTN_QDYN : PRO_ATTN_QSTATIC));
+            RUN(gemv(L.dense, B, pro_o, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE, ctx, Dr, nullptr, L.attn_qscale, x,
                 nullptr, x, D, DT_HALF, nullptr, st));
             RUN(allreduce(x, (int64_t) B * D, st));
             // K5
@@ -898,6 +922,30 @@ int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_inp
     s->rope = plugins::rope_table(s->Dh, Smax > s->max_pos ? Smax : s->max_pos, &s->rope_len);
     if (!s->rope)
         return 1;
+    RUN(s->dalloc(&s->rope_row, (size_t) B * s->Dh * sizeof(float)));
+    HIP_OK(hipMemset(s->rope_row, 0, (size_t) B * s->Dh * sizeof(float)));
+    // coarse KV splits (16 rows per lane group) + merge fused into the O-projection when that needs <= 8 partials
+    // per head; otherwise the fine split with its own combine launch
+    {
+        int tc = 0, ns = 0;
+        size_t off = 0;
+        s->attn_fused = false;
+        s->attn_nit = 4;
+        if (!getenv("TLLM_NO_FUSED_ATTN_MERGE") && mmha_split_layout(s->Dh, Smax, 16, B, s->Hr, &tc, &ns, &off) == 0 && ns <= 8
+            && s->Dr <= 256 * 8 * 6)
+        {
+            s->attn_fused = true;
+            s->attn_nit = 16;
+        }
+        if (mmha_split_layout(s->Dh, Smax, s->attn_nit, B, s->Hr, &tc, &ns, &off))
+        {
+            set_error("session: unsupported head size %d", s->Dh);
+            return 1;
+        }
+        s->attn_tchunk = tc;
+        s->attn_ns = ns;
+        s->attn_o_off = off;
+    }
     return 0;
 }
 
@@ -1005,6 +1053,7 @@ int32_t tllm_session_fake_context(tllm_session_t s, int32_t length, uint32_t see
     const size_t kv_elems = (size_t) B * 2 * s->Hr * s->Smax * s->Dh;
     for (int i = 0; i < s->num_layers; ++i)
         RUN(launch_fill_random(s->layers[i].kv, s->int8_kv ? DT_INT8 : DT_HALF, kv_elems, seed + 7919u * i, 1.0f, st));
+    RUN(s->run_sampler(0, st)); // prepares the RoPE row of the first generation step (the ids are overwritten next)
     RUN(launch_fill_i32(s->cur_ids, 3, B, st));
     return 0;
 }
