@@ -2,11 +2,16 @@
 //
 //   y[m,n] = epi( scale(n,m) * sum_k pro(x)[m,k] * W[n,k] )
 //
-// One wave owns R weight rows and streams them with 16-byte non-temporal loads (1 KiB per wave
-// instruction, U k-chunks in flight per row); pro(x) is built once per workgroup in LDS (RMSNorm and/or
-// int8 quantisation fused in, so the normalised / quantised activation never goes to HBM); the dot
-// products use v_dot2_f32_f16 (fp16 x fp16 -> fp32) or v_dot4_i32_i8 (SmoothQuant, exact int32);
-// reduction over the 64 lanes by cross-lane shuffles; residual-add / SwiGLU / quantising epilogues fused.
+// One wave owns 2 weight rows per step and streams them with 16-byte non-temporal loads (1 KiB per wave
+// instruction, 4 k-chunks per row = an 8 KiB tile, double-buffered); pro(x) is built once per workgroup in
+// registers and published to LDS (RMSNorm and/or int8 quantisation and/or the split-KV attention merge fused in,
+// so the normalised / quantised activation never goes to HBM); the dot products use v_dot2_f32_f16
+// (fp16 x fp16 -> fp32) or v_dot4_i32_i8 (SmoothQuant, exact int32); reduction over the 64 lanes on the DPP
+// network; residual-add / SwiGLU / quantising epilogues fused.  Persistent grid (<= what the chip holds at once).
+//
+// The kernel is specialised at compile time on (weight type, prologue family, epilogue family, row-count bucket):
+// one generic kernel with run-time switches was 14k instructions and its cold instruction fetch showed up as a
+// ~2 us floor on every launch.
 //
 // Reference semantics: A7 P/gemmPlugin/gemmPlugin.cpp:121-190; A8 K/weightOnlyMatrixVectorMultiplication.cu:136-277
 // (y = sum_k x[k] * (q[k,n] * s[n])); A10 cutlass_extensions/.../epilogue_per_row_per_col_scale.h:279-347
@@ -24,19 +29,35 @@ namespace kernels
 {
 using namespace dev;
 
-int gemv_tune_r = 0;             // test/bench override: rows per wave (0 = heuristic)
+int gemv_tune_r = 0;             // (kept for the C ABI; the kernel is fixed at 2 rows x 4 chunks per tile)
 int gemv_tune_blocks_per_cu = 0; // test/bench override: persistent workgroups per CU (0 = occupancy query)
 
 namespace
 {
+
+constexpr int R = 2, U = 4;
+constexpr int kRedBytes = 256;
+constexpr int kNXV = 6; // 16-byte x vectors a thread keeps in registers: K <= 256 * 8 * 6 = 12288 halfs
+
+enum ProKind
+{
+    PK_COPY = 0,  // x already in the operand type
+    PK_NORM = 1,  // RMSNorm (+ quant for SQ)
+    PK_QUANT = 2, // fp16 -> s8 (SQ)
+    PK_ATTN = 3   // split-KV merge (+ quant for SQ)
+};
+enum EpiKind
+{
+    EK_PLAIN = 0, // none | residual
+    EK_SWIGLU = 1 // swiglu (+ static quant)
+};
 
 struct GemvArgs
 {
     GemvParams p;
     int32_t Kp;      // K rounded up to the weight vector width
     int32_t nchunks; // ceil(Kp / (64 * VEC))
-    int32_t ngroups; // row groups (one per wave-iteration)
-    int32_t xh_bytes; // bytes of the fp16 staging region per row m (0 if absent)
+    int32_t ngroups; // row groups (one per wave-step)
 };
 
 template <int WT>
@@ -46,29 +67,31 @@ struct WTraits<W_FP16>
 {
     static constexpr int VEC = 8;
     static constexpr bool IS_SQ = false;
+    static constexpr uint32_t ZERO = 0u;
 };
 template <>
 struct WTraits<W_INT8_WOQ>
 {
     static constexpr int VEC = 16;
     static constexpr bool IS_SQ = false;
+    static constexpr uint32_t ZERO = 0x80808080u; // q + 128
 };
 template <>
 struct WTraits<W_INT4_WOQ>
 {
     static constexpr int VEC = 32;
     static constexpr bool IS_SQ = false;
+    static constexpr uint32_t ZERO = 0x88888888u; // q + 8
 };
 template <>
 struct WTraits<W_INT8_SQ>
 {
     static constexpr int VEC = 16;
     static constexpr bool IS_SQ = true;
+    static constexpr uint32_t ZERO = 0u;
 };
 
 // ---- per-16-byte dot products -----------------------------------------------------------------
-
-// fp16 weights: 8 halfs vs 8 halfs of x
 __device__ __forceinline__ float dot_fp16(const uint4& w, const uint4& x, float acc)
 {
     acc = dot2(w.x, x.x, acc);
@@ -82,11 +105,9 @@ __device__ __forceinline__ float dot_fp16(const uint4& w, const uint4& x, float 
 __device__ __forceinline__ float dot_u8x4(uint32_t w, uint32_t x01, uint32_t x23, float acc)
 {
     const uint32_t magic = 0x64646464u;
-    uint32_t lo = __builtin_amdgcn_perm(magic, w, 0x04010400u); // {1024+b0, 1024+b1}
-    uint32_t hi = __builtin_amdgcn_perm(magic, w, 0x04030402u); // {1024+b2, 1024+b3}
-    const h2_t bias = {(_Float16) 1152.f, (_Float16) 1152.f};   // 1024 + 128
-    h2_t l = u32_as_h2(lo) - bias;
-    h2_t h = u32_as_h2(hi) - bias;
+    const h2_t bias = {(_Float16) 1152.f, (_Float16) 1152.f}; // 1024 + 128
+    const h2_t l = u32_as_h2(__builtin_amdgcn_perm(magic, w, 0x04010400u)) - bias;
+    const h2_t h = u32_as_h2(__builtin_amdgcn_perm(magic, w, 0x04030402u)) - bias;
     acc = __builtin_amdgcn_fdot2(l, u32_as_h2(x01), acc, false);
     acc = __builtin_amdgcn_fdot2(h, u32_as_h2(x23), acc, false);
     return acc;
@@ -106,17 +127,13 @@ __device__ __forceinline__ float dot_u4x8(uint32_t w, const uint4& x, float acc)
 {
     const uint32_t m = 0x64006400u;
     const uint32_t w8 = w >> 8;
-    h2_t e01 = u32_as_h2((w & 0x000f000fu) | m);
-    h2_t e23 = u32_as_h2((w & 0x00f000f0u) | m);
-    h2_t e45 = u32_as_h2((w8 & 0x000f000fu) | m);
-    h2_t e67 = u32_as_h2((w8 & 0x00f000f0u) | m);
     const h2_t b0 = {(_Float16) 1032.f, (_Float16) 1032.f}; // 1024 + 8
     const h2_t s1 = {(_Float16) 0.0625f, (_Float16) 0.0625f};
     const h2_t b1 = {(_Float16) -72.f, (_Float16) -72.f}; // (1024 + 16 n) / 16 - 72 = n - 8
-    e01 = e01 - b0;
-    e45 = e45 - b0;
-    e23 = e23 * s1 + b1;
-    e67 = e67 * s1 + b1;
+    const h2_t e01 = u32_as_h2((w & 0x000f000fu) | m) - b0;
+    const h2_t e23 = u32_as_h2((w & 0x00f000f0u) | m) * s1 + b1;
+    const h2_t e45 = u32_as_h2((w8 & 0x000f000fu) | m) - b0;
+    const h2_t e67 = u32_as_h2((w8 & 0x00f000f0u) | m) * s1 + b1;
     acc = __builtin_amdgcn_fdot2(e01, u32_as_h2(x.x), acc, false);
     acc = __builtin_amdgcn_fdot2(e23, u32_as_h2(x.y), acc, false);
     acc = __builtin_amdgcn_fdot2(e45, u32_as_h2(x.z), acc, false);
@@ -144,67 +161,57 @@ __device__ __forceinline__ float silu_mul_fp16(float g, float u)
 }
 
 // ---- the kernel --------------------------------------------------------------------------------
-// LDS map: [0,256) reduction scratch | xh: MB rows of Kp fp16 (absent for raw-s8 input) | xq: MB rows of Kp s8 (SQ)
+// LDS map: [0,256) reduction scratch | MB rows of Kp activations (fp16, or s8 for SmoothQuant)
 //
 // Latency structure (the per-launch floor matters: a 7B layer is 4 launches of 17-90 MB, i.e. 3-15 us each at HBM
-// speed): 1. the x (and gamma) vectors are requested first, 2. the first weight tile of every wave is requested
-// right behind them (it does not depend on x) and streams in while 3. the workgroup builds pro(x) in registers
-// (sum of squares -> one barrier -> normalise / quantise) and publishes it to LDS (one barrier); 4. dot products,
-// 5. cross-lane reduction + epilogue.  Further tiles (large N) are loaded in the loop; co-resident workgroups
-// (up to 8 per CU) overlap each other's phases.
-constexpr int kRedBytes = 256;
-constexpr int kNXV = 6; // x vectors (8 halfs) a thread keeps in registers: K <= 256 * 8 * 6 = 12288
-
-template <int WT, int R, int U, int MB>
+// speed).  Everything that does not depend on x is requested at t = 0, in one memory round trip: x / gamma, the first
+// weight tile of every wave, the epilogue operands (scales, residual) of its first row group, the launch-constant
+// scales.  No branches around loads (a lane-dependent `if` makes the compiler fence each load with s_waitcnt + exec
+// masking): out-of-range lanes load a clamped, valid address and the value is replaced by a select.  Then: pro(x) in
+// registers (sum of squares -> ONE barrier -> normalise / quantise) -> LDS -> ONE barrier -> dots -> DPP reduction ->
+// epilogue.  Further tiles are double-buffered, with the next group's epilogue operands requested ahead of the next
+// tile so that waiting for them never drains the weight stream.
+template <int WT, int PK, int EK, int MB>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 {
     using TR = WTraits<WT>;
     constexpr int VEC = TR::VEC;
     constexpr bool SQ = TR::IS_SQ;
+    constexpr bool SWIGLU = EK == EK_SWIGLU;
+    constexpr bool X_HALF = !(SQ && PK == PK_COPY); // the input activations are fp16 (else raw s8)
     using acc_t = typename std::conditional<SQ, int, float>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const GemvParams& p = a.p;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int K = p.K, Kp = a.Kp;
     float* red = reinterpret_cast<float*>(smem);
-    uint16_t* xh = reinterpret_cast<uint16_t*>(smem + kRedBytes);
-    int8_t* xq = reinterpret_cast<int8_t*>(smem + kRedBytes + (size_t) a.xh_bytes * MB);
-    const bool x_is_half = !(SQ && p.pro == PRO_NONE);
-    const bool do_norm = p.pro == PRO_RMSNORM || p.pro == PRO_RMSNORM_QSTATIC || p.pro == PRO_RMSNORM_QDYN;
-    const bool q_static = p.pro == PRO_RMSNORM_QSTATIC || p.pro == PRO_QSTATIC || p.pro == PRO_ATTN_QSTATIC;
-    const bool q_dyn = p.pro == PRO_RMSNORM_QDYN || p.pro == PRO_QDYN || p.pro == PRO_ATTN_QDYN;
-    const bool attn = p.pro >= PRO_ATTN;
-    float row_scale[MB]; // per-token dequant scale when the prologue quantises dynamically
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-        row_scale[m] = 1.f;
+    char* xs = smem + kRedBytes; // [MB][Kp] halfs, or [MB][Kp] s8 for SQ
+    constexpr int XES = SQ ? 1 : 2;
+    const bool q_dyn = SQ && (p.pro == PRO_RMSNORM_QDYN || p.pro == PRO_QDYN || p.pro == PRO_ATTN_QDYN);
+    const bool q_static = SQ && (p.pro == PRO_RMSNORM_QSTATIC || p.pro == PRO_QSTATIC || p.pro == PRO_ATTN_QSTATIC);
 
     // ------------------------------------------------------------------ weight-tile helpers
-    const bool swiglu = p.epi == EPI_SWIGLU || p.epi == EPI_SWIGLU_QSTATIC;
     const char* wbase = reinterpret_cast<const char*>(p.w);
     const char* wup = p.w_up ? reinterpret_cast<const char*>(p.w_up) : wbase + (int64_t) p.N * p.ldw;
-    const int lane_kbyte = lane * 16; // byte offset of this lane's vector inside a chunk row
-
+    const int lane_kbyte = lane * 16;
+    const int64_t last_vec = p.ldw - 16;
     auto rows_of_group = [&](int g, const char* (&rowptr)[R]) {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
+        if constexpr (SWIGLU)
         {
-            if (swiglu)
-            {
-                const int o = g * (R / 2) + (r % (R / 2 > 0 ? R / 2 : 1));
-                rowptr[r] = ((r < R / 2) ? wbase : wup) + (o < p.N ? (int64_t) o * p.ldw : 0);
-            }
-            else
+            const int o = g < p.N ? g : p.N - 1; // one output per group: gate row o, up row o
+            rowptr[0] = wbase + (int64_t) o * p.ldw;
+            rowptr[1] = wup + (int64_t) o * p.ldw;
+        }
+        else
+        {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
             {
                 const int row = g * R + r;
-                rowptr[r] = wbase + (row < p.N ? (int64_t) row * p.ldw : 0);
+                rowptr[r] = wbase + (int64_t) (row < p.N ? row : p.N - 1) * p.ldw;
             }
         }
     };
-    // No branches around loads anywhere in this kernel: a lane-dependent `if` makes the compiler fence every load
-    // with s_waitcnt + exec masking, which serialises the memory round trips.  Out-of-range lanes load a clamped,
-    // valid address and the value is replaced by a select.
-    const int64_t last_vec = p.ldw - 16; // byte offset of the last 16-byte vector of a weight row
     auto load_tile = [&](const char* const (&rowptr)[R], int c, uint4 (&wv)[U][R]) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -215,137 +222,149 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 #pragma unroll
             for (int r = 0; r < R; ++r)
             {
-                // neutral element of the weight encoding: 0 (fp16 / s8), q + 128 = 0x80, nibble q + 8 = 0x8
-                constexpr uint32_t kZeroW = WT == W_INT8_WOQ ? 0x80808080u : (WT == W_INT4_WOQ ? 0x88888888u : 0u);
                 const uint4 v = ld_nt16(rowptr[r] + off);
-                wv[u][r] = make_uint4(ok ? v.x : kZeroW, ok ? v.y : kZeroW, ok ? v.z : kZeroW, ok ? v.w : kZeroW);
+                wv[u][r] = make_uint4(ok ? v.x : TR::ZERO, ok ? v.y : TR::ZERO, ok ? v.z : TR::ZERO, ok ? v.w : TR::ZERO);
             }
         }
     };
 
-    // ------------------------------------------------------------------ prologue
-    const uint16_t* gam = reinterpret_cast<const uint16_t*>(p.gamma);
-    const bool vec_half = x_is_half && ((K & 7) == 0)
-        && (attn || (((p.ldx & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0)))
-        && (!do_norm || (reinterpret_cast<uintptr_t>(p.gamma) & 15) == 0);
-    const bool reg_path = vec_half && Kp <= 256 * 8 * kNXV;
-
-    // 1. request x (row 0) and gamma
+    // ------------------------------------------------------------------ t = 0: every x-independent request
     uint4 xv[kNXV], gv[kNXV];
-    // x row m as 8-half vectors: from memory, or (PRO_ATTN*) merged from the split-KV attention partials:
-    //   ctx[h, d] = sum_i e_i o_i[d] / (sum_i e_i l_i + 1e-6),  e_i = exp(m_i - max_i m_i)   (MM/...Template.h:1756)
     auto load_x_row = [&](int m) {
-        if (!attn)
+        if constexpr (PK == PK_ATTN)
+        {
+            // ctx[h, d] = sum_i e_i o_i[d] / (sum_i e_i l_i + 1e-6),  e_i = exp(m_i - max_i m_i)  (MM/...Template.h:1756)
+            const float2* ml = reinterpret_cast<const float2*>(p.attn_ml);
+            int ns = p.attn_seq_len[m] / p.attn_tchunk + 1;
+            ns = ns > p.attn_nsmax ? p.attn_nsmax : ns;
+#pragma unroll
+            for (int j = 0; j < kNXV; ++j)
+            {
+                xv[j] = make_uint4(0, 0, 0, 0);
+                if (j * 2048 < Kp) // uniform
+                {
+                    const int k = (tid + j * 256) * 8;
+                    const int kc = k < K ? k : K - 8;
+                    const int hh = kc / p.attn_dh, d0 = kc % p.attn_dh;
+                    const int64_t base = ((int64_t) m * p.attn_heads + hh) * p.attn_nsmax;
+                    float Mx = -INFINITY;
+                    for (int i = 0; i < ns; ++i)
+                        Mx = fmaxf(Mx, ml[base + i].x);
+                    float L = 0.f;
+                    float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i < ns; ++i)
+                    {
+                        const float2 v = ml[base + i];
+                        const float e = (v.x == -INFINITY) ? 0.f : __expf(v.x - Mx);
+                        const float4 a0 = *reinterpret_cast<const float4*>(p.attn_o + (base + i) * p.attn_dh + d0);
+                        const float4 a1 = *reinterpret_cast<const float4*>(p.attn_o + (base + i) * p.attn_dh + d0 + 4);
+                        L += v.y * e;
+                        o8[0] += a0.x * e;
+                        o8[1] += a0.y * e;
+                        o8[2] += a0.z * e;
+                        o8[3] += a0.w * e;
+                        o8[4] += a1.x * e;
+                        o8[5] += a1.y * e;
+                        o8[6] += a1.z * e;
+                        o8[7] += a1.w * e;
+                    }
+                    const float inv = (k < K) ? 1.f / (L + 1.e-6f) : 0.f;
+                    xv[j] = make_uint4(pack_h2(o8[0] * inv, o8[1] * inv), pack_h2(o8[2] * inv, o8[3] * inv),
+                        pack_h2(o8[4] * inv, o8[5] * inv), pack_h2(o8[6] * inv, o8[7] * inv));
+                }
+            }
+        }
+        else if constexpr (X_HALF)
         {
             const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * p.ldx;
 #pragma unroll
             for (int j = 0; j < kNXV; ++j)
             {
-                const int k = (tid + j * 256) * 8;
-                if (j * 2048 < Kp) // uniform: vector index range used by this K
+                xv[j] = make_uint4(0, 0, 0, 0);
+                if (j * 2048 < Kp) // uniform
                 {
+                    const int k = (tid + j * 256) * 8;
                     const uint4 v = *reinterpret_cast<const uint4*>(xg + (k < K ? k : K - 8));
                     xv[j] = make_uint4(k < K ? v.x : 0u, k < K ? v.y : 0u, k < K ? v.z : 0u, k < K ? v.w : 0u);
                 }
-                else
-                    xv[j] = make_uint4(0, 0, 0, 0);
             }
-            return;
         }
-        const float2* ml = reinterpret_cast<const float2*>(p.attn_ml);
-        int ns = p.attn_seq_len[m] / p.attn_tchunk + 1;
-        ns = ns > p.attn_nsmax ? p.attn_nsmax : ns;
-#pragma unroll
-        for (int j = 0; j < kNXV; ++j)
+        else
         {
-            const int k = (tid + j * 256) * 8;
-            xv[j] = make_uint4(0, 0, 0, 0);
-            if (k < K)
+            // raw s8 activations: 16 values per vector
+            const int8_t* xg = reinterpret_cast<const int8_t*>(p.x) + (int64_t) m * p.ldx;
+#pragma unroll
+            for (int j = 0; j < kNXV; ++j)
             {
-                const int hh = k / p.attn_dh, d0 = k % p.attn_dh;
-                const int64_t base = ((int64_t) m * p.attn_heads + hh) * p.attn_nsmax;
-                float Mx = -INFINITY;
-                for (int i = 0; i < ns; ++i)
-                    Mx = fmaxf(Mx, ml[base + i].x);
-                float L = 0.f;
-                float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int i = 0; i < ns; ++i)
+                xv[j] = make_uint4(0, 0, 0, 0);
+                if (j * 4096 < Kp) // uniform
                 {
-                    const float2 v = ml[base + i];
-                    const float e = (v.x == -INFINITY) ? 0.f : __expf(v.x - Mx);
-                    const float4 a0 = *reinterpret_cast<const float4*>(p.attn_o + (base + i) * p.attn_dh + d0);
-                    const float4 a1 = *reinterpret_cast<const float4*>(p.attn_o + (base + i) * p.attn_dh + d0 + 4);
-                    L += v.y * e;
-                    o8[0] += a0.x * e;
-                    o8[1] += a0.y * e;
-                    o8[2] += a0.z * e;
-                    o8[3] += a0.w * e;
-                    o8[4] += a1.x * e;
-                    o8[5] += a1.y * e;
-                    o8[6] += a1.z * e;
-                    o8[7] += a1.w * e;
+                    const int k = (tid + j * 256) * 16;
+                    const uint4 v = *reinterpret_cast<const uint4*>(xg + (k < K ? k : K - 16));
+                    xv[j] = make_uint4(k < K ? v.x : 0u, k < K ? v.y : 0u, k < K ? v.z : 0u, k < K ? v.w : 0u);
                 }
-                const float inv = 1.f / (L + 1.e-6f);
-                xv[j] = make_uint4(pack_h2(o8[0] * inv, o8[1] * inv), pack_h2(o8[2] * inv, o8[3] * inv),
-                    pack_h2(o8[4] * inv, o8[5] * inv), pack_h2(o8[6] * inv, o8[7] * inv));
             }
         }
     };
-    if (reg_path && !attn)
-    {
+    if constexpr (PK != PK_ATTN)
         load_x_row(0);
+    if constexpr (PK == PK_NORM)
+    {
+        const uint16_t* gam = reinterpret_cast<const uint16_t*>(p.gamma);
 #pragma unroll
         for (int j = 0; j < kNXV; ++j)
         {
-            const int k = (tid + j * 256) * 8;
             gv[j] = make_uint4(0, 0, 0, 0);
-            if (do_norm && j * 2048 < Kp) // uniform
+            if (j * 2048 < Kp) // uniform
+            {
+                const int k = (tid + j * 256) * 8;
                 gv[j] = *reinterpret_cast<const uint4*>(gam + (k < K ? k : K - 8));
+            }
         }
     }
-    // 2. request the first weight tile of this wave
     const int g0 = blockIdx.x * 4 + wid;
+    const int gstride = gridDim.x * 4;
     const char* rowptr[R];
     uint4 wv[U][R];
     rows_of_group(g0 < a.ngroups ? g0 : 0, rowptr);
     load_tile(rowptr, 0, wv);
-    // 2b. ... and everything else that does not depend on x: the epilogue operands (scales, residual) of this
-    //     wave's first row group and the launch-constant scales.  (Requested after the tile so that waiting for x
-    //     does not wait for them; consumed after the dot products.)
-    const int gstride = gridDim.x * 4;
-    const int nouts = swiglu ? R / 2 : R;
+
+    constexpr int NOUTS = SWIGLU ? 1 : R;         // outputs per row group
     const int my_o = lane / MB, my_m = lane % MB; // the (output, row) this lane finishes
-    const bool my_active = my_o < nouts && my_m < p.M;
+    const bool my_active = my_o < NOUTS && my_m < p.M;
     struct EpiOps
     {
         float s0, s1, res;
     };
     auto load_ops = [&](int g) {
         EpiOps e = {1.f, 1.f, 0.f};
-        int n = swiglu ? g * (R / 2) + my_o : g * R + my_o;
+        int n = g * NOUTS + (my_o < NOUTS ? my_o : 0);
         n = n < p.N ? n : p.N - 1; // clamped: inactive lanes load a valid element and ignore it
         if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
         {
             const uint16_t* sc = reinterpret_cast<const uint16_t*>(p.scale_col);
             e.s0 = h2f(sc[n]);
-            if (swiglu) // uniform
+            if constexpr (SWIGLU)
                 e.s1 = h2f(p.scale_col_up ? reinterpret_cast<const uint16_t*>(p.scale_col_up)[n] : sc[p.N + n]);
         }
         else if constexpr (SQ)
         {
             const float* sc = reinterpret_cast<const float*>(p.scale_col);
             e.s0 = sc[p.per_channel ? n : 0];
-            if (swiglu) // uniform
+            if constexpr (SWIGLU)
             {
                 const float* su = reinterpret_cast<const float*>(p.scale_col_up);
                 e.s1 = su ? su[p.per_channel ? n : 0] : sc[p.per_channel ? p.N + n : 0];
             }
         }
-        if (p.epi == EPI_RESIDUAL) // uniform
-            e.res = h2f(reinterpret_cast<const uint16_t*>(p.residual)[(int64_t) (my_m < p.M ? my_m : 0) * p.ldy + n]);
+        if constexpr (!SWIGLU)
+        {
+            if (p.epi == EPI_RESIDUAL) // uniform
+                e.res = h2f(reinterpret_cast<const uint16_t*>(p.residual)[(int64_t) (my_m < p.M ? my_m : 0) * p.ldy + n]);
+        }
         return e;
     };
-    EpiOps ops_cur = load_ops(g0);
+    EpiOps ops_cur = load_ops(g0 < a.ngroups ? g0 : 0);
     float static_row_scale = 1.f, static_row_scale_up = 1.f, epi_q = 1.f, pro_q = 1.f;
     if constexpr (SQ)
     {
@@ -355,69 +374,87 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         if (q_static)
             pro_q = p.act_scale[0];
     }
-    if (p.epi == EPI_SWIGLU_QSTATIC)
-        epi_q = p.epi_scale[0];
-
-    // 3. build pro(x) in LDS
-    if (reg_path)
+    if constexpr (SWIGLU)
     {
+        if (p.epi == EPI_SWIGLU_QSTATIC)
+            epi_q = p.epi_scale[0];
+    }
+
+    // ------------------------------------------------------------------ pro(x) -> LDS
+    float row_scale[MB];
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+    for (int m = 0; m < MB; ++m)
+        row_scale[m] = 1.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+    {
+        if (m >= p.M) // uniform
+            continue;
+        if (m > 0 || PK == PK_ATTN)
+            load_x_row(m);
+        if constexpr (!X_HALF)
         {
-            if (m >= p.M)
-                continue;
-            if (m > 0 || attn)
-                load_x_row(m); // (attention partials: requested after the weight tile, which streams meanwhile)
-            float inv = 1.f;
-            if (do_norm)
+#pragma unroll
+            for (int j = 0; j < kNXV; ++j)
             {
-                float ss = 0.f;
-#pragma unroll
-                for (int j = 0; j < kNXV; ++j)
-                {
-                    const uint32_t ws[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                    {
-                        const h2_t h = u32_as_h2(ws[q]);
-                        const float f0 = (float) h.x, f1 = (float) h.y;
-                        ss += f0 * f0 + f1 * f1;
-                    }
-                }
-                ss = wave_sum(ss);
-                if (lane == 0)
-                    red[m * 4 + wid] = ss;
-                __syncthreads();
-                ss = red[m * 4] + red[m * 4 + 1] + red[m * 4 + 2] + red[m * 4 + 3];
-                inv = 1.0f / sqrtf(ss / (float) K + p.eps);
+                const int k = (tid + j * 256) * 16;
+                if (k < Kp)
+                    *reinterpret_cast<uint4*>(xs + (size_t) m * Kp + k) = xv[j];
             }
-            float amax = 0.f;
-            if (do_norm || q_dyn)
+            continue;
+        }
+        float inv = 1.f;
+        if constexpr (PK == PK_NORM)
+        {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < kNXV; ++j)
             {
+                const uint32_t ws[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
 #pragma unroll
-                for (int j = 0; j < kNXV; ++j)
+                for (int q = 0; q < 4; ++q)
                 {
-                    uint32_t xs4[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-                    const uint32_t gs4[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                    {
-                        h2_t h = u32_as_h2(xs4[q]);
-                        if (do_norm)
-                        {
-                            const h2_t gg = u32_as_h2(gs4[q]);
-                            const float n0 = h2f(f2h((float) h.x * inv)), n1 = h2f(f2h((float) h.y * inv));
-                            h.x = (_Float16) (n0 * (float) gg.x);
-                            h.y = (_Float16) (n1 * (float) gg.y);
-                            xs4[q] = h2_as_u32(h);
-                        }
-                        amax = fmaxf(amax, fmaxf(fabsf((float) h.x), fabsf((float) h.y)));
-                    }
-                    xv[j] = make_uint4(xs4[0], xs4[1], xs4[2], xs4[3]);
+                    const h2_t h = u32_as_h2(ws[q]);
+                    const float f0 = (float) h.x, f1 = (float) h.y;
+                    ss += f0 * f0 + f1 * f1;
                 }
             }
-            float qs = 1.f;
-            if (SQ && q_dyn)
+            ss = wave_sum(ss);
+            if (lane == 0)
+                red[m * 4 + wid] = ss;
+            __syncthreads();
+            ss = red[m * 4] + red[m * 4 + 1] + red[m * 4 + 2] + red[m * 4 + 3];
+            inv = 1.0f / sqrtf(ss / (float) K + p.eps);
+        }
+        float amax = 0.f;
+        if (PK == PK_NORM || q_dyn)
+        {
+#pragma unroll
+            for (int j = 0; j < kNXV; ++j)
+            {
+                uint32_t xs4[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+                const uint32_t gs4[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                {
+                    h2_t h = u32_as_h2(xs4[q]);
+                    if constexpr (PK == PK_NORM)
+                    {
+                        const h2_t gg = u32_as_h2(gs4[q]);
+                        const float n0 = h2f(f2h((float) h.x * inv)), n1 = h2f(f2h((float) h.y * inv));
+                        h.x = (_Float16) (n0 * (float) gg.x);
+                        h.y = (_Float16) (n1 * (float) gg.y);
+                        xs4[q] = h2_as_u32(h);
+                    }
+                    amax = fmaxf(amax, fmaxf(fabsf((float) h.x), fabsf((float) h.y)));
+                }
+                xv[j] = make_uint4(xs4[0], xs4[1], xs4[2], xs4[3]);
+            }
+        }
+        float qs = pro_q;
+        if constexpr (SQ)
+        {
+            if (q_dyn) // uniform
             {
                 amax = wave_max(amax);
                 if (lane == 0)
@@ -430,133 +467,41 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
                 if (blockIdx.x == 0 && tid == 0 && p.dyn_scale_out)
                     p.dyn_scale_out[m] = amax / 127.f;
             }
-            else if (SQ && q_static)
-                qs = pro_q;
-#pragma unroll
-            for (int j = 0; j < kNXV; ++j)
-            {
-                const int k = (tid + j * 256) * 8;
-                if (k < Kp)
-                {
-                    if (SQ)
-                    {
-                        const uint32_t ws[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-                        uint32_t o[2] = {0, 0};
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                        {
-                            const h2_t h = u32_as_h2(ws[q]);
-                            const uint32_t b0 = (uint8_t) f2i8_rni_sat((float) h.x * qs);
-                            const uint32_t b1 = (uint8_t) f2i8_rni_sat((float) h.y * qs);
-                            o[q >> 1] |= (b0 | (b1 << 8)) << (16 * (q & 1));
-                        }
-                        *reinterpret_cast<uint2*>(xq + (size_t) m * Kp + k) = make_uint2(o[0], o[1]);
-                    }
-                    else
-                        *reinterpret_cast<uint4*>(xh + (size_t) m * Kp + k) = xv[j];
-                }
-            }
         }
-    }
-    else
-    {
-        // generic path (unaligned / very long x): through LDS, scalar passes
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int j = 0; j < kNXV; ++j)
         {
-            if (m >= p.M)
-                continue;
-            if (x_is_half)
+            const int k = (tid + j * 256) * 8;
+            if (k < Kp)
             {
-                const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * p.ldx;
-                uint16_t* xs = xh + (size_t) m * Kp;
-                float ss = 0.f;
-                for (int k = tid; k < Kp; k += 256)
+                if constexpr (SQ)
                 {
-                    const uint16_t b = k < K ? xg[k] : (uint16_t) 0;
-                    xs[k] = b;
-                    const float f = h2f(b);
-                    ss += f * f;
-                }
-                float amax = 0.f;
-                if (do_norm)
-                {
-                    ss = block_sum(ss, red);
-                    const float inv = 1.0f / sqrtf(ss / (float) K + p.eps);
-                    for (int k = tid; k < K; k += 256)
+                    const uint32_t ws[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+                    uint32_t o[2] = {0, 0};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
                     {
-                        const float n16 = h2f(f2h(h2f(xs[k]) * inv));
-                        const uint16_t yb = f2h(n16 * h2f(gam[k]));
-                        xs[k] = yb;
-                        amax = fmaxf(amax, fabsf(h2f(yb)));
+                        const h2_t h = u32_as_h2(ws[q]);
+                        const uint32_t b0 = (uint8_t) f2i8_rni_sat((float) h.x * qs);
+                        const uint32_t b1 = (uint8_t) f2i8_rni_sat((float) h.y * qs);
+                        o[q >> 1] |= (b0 | (b1 << 8)) << (16 * (q & 1));
                     }
-                }
-                else if (q_dyn)
-                    for (int k = tid; k < K; k += 256)
-                        amax = fmaxf(amax, fabsf(h2f(xs[k])));
-                if (SQ && (q_static || q_dyn))
-                {
-                    float qs;
-                    if (q_dyn)
-                    {
-                        amax = block_max(amax, red);
-                        amax = fmaxf(amax, h2f(f2h(1e-6f)));
-                        qs = 127.f / amax;
-                        row_scale[m] = amax / 127.f;
-                        if (blockIdx.x == 0 && tid == 0 && p.dyn_scale_out)
-                            p.dyn_scale_out[m] = amax / 127.f;
-                    }
-                    else
-                        qs = p.act_scale[0];
-                    int8_t* qd = xq + (size_t) m * Kp;
-                    for (int k = tid; k < Kp; k += 256)
-                        qd[k] = k < K ? f2i8_rni_sat(h2f(xs[k]) * qs) : (int8_t) 0;
-                }
-                __syncthreads();
-            }
-            else
-            {
-                // raw s8 activations (SmoothQuantGemm plugin input 0)
-                const int8_t* xg = reinterpret_cast<const int8_t*>(p.x) + (int64_t) m * p.ldx;
-                int8_t* qd = xq + (size_t) m * Kp;
-                const bool vec_ok = ((K & 15) == 0) && ((p.ldx & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
-                if (vec_ok)
-                {
-                    for (int k = tid * 16; k < Kp; k += 256 * 16)
-                        *reinterpret_cast<uint4*>(qd + k) = *reinterpret_cast<const uint4*>(xg + k);
+                    *reinterpret_cast<uint2*>(xs + (size_t) m * Kp + k) = make_uint2(o[0], o[1]);
                 }
                 else
-                {
-                    for (int k = tid; k < Kp; k += 256)
-                        qd[k] = k < K ? xg[k] : (int8_t) 0;
-                }
+                    *reinterpret_cast<uint4*>(xs + ((size_t) m * Kp + k) * 2) = xv[j];
             }
         }
     }
     __syncthreads();
-    if (blockIdx.x == 0 && p.x_pro_out && p.pro != PRO_NONE)
+    if (blockIdx.x == 0 && p.x_pro_out && PK != PK_COPY)
     {
         for (int m = 0; m < MB && m < p.M; ++m)
-        {
-            if (SQ)
-            {
-                int8_t* o = reinterpret_cast<int8_t*>(p.x_pro_out) + (int64_t) m * K;
-                for (int k = tid; k < K; k += 256)
-                    o[k] = xq[(size_t) m * Kp + k];
-            }
-            else
-            {
-                uint16_t* o = reinterpret_cast<uint16_t*>(p.x_pro_out) + (int64_t) m * K;
-                for (int k = tid; k < K; k += 256)
-                    o[k] = xh[(size_t) m * Kp + k];
-            }
-        }
+            for (int k = tid; k < K * XES; k += 256)
+                reinterpret_cast<char*>(p.x_pro_out)[(int64_t) m * K * XES + k] = xs[(size_t) m * Kp * XES + k];
     }
 
-    // ------------------------------------------------------------------ main loop
-    // Persistent waves: wave w of workgroup b owns row groups g0, g0 + stride, ...; its tiles (U chunks x R rows,
-    // 16-byte loads) are double-buffered: while tile t is being reduced, tile t+1 is in flight, and the epilogue
-    // operands (scales, residual) of t are requested BEFORE t+1 so that waiting for them never drains the stream.
+    // ------------------------------------------------------------------ main loop: persistent waves, double buffer
     const int tiles_per_group = (a.nchunks + U - 1) / U;
     const int ngroups_mine = g0 < a.ngroups ? (a.ngroups - g0 + gstride - 1) / gstride : 0;
     const int ntiles = ngroups_mine * tiles_per_group;
@@ -588,14 +533,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     auto step = [&](uint4 (&cur)[U][R], uint4 (&nxt)[U][R]) {
         const bool last = ci_p == tiles_per_group - 1;
         const int g = g0 + gi_p * gstride;
-        const int n = swiglu ? g * (R / 2) + my_o : g * R + my_o;
+        const int n = g * NOUTS + (my_o < NOUTS ? my_o : 0);
         const bool fin = last && my_active && n < p.N;
-        // (1) epilogue operands: this group's were requested one group ahead (ops_cur); request the next group's
         const int64_t oidx = (int64_t) my_m * p.ldy + n;
+        // (1) the next group's epilogue operands, (2) the next tile
         EpiOps ops_nxt = ops_cur;
         if (last)
-            ops_nxt = load_ops(g + gstride);
-        // (2) next tile into the other buffer
+            ops_nxt = load_ops(g + gstride < a.ngroups ? g + gstride : g);
         if (t_issue < ntiles)
         {
             if (ci_i == 0)
@@ -614,48 +558,47 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         for (int u = 0; u < U; ++u)
         {
             int k0 = ((c + u) * 64 + lane) * VEC;
-            k0 = k0 < Kp ? k0 : Kp - VEC; // out-of-range lanes: the weight vector was zeroed, any x will do
+            k0 = k0 < Kp ? k0 : Kp - VEC; // out-of-range lanes: the weight vector is the neutral element
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
             {
-#pragma unroll
-                for (int m = 0; m < MB; ++m)
+                const char* xr = xs + ((size_t) m * Kp + k0) * XES;
+                if constexpr (WT == W_FP16)
                 {
-                    if constexpr (WT == W_FP16)
-                    {
-                        const uint4 xa = *reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0);
+                    const uint4 xa = *reinterpret_cast<const uint4*>(xr);
 #pragma unroll
-                        for (int r = 0; r < R; ++r)
-                            acc[r][m] = dot_fp16(cur[u][r], xa, acc[r][m]);
-                    }
-                    else if constexpr (WT == W_INT8_WOQ)
-                    {
-                        const uint4 xa = *reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0);
-                        const uint4 xb = *reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0 + 8);
+                    for (int r = 0; r < R; ++r)
+                        acc[r][m] = dot_fp16(cur[u][r], xa, acc[r][m]);
+                }
+                else if constexpr (WT == W_INT8_WOQ)
+                {
+                    const uint4 xa = *reinterpret_cast<const uint4*>(xr);
+                    const uint4 xb = *reinterpret_cast<const uint4*>(xr + 16);
 #pragma unroll
-                        for (int r = 0; r < R; ++r)
-                            acc[r][m] = dot_woq8(cur[u][r], xa, xb, acc[r][m]);
-                    }
-                    else if constexpr (WT == W_INT4_WOQ)
-                    {
-                        const uint4* xp = reinterpret_cast<const uint4*>(xh + (size_t) m * Kp + k0);
-                        const uint4 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+                    for (int r = 0; r < R; ++r)
+                        acc[r][m] = dot_woq8(cur[u][r], xa, xb, acc[r][m]);
+                }
+                else if constexpr (WT == W_INT4_WOQ)
+                {
+                    const uint4* xp = reinterpret_cast<const uint4*>(xr);
+                    const uint4 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
 #pragma unroll
-                        for (int r = 0; r < R; ++r)
-                        {
-                            float tt = acc[r][m];
-                            tt = dot_u4x8(cur[u][r].x, x0, tt);
-                            tt = dot_u4x8(cur[u][r].y, x1, tt);
-                            tt = dot_u4x8(cur[u][r].z, x2, tt);
-                            tt = dot_u4x8(cur[u][r].w, x3, tt);
-                            acc[r][m] = tt;
-                        }
-                    }
-                    else
+                    for (int r = 0; r < R; ++r)
                     {
-                        const uint4 xa = *reinterpret_cast<const uint4*>(xq + (size_t) m * Kp + k0);
-#pragma unroll
-                        for (int r = 0; r < R; ++r)
-                            acc[r][m] = dot_sq(cur[u][r], xa, acc[r][m]);
+                        float tt = acc[r][m];
+                        tt = dot_u4x8(cur[u][r].x, x0, tt);
+                        tt = dot_u4x8(cur[u][r].y, x1, tt);
+                        tt = dot_u4x8(cur[u][r].z, x2, tt);
+                        tt = dot_u4x8(cur[u][r].w, x3, tt);
+                        acc[r][m] = tt;
                     }
+                }
+                else
+                {
+                    const uint4 xa = *reinterpret_cast<const uint4*>(xr);
+#pragma unroll
+                    for (int r = 0; r < R; ++r)
+                        acc[r][m] = dot_sq(cur[u][r], xa, acc[r][m]);
                 }
             }
         }
@@ -676,38 +619,37 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
             {
                 const acc_t tot = wave_sum(acc[r][m]);
                 acc[r][m] = 0;
-                if (r < nouts && lane == r * MB + m)
+                if (r < NOUTS && lane == r * MB + m)
                 {
                     ai = (int) tot;
                     v0 = (float) tot;
                 }
-                if (swiglu && r >= R / 2 && lane == (r - R / 2) * MB + m)
+                if (SWIGLU && r == 1 && lane == m)
                     v1 = (float) tot;
             }
         const EpiOps e = ops_cur;
         ops_cur = ops_nxt;
         if (!fin)
             return;
-        const float s0 = e.s0 * my_row_scale, s1 = e.s1 * my_row_scale_up, resv = e.res;
-        const float r0 = v0 * s0;
-        if (p.epi == EPI_NONE)
+        const float r0 = v0 * (e.s0 * my_row_scale);
+        if constexpr (SWIGLU)
         {
-            if (p.out_dtype == DT_HALF)
+            const float o16 = silu_mul_fp16(r0, v1 * (e.s1 * my_row_scale_up));
+            if (p.epi == EPI_SWIGLU)
+                reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(o16);
+            else
+                reinterpret_cast<int8_t*>(p.y)[oidx] = f2i8_rni_sat(o16 * epi_q);
+        }
+        else
+        {
+            if (p.epi == EPI_RESIDUAL)
+                reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(h2f(f2h(r0)) + e.res);
+            else if (p.out_dtype == DT_HALF)
                 reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(r0);
             else if (p.out_dtype == DT_FLOAT)
                 reinterpret_cast<float*>(p.y)[oidx] = r0;
             else
                 reinterpret_cast<int32_t*>(p.y)[oidx] = SQ ? ai : (int32_t) r0;
-        }
-        else if (p.epi == EPI_RESIDUAL)
-            reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(h2f(f2h(r0)) + resv);
-        else
-        {
-            const float o16 = silu_mul_fp16(r0, v1 * s1);
-            if (p.epi == EPI_SWIGLU)
-                reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(o16);
-            else
-                reinterpret_cast<int8_t*>(p.y)[oidx] = f2i8_rni_sat(o16 * epi_q);
         }
     };
 
@@ -721,20 +663,23 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     }
 }
 
-template <int WT, int R, int U, int MB>
-int launch_inst(const GemvArgs& a, int blocks, size_t smem, hipStream_t stream)
+template <int WT, int PK, int EK, int MB>
+int launch_inst(const GemvArgs& a, hipStream_t stream)
 {
-    auto kfn = gemv_kernel<WT, R, U, MB>;
-    if (smem > 64 * 1024)
+    auto kfn = gemv_kernel<WT, PK, EK, MB>;
+    const size_t smem = kRedBytes + (size_t) MB * a.Kp * (WT == W_INT8_SQ ? 1 : 2);
+    if (smem > 160 * 1024)
     {
-        static bool attr_done = false;
-        if (!attr_done)
-        {
-            (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
-        }
+        set_error("gemv: K=%d x M=%d does not fit LDS", a.p.K, a.p.M);
+        return -1;
     }
-    // persistent grid: no more workgroups than the chip holds at once
+    static bool attr_done = false;
+    if (smem > 64 * 1024 && !attr_done)
+    {
+        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    // persistent grid: no more workgroups than the chip holds at once, every wave the same number of row groups
     static int cus = 0;
     static std::map<size_t, int> occ_cache;
     if (!cus)
@@ -752,10 +697,10 @@ int launch_inst(const GemvArgs& a, int blocks, size_t smem, hipStream_t stream)
             nb = 2;
         it = occ_cache.emplace(smem, nb > 8 ? 8 : nb).first;
     }
+    int blocks = (a.ngroups + 3) / 4;
     const int max_blocks = cus * (gemv_tune_blocks_per_cu > 0 ? gemv_tune_blocks_per_cu : it->second);
     if (blocks > max_blocks)
     {
-        // every wave gets the same number of row groups (a ragged last round costs a whole extra tile time)
         const int waves = max_blocks * 4;
         const int groups_per_wave = (a.ngroups + waves - 1) / waves;
         blocks = (a.ngroups + 4 * groups_per_wave - 1) / (4 * groups_per_wave);
@@ -770,21 +715,49 @@ int launch_inst(const GemvArgs& a, int blocks, size_t smem, hipStream_t stream)
     return 0;
 }
 
-template <int WT, int R, int U>
-int launch_mb(const GemvArgs& a, int blocks, size_t smem_per_m, hipStream_t stream)
+template <int WT, int PK, int EK>
+int launch_mb(const GemvArgs& a, hipStream_t stream)
 {
-    const int M = a.p.M;
-    if (M <= 1)
-        return launch_inst<WT, R, U, 1>(a, blocks, kRedBytes + smem_per_m, stream);
-    if (M <= 2)
-        return launch_inst<WT, R, U, 2>(a, blocks, kRedBytes + 2 * smem_per_m, stream);
-    if (M <= 4)
-        return launch_inst<WT, R, U, 4>(a, blocks, kRedBytes + 4 * smem_per_m, stream);
-    return launch_inst<WT, R, U, 8>(a, blocks, kRedBytes + 8 * smem_per_m, stream);
+    if (a.p.M <= 1)
+        return launch_inst<WT, PK, EK, 1>(a, stream);
+    if (a.p.M <= 2)
+        return launch_inst<WT, PK, EK, 2>(a, stream);
+    if (a.p.M <= 4)
+        return launch_inst<WT, PK, EK, 4>(a, stream);
+    return launch_inst<WT, PK, EK, 8>(a, stream);
+}
+
+template <int WT>
+int launch_wt(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream)
+{
+    constexpr bool SQ = WT == W_INT8_SQ;
+    if (swiglu)
+    {
+        switch (pk)
+        {
+        case PK_COPY: return launch_mb<WT, PK_COPY, EK_SWIGLU>(a, stream);
+        case PK_NORM: return launch_mb<WT, PK_NORM, EK_SWIGLU>(a, stream);
+        default: break;
+        }
+        set_error("gemv: SwiGLU epilogue is built with the copy / RMSNorm prologues only");
+        return -1;
+    }
+    switch (pk)
+    {
+    case PK_COPY: return launch_mb<WT, PK_COPY, EK_PLAIN>(a, stream);
+    case PK_NORM: return launch_mb<WT, PK_NORM, EK_PLAIN>(a, stream);
+    case PK_QUANT:
+        if constexpr (SQ)
+            return launch_mb<WT, PK_QUANT, EK_PLAIN>(a, stream);
+        break;
+    case PK_ATTN: return launch_mb<WT, PK_ATTN, EK_PLAIN>(a, stream);
+    default: break;
+    }
+    set_error("gemv: unsupported prologue for this weight type");
+    return -1;
 }
 
 } // namespace
-
 
 int launch_gemv(const GemvParams& p, hipStream_t stream)
 {
@@ -802,14 +775,31 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
         set_error("gemv: quantising prologue needs W_INT8_SQ");
         return -1;
     }
-    if (p.pro >= PRO_ATTN)
+    int pk;
+    switch (p.pro)
     {
-        if (!p.attn_ml || !p.attn_o || !p.attn_seq_len || p.attn_heads * p.attn_dh != p.K || (p.attn_dh & 7)
-            || p.attn_tchunk <= 0 || p.attn_nsmax <= 0 || p.K > 256 * 8 * 6)
-        {
-            set_error("gemv: PRO_ATTN needs the split-KV partials (heads * dh == K <= 12288, dh %% 8 == 0)");
-            return -1;
-        }
+    case PRO_NONE: pk = PK_COPY; break;
+    case PRO_RMSNORM:
+    case PRO_RMSNORM_QSTATIC:
+    case PRO_RMSNORM_QDYN: pk = PK_NORM; break;
+    case PRO_QSTATIC:
+    case PRO_QDYN: pk = PK_QUANT; break;
+    case PRO_ATTN:
+    case PRO_ATTN_QSTATIC:
+    case PRO_ATTN_QDYN: pk = PK_ATTN; break;
+    default: set_error("gemv: bad prologue %d", p.pro); return -1;
+    }
+    if (sq && (p.pro == PRO_RMSNORM || p.pro == PRO_ATTN))
+    {
+        set_error("gemv: W_INT8_SQ needs a quantising prologue (or s8 activations with PRO_NONE)");
+        return -1;
+    }
+    if (pk == PK_ATTN
+        && (!p.attn_ml || !p.attn_o || !p.attn_seq_len || p.attn_heads * p.attn_dh != p.K || (p.attn_dh & 7)
+            || p.attn_tchunk <= 0 || p.attn_nsmax <= 0))
+    {
+        set_error("gemv: PRO_ATTN needs the split-KV partials (heads * dh == K, dh %% 8 == 0)");
+        return -1;
     }
     if ((reinterpret_cast<uintptr_t>(p.w) & 15) || (p.ldw & 15))
     {
@@ -825,9 +815,22 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     case W_INT4_WOQ: vec = 32; break;
     default: set_error("gemv: bad wtype %d", p.wtype); return -1;
     }
-    if (p.wtype == W_FP16 && (p.K % 8))
+    // activations: 16-byte vectors kept in registers by 256 threads
+    const bool raw_s8 = sq && p.pro == PRO_NONE;
+    const int xvec = raw_s8 ? 16 : 8;
+    if ((p.K % xvec) || p.K > 256 * xvec * kNXV)
     {
-        set_error("gemv: fp16 weights need K %% 8 == 0 (K=%d)", p.K);
+        set_error("gemv: K=%d must be a multiple of %d and <= %d", p.K, xvec, 256 * xvec * kNXV);
+        return -1;
+    }
+    if (pk != PK_ATTN && ((reinterpret_cast<uintptr_t>(p.x) & 15) || ((p.ldx * (raw_s8 ? 1 : 2)) & 15)))
+    {
+        set_error("gemv: activation pointer / row stride must be 16-byte aligned");
+        return -1;
+    }
+    if (pk == PK_NORM && (reinterpret_cast<uintptr_t>(p.gamma) & 15))
+    {
+        set_error("gemv: RMSNorm weight must be 16-byte aligned");
         return -1;
     }
     GemvArgs a;
@@ -839,50 +842,14 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
         return -1;
     }
     a.nchunks = (a.Kp + 64 * vec - 1) / (64 * vec);
-    const bool x_is_half = !(sq && p.pro == PRO_NONE);
-    a.xh_bytes = x_is_half ? a.Kp * 2 : 0;
-    const size_t smem_per_m = (size_t) a.xh_bytes + (sq ? (size_t) a.Kp : 0);
-    const int mb = p.M <= 1 ? 1 : (p.M <= 2 ? 2 : (p.M <= 4 ? 4 : 8));
-    if (kRedBytes + mb * smem_per_m > 160 * 1024)
-    {
-        set_error("gemv: K=%d x M=%d does not fit LDS", p.K, p.M);
-        return -1;
-    }
-
-    // rows per wave: enough 1-KiB loads in flight per wave (R*U >= 8) without starving the grid
-    int R = 2;
-    if (gemv_tune_r)
-        R = gemv_tune_r;
-    else if (swiglu)
-        R = 2;
-    else if (a.nchunks <= 2)
-        R = 4;
-    if (swiglu && (R & 1))
-        R = 2;
-    const int outs_per_group = swiglu ? R / 2 : R;
-    a.ngroups = (p.N + outs_per_group - 1) / outs_per_group;
-    int blocks = (a.ngroups + 3) / 4;
-    const int max_blocks = 256 * 16;
-    if (blocks > max_blocks)
-        blocks = max_blocks;
-
-#define TLLM_GEMV_DISPATCH(WT)                                                                                         \
-    if (R == 4)                                                                                                        \
-        return launch_mb<WT, 4, 2>(a, blocks, smem_per_m, stream);                                                     \
-    else if (R == 1)                                                                                                   \
-        return launch_mb<WT, 1, 8>(a, blocks, smem_per_m, stream);                                                     \
-    else                                                                                                               \
-        return launch_mb<WT, 2, 4>(a, blocks, smem_per_m, stream);
-
+    a.ngroups = swiglu ? p.N : (p.N + R - 1) / R;
     switch (p.wtype)
     {
-    case W_FP16: TLLM_GEMV_DISPATCH(W_FP16)
-    case W_INT8_WOQ: TLLM_GEMV_DISPATCH(W_INT8_WOQ)
-    case W_INT4_WOQ: TLLM_GEMV_DISPATCH(W_INT4_WOQ)
-    case W_INT8_SQ: TLLM_GEMV_DISPATCH(W_INT8_SQ)
+    case W_FP16: return launch_wt<W_FP16>(a, pk, swiglu, stream);
+    case W_INT8_WOQ: return launch_wt<W_INT8_WOQ>(a, pk, swiglu, stream);
+    case W_INT4_WOQ: return launch_wt<W_INT4_WOQ>(a, pk, swiglu, stream);
+    default: return launch_wt<W_INT8_SQ>(a, pk, swiglu, stream);
     }
-#undef TLLM_GEMV_DISPATCH
-    return -1;
 }
 
 } // namespace kernels
