@@ -234,9 +234,12 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         if constexpr (PK == PK_ATTN)
         {
             // ctx[h, d] = sum_i e_i o_i[d] / (sum_i e_i l_i + 1e-6),  e_i = exp(m_i - max_i m_i)  (MM/...Template.h:1756)
+            // All partial slots (<= 8) are requested unconditionally and together - addresses do not depend on the
+            // sequence length; slots beyond the active count get weight 0 by a select.
+            constexpr int NSM = 8;
             const float2* ml = reinterpret_cast<const float2*>(p.attn_ml);
-            int ns = p.attn_seq_len[m] / p.attn_tchunk + 1;
-            ns = ns > p.attn_nsmax ? p.attn_nsmax : ns;
+            const int seq = p.attn_seq_len[m];
+            const int nsm = p.attn_nsmax < NSM ? p.attn_nsmax : NSM;
 #pragma unroll
             for (int j = 0; j < kNXV; ++j)
             {
@@ -247,26 +250,37 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
                     const int kc = k < K ? k : K - 8;
                     const int hh = kc / p.attn_dh, d0 = kc % p.attn_dh;
                     const int64_t base = ((int64_t) m * p.attn_heads + hh) * p.attn_nsmax;
+                    float2 mls[NSM];
+                    float4 oa[NSM], ob[NSM];
+#pragma unroll
+                    for (int i = 0; i < NSM; ++i)
+                    {
+                        const int ic = i < nsm ? i : 0; // uniform clamp
+                        mls[i] = ml[base + ic];
+                        oa[i] = *reinterpret_cast<const float4*>(p.attn_o + (base + ic) * p.attn_dh + d0);
+                        ob[i] = *reinterpret_cast<const float4*>(p.attn_o + (base + ic) * p.attn_dh + d0 + 4);
+                    }
+                    const int ns = seq / p.attn_tchunk + 1; // active splits
                     float Mx = -INFINITY;
-                    for (int i = 0; i < ns; ++i)
-                        Mx = fmaxf(Mx, ml[base + i].x);
+#pragma unroll
+                    for (int i = 0; i < NSM; ++i)
+                        Mx = (i < ns && i < nsm) ? fmaxf(Mx, mls[i].x) : Mx;
                     float L = 0.f;
                     float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    for (int i = 0; i < ns; ++i)
+#pragma unroll
+                    for (int i = 0; i < NSM; ++i)
                     {
-                        const float2 v = ml[base + i];
-                        const float e = (v.x == -INFINITY) ? 0.f : __expf(v.x - Mx);
-                        const float4 a0 = *reinterpret_cast<const float4*>(p.attn_o + (base + i) * p.attn_dh + d0);
-                        const float4 a1 = *reinterpret_cast<const float4*>(p.attn_o + (base + i) * p.attn_dh + d0 + 4);
-                        L += v.y * e;
-                        o8[0] += a0.x * e;
-                        o8[1] += a0.y * e;
-                        o8[2] += a0.z * e;
-                        o8[3] += a0.w * e;
-                        o8[4] += a1.x * e;
-                        o8[5] += a1.y * e;
-                        o8[6] += a1.z * e;
-                        o8[7] += a1.w * e;
+                        const bool act = i < ns && i < nsm && mls[i].x != -INFINITY;
+                        const float e = act ? __expf(mls[i].x - Mx) : 0.f;
+                        L += act ? mls[i].y * e : 0.f;
+                        o8[0] += act ? oa[i].x * e : 0.f;
+                        o8[1] += act ? oa[i].y * e : 0.f;
+                        o8[2] += act ? oa[i].z * e : 0.f;
+                        o8[3] += act ? oa[i].w * e : 0.f;
+                        o8[4] += act ? ob[i].x * e : 0.f;
+                        o8[5] += act ? ob[i].y * e : 0.f;
+                        o8[6] += act ? ob[i].z * e : 0.f;
+                        o8[7] += act ? ob[i].w * e : 0.f;
                     }
                     const float inv = (k < K) ? 1.f / (L + 1.e-6f) : 0.f;
                     xv[j] = make_uint4(pack_h2(o8[0] * inv, o8[1] * inv), pack_h2(o8[2] * inv, o8[3] * inv),
@@ -306,8 +320,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
             }
         }
     };
-    if constexpr (PK != PK_ATTN)
-        load_x_row(0);
+    load_x_row(0);
     if constexpr (PK == PK_NORM)
     {
         const uint16_t* gam = reinterpret_cast<const uint16_t*>(p.gamma);
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     {
         if (m >= p.M) // uniform
             continue;
-        if (m > 0 || PK == PK_ATTN)
+        if (m > 0)
             load_x_row(m);
         if constexpr (!X_HALF)
         {
