@@ -41,7 +41,9 @@ def parse():
     ap.add_argument('--layers', type=int, default=32, help='debug only: fewer layers (the result line says so)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
-    ap.add_argument('--cpu-tokens', type=int, default=3)
+    ap.add_argument('--cpu-tokens', type=int, default=0, help='CPU-baseline decode steps (0 = sized to ~20 s)')
+    ap.add_argument('--cpu-threads', type=int, default=0)
+    ap.add_argument('--cpu-sweep', default='', help='debug: comma list of thread counts to try (stderr)')
     return ap.parse_args()
 
 
@@ -150,13 +152,34 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     kv_row = sess.step_bytes(1) - sess_b0
     head_bytes = ((cfg['vocab_size'] + world - 1) // world) * cfg['hidden_size'] * 2
     res['gemv_layer_bytes_per_step'] = sess_b0 - kv_row - head_bytes
+    # live timing of each per-layer kernel (one HIP event pair around 4 x 32 back-to-back launches, every launch on
+    # its own layer's weights = cold HBM as in a real step); the roofline is quoted on the dominant one (gate|up)
+    res['kernel_us'] = {k: sess.time_kernel(k, 4, stream=stream)[0] for k in NativeSession.LAYER_KERNELS}
+    D, Ir = cfg['hidden_size'], cfg['inter_size'] // world
+    wbytes = {'sq': 1.0, 'woq8': 1.0, 'woq4': 0.5, 'fp16': 2.0}[mode]
+    sbytes = {'sq': 4, 'woq8': 2, 'woq4': 2, 'fp16': 0}[mode]  # per-output-channel scale
+    # gate|up GEMV, algorithmic HBM bytes per launch: both weight matrices + their scales + x + gamma + the output row
+    res['gate_up_bytes'] = 2 * Ir * D * wbytes + 2 * Ir * sbytes + D * 2 + D * 2 + Ir * (1 if mode == 'sq' else 2)
     sess.close()
     del weights
     torch.cuda.empty_cache()
     return res
 
 
-def cpu_baseline(n_tokens, context):
+def _default_cpu_threads():
+    """Threads for the CPU baseline: the physical cores of the host, capped at 64 - a batch-1 decode step is a chain
+    of memory-bound GEMVs and oversubscribing a large multi-socket host makes it slower, not faster (measured on the
+    256-thread GPU host: DESIGN.md, Measurement)."""
+    n = os.cpu_count() or 1
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False) or n
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(n_tokens, context, threads=0, sweep=None):
     """HF transformers LlamaForCausalLM on the host CPU (the reference's run_hf.py flow,
     T/examples/llama_quant/run_hf.py:41-104, minus .cuda()): greedy decode of `n_tokens` tokens at batch 1 with a
     `context`-token KV cache.  Bounded sample: synthetic weights tiled from a random pool, synthetic KV cache instead
@@ -168,7 +191,7 @@ def cpu_baseline(n_tokens, context):
         from transformers.cache_utils import DynamicCache
     except Exception as e:  # pragma: no cover
         return dict(value=None, unit='tokens/s', cores=os.cpu_count(), kind='reference', sample=f'transformers unavailable: {e}')
-    cores = os.cpu_count() or 1
+    cores = threads or _default_cpu_threads()
     try:
         import psutil
         avail = psutil.virtual_memory().available
@@ -209,6 +232,19 @@ def cpu_baseline(n_tokens, context):
         out = model(input_ids=ids, past_key_values=cache, use_cache=True, position_ids=torch.tensor([[pos]]))
         ids = out.logits[:, -1].argmax(-1, keepdim=True)
         pos += 1
+        for th in (sweep or []):  # debug: tokens/s at other thread counts (stderr only)
+            torch.set_num_threads(th)
+            t0 = time.perf_counter()
+            out = model(input_ids=ids, past_key_values=cache, use_cache=True, position_ids=torch.tensor([[pos]]))
+            pos += 1
+            print(f'[cpu_baseline sweep] threads={th}: {1.0 / (time.perf_counter() - t0):.3f} tok/s', file=sys.stderr)
+        torch.set_num_threads(cores)
+        if n_tokens <= 0:  # size the sample to ~20 s of CPU work from one probe token
+            t0 = time.perf_counter()
+            out = model(input_ids=ids, past_key_values=cache, use_cache=True, position_ids=torch.tensor([[pos]]))
+            ids = out.logits[:, -1].argmax(-1, keepdim=True)
+            pos += 1
+            n_tokens = int(max(2, min(64, round(20.0 / max(time.perf_counter() - t0, 1e-3)))))
         t0 = time.perf_counter()
         for _ in range(n_tokens):
             out = model(input_ids=ids, past_key_values=cache, use_cache=True, position_ids=torch.tensor([[pos]]))
@@ -267,22 +303,22 @@ def main():
         return
 
     prof = res['profile']
-    gemv_ms, gemv_n = prof['gemv_layer']
     prof_steps = 8
-    avg_dur_s = gemv_ms * 1e-3 / max(gemv_n, 1)
-    bytes_per_launch = res['gemv_layer_bytes_per_step'] * prof_steps / max(gemv_n, 1)
+    avg_dur_s = res['kernel_us']['gate_up'] * 1e-6
+    bytes_per_launch = res['gate_up_bytes']
     achieved = bytes_per_launch / avg_dur_s / 1e9 if avg_dur_s > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(args.config, {}).get('gemv_layer_hbm_bytes_per_launch')
+            traffic = json.load(open(pmc)).get(args.config, {}).get('gate_up_hbm_bytes_per_launch')
         except Exception:
             traffic = None
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(args.cpu_tokens, args.context)
+            cpu = cpu_baseline(args.cpu_tokens, args.context, args.cpu_threads,
+                               [int(x) for x in args.cpu_sweep.split(',') if x])
         except Exception as e:
             cpu = dict(value=None, unit='tokens/s', cores=os.cpu_count(), kind='reference', sample=f'failed: {e!r}')
     names = {'sq': 'SmoothQuant per-channel int8 (act+weight) + int8 KV cache', 'woq8': 'weight-only int8 + int8 KV cache',
@@ -305,11 +341,12 @@ def main():
                    'seq_len': args.context, 'parallelism': f'tp{world}'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     'kernel': 'gemv_kernel (layer GEMVs: QKV, O, gate|up, down)',
+                     'kernel': 'gemv_kernel<WT, PK_NORM, EK_SWIGLU, 1> (RMSNorm -> gate|up GEMV -> SwiGLU; ~25-30 % of a step)',
                      'bytes_per_launch': bytes_per_launch, 'avg_launch_us': avg_dur_s * 1e6},
         'cpu_baseline': cpu,
         'step': {'hbm_bytes': res['step_bytes'], 'hbm_frac_of_peak': res['step_bytes'] / (res['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  'device_ms_per_step': res['dev_ms'] / args.steps, 'outputs_finite': res['finite'],
+                 'layer_kernel_us': res['kernel_us'],
                  'profile_ms_per_step': {k: v[0] / prof_steps for k, v in prof.items()},
                  'launches_per_step': {k: v[1] / prof_steps for k, v in prof.items()}},
     }

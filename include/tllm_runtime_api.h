@@ -78,6 +78,15 @@ void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer);
  * algorithmic-bytes model of SURVEY.md §8(d), evaluated for this session's configuration. */
 int64_t tllm_session_step_bytes(tllm_session_t s, int32_t context_len);
 
+/* Live per-kernel timing for bench.py's roofline: launches ONLY kernel K<which> of every layer (1 = RMSNorm+QKV GEMV,
+ * 2 = decode attention, 4 = O-projection GEMV, 5 = RMSNorm+gate|up GEMV+SwiGLU, 6 = down GEMV) back to back,
+ * `sweeps` passes over the layers (each layer has its own weights, so every launch streams cold HBM exactly as in a
+ * real step), bracketed by one HIP event pair on the session's stream.  avg_us = elapsed / launches (inter-launch
+ * gaps included).  Activations are whatever the buffers hold: timing only, call tllm_session_fake_context or
+ * tllm_session_context again before generating. */
+int32_t tllm_session_time_kernel(tllm_session_t s, int32_t which, int32_t sweeps, float* avg_us, int64_t* launches,
+    tllm_stream_t stream);
+
 /* Instrumented generation steps (eager, a hipEvent pair around every launch) for the roofline report:
  * elapsed milliseconds and launch counts per class over `n_steps` steps.
  * Classes: 0 layer GEMVs (QKV, O, gate|up, down), 1 lm_head GEMV, 2 attention (split-KV + combine),

@@ -183,6 +183,7 @@ struct tllm_session
         PC_COUNT = 5
     };
     bool profiling = false;
+    int only_kernel = -1; // tllm_session_time_kernel: launch just K<only_kernel> of every layer (1,2,4,5,6)
     int gemv_cls = PC_GEMV_LAYER;
     struct ProfRec
     {
@@ -579,7 +580,9 @@ struct tllm_session
             set_error("session: generation step supports batch <= 8 (got %d)", B);
             return 1;
         }
-        RUN(timed(PC_OTHER, st, [&] { return launch_embedding(x, cur_ids, emb, B, D, vocab, st); }));
+        const int ok = only_kernel;
+        if (ok < 0)
+            RUN(timed(PC_OTHER, st, [&] { return launch_embedding(x, cur_ids, emb, B, D, vocab, st); }));
         const bool r0 = rank == 0;
         for (int li = 0; li < num_layers; ++li)
         {
@@ -587,6 +590,7 @@ struct tllm_session
             const int pro_norm = !sq ? PRO_RMSNORM : (per_token ? PRO_RMSNORM_QDYN : PRO_RMSNORM_QSTATIC);
             const int pro_q = !sq ? PRO_NONE : (per_token ? PRO_QDYN : PRO_QSTATIC);
             // K1
+            if (ok < 0 || ok == 1)
             RUN(gemv(L.qkv, B, pro_norm, EPI_NONE, x, D, L.ln1, L.ln1_scale, nullptr, nullptr, qkv, 3 * Dr, DT_HALF,
                 nullptr, st));
             // K2/K3
@@ -615,22 +619,30 @@ struct tllm_session
             m.skip_combine = attn_fused ? 1 : 0;
             m.out = ctx;
             m.workspace = mmha_ws;
-            RUN(timed(PC_ATTENTION, st, [&] { return launch_mmha(m, st); }));
+            if (ok < 0 || ok == 2)
+                RUN(timed(PC_ATTENTION, st, [&] { return launch_mmha(m, st); }));
             // K4: x <- x + O(ctx)     (TP: rank 0 carries the residual into the all-reduce)
             const int pro_o = !attn_fused ? pro_q : (!sq ? PRO_ATTN : (per_token ? PRO_ATTN_QDYN : PRO_ATTN_QSTATIC));
+            if (ok < 0 || ok == 4)
             RUN(gemv(L.dense, B, pro_o, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE, ctx, Dr, nullptr, L.attn_qscale, x,
                 nullptr, x, D, DT_HALF, nullptr, st));
-            RUN(allreduce(x, (int64_t) B * D, st));
+            if (ok < 0)
+                RUN(allreduce(x, (int64_t) B * D, st));
             // K5
             const bool q_inter = sq && !per_token;
+            if (ok < 0 || ok == 5)
             RUN(gemv(L.fc, B, pro_norm, q_inter ? EPI_SWIGLU_QSTATIC : EPI_SWIGLU, x, D, L.ln2, L.ln2_scale, nullptr,
                 L.mlp_qscale, q_inter ? (void*) q8 : inter_buf, Ir, q_inter ? DT_INT8 : DT_HALF, &L.gate, st));
             // K6
+            if (ok < 0 || ok == 6)
             RUN(gemv(L.proj, B, q_inter ? PRO_NONE : pro_q, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE,
                 q_inter ? (const void*) q8 : inter_buf, Ir, nullptr, L.mlp_qscale, x, nullptr, x, D, DT_HALF, nullptr,
                 st));
-            RUN(allreduce(x, (int64_t) B * D, st));
+            if (ok < 0)
+                RUN(allreduce(x, (int64_t) B * D, st));
         }
+        if (ok >= 0)
+            return 0;
         RUN(run_head(x, st));
         RUN(run_sampler(1, st));
         return 0;
@@ -1166,6 +1178,39 @@ int64_t tllm_session_step_bytes(tllm_session_t s, int32_t context_len)
     for (auto& L : s->layers)
         bytes += lin(L.qkv) + lin(L.dense) + lin(L.fc) + lin(L.gate) + lin(L.proj) + kv_row * s->B * (context_len + 1);
     return bytes;
+}
+
+int32_t tllm_session_time_kernel(tllm_session_t s, int32_t which, int32_t sweeps, float* avg_us, int64_t* launches,
+    tllm_stream_t stream)
+{
+    if (!s || !s->B || sweeps < 1 || !avg_us || !launches || !(which == 1 || which == 2 || which == 4 || which == 5 || which == 6))
+    {
+        set_error("tllm_session_time_kernel: bad arguments (which in {1,2,4,5,6}) / setup not called");
+        return 1;
+    }
+    hipStream_t st = s->pick(stream);
+    hipEvent_t a, b;
+    (void) hipEventCreate(&a);
+    (void) hipEventCreate(&b);
+    s->only_kernel = which;
+    int rc = s->run_decode_step(st); // untimed sweep
+    (void) hipEventRecord(a, st);
+    for (int i = 0; i < sweeps && !rc; ++i)
+        rc = s->run_decode_step(st);
+    (void) hipEventRecord(b, st);
+    s->only_kernel = -1;
+    (void) hipStreamSynchronize(st);
+    float ms = 0.f;
+    if (!rc && hipEventElapsedTime(&ms, a, b) != hipSuccess)
+    {
+        set_error("tllm_session_time_kernel: event timing failed");
+        rc = 1;
+    }
+    (void) hipEventDestroy(a);
+    (void) hipEventDestroy(b);
+    *launches = (int64_t) sweeps * s->num_layers;
+    *avg_us = ms * 1000.f / (float) *launches;
+    return rc;
 }
 
 int32_t tllm_session_profile(tllm_session_t s, int32_t n_steps, float* ms_per_class, int64_t* launches_per_class,

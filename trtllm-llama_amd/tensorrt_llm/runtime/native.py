@@ -52,6 +52,9 @@ def _lib():
     lib.tllm_session_step_bytes.restype = c.c_int64
     lib.tllm_session_profile.argtypes = [c.c_void_p, c.c_int32, c.POINTER(c.c_float), c.POINTER(c.c_int64), c.c_void_p]
     lib.tllm_session_profile.restype = c.c_int32
+    lib.tllm_session_time_kernel.argtypes = [c.c_void_p, c.c_int32, c.c_int32, c.POINTER(c.c_float), c.POINTER(c.c_int64),
+                                             c.c_void_p]
+    lib.tllm_session_time_kernel.restype = c.c_int32
     lib.tllm_session_destroy.argtypes = [c.c_void_p]
     lib.tllm_session_destroy.restype = None
     lib.tllm_gemv_set_rows_per_wave.argtypes = [c.c_int32]
@@ -148,6 +151,16 @@ class NativeSession:
         cnt = (ctypes.c_int64 * 5)()
         _check(_lib().tllm_session_profile(self._h, n_steps, ms, cnt, stream), 'profile')
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(self.PROFILE_CLASSES)}
+
+    LAYER_KERNELS = {'qkv': 1, 'attention': 2, 'o_proj': 4, 'gate_up': 5, 'down': 6}
+
+    def time_kernel(self, which: str, sweeps: int = 4, stream: int = 0):
+        """(average microseconds per launch, launches) of one per-layer kernel launched back to back over all layers."""
+        us = ctypes.c_float()
+        n = ctypes.c_int64()
+        _check(_lib().tllm_session_time_kernel(self._h, self.LAYER_KERNELS[which], sweeps, ctypes.byref(us),
+                                               ctypes.byref(n), stream), 'time_kernel')
+        return float(us.value), int(n.value)
 
     def kv_cache_ptr(self, layer: int) -> int:
         return _lib().tllm_session_kv_cache_ptr(self._h, layer)
