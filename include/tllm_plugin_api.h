@@ -105,7 +105,8 @@ const char* tllm_last_error(void);
  * (PY/functional.py:2826-2893, PY/quantization/functional.py:12-212, PY/layers/linear.py:13-35).
  * Registered names (P/api/InferPlugin.cpp:153-168 subset):
  *   "GPTAttention", "Gemm", "SmoothQuantGemm", "WeightOnlyQuantMatmul", "QuantizeTensor",
- *   "QuantizePerToken", "LayernormQuantization", "AllReduce", "AllGather"
+ *   "QuantizePerToken", "AllReduce", "AllGather"
+ *   ("LayernormQuantization" is not on the LLaMA path - LLaMA normalises with RMSNorm - and is not registered)
  * plus the MI355X additions that the reference composes out of TensorRT pointwise layers:
  *   "Rmsnorm", "RmsnormQuantization", "SwiGLU"
  * Field names / types / defaults are the reference's; an unknown or missing field makes creation
@@ -175,7 +176,9 @@ int32_t tllm_comm_destroy_all(void);
  * Host (CPU) function; `weight_kn` is row-major [k, n] fp16 bits.  bits = 8 or 4.
  * processed layout (this library's own, replaces the SM80 interleave of
  * T/cpp/tensorrt_llm/kernels/cutlass_kernels/cutlass_preprocessors.cpp:158-535):
- *   int8: [n, k] row-major (k contiguous);  int4: [n, k/2], element k in the low nibble when k is even.
+ *   int8: [n, roundup(k,16)] row-major (k contiguous), stored as u8 = q + 128;
+ *   int4: [n, roundup(k,32)/2], nibble = q + 8, the 8 nibbles of every 32-bit word (low to high) hold elements
+ *         e0 e2 e4 e6 e1 e3 e5 e7 of that group of 8.
  * `unprocessed_out` (optional, may be NULL) receives the plain quantised [k, n] (int8) or [k, n/2] (int4,
  * low nibble first) tensor — the op's 3-output variant `_symmetric_quantize_last_axis_of_batched_matrix`.
  * ---------------------------------------------------------------------------------------------- */

@@ -330,3 +330,34 @@ def test_context_attention_vs_oracle(int8_kv, H, Dh, S):
 def test_plugin_rejects_unbuilt_features():
     p = capi.Plugin.create('GPTAttention', [capi.PluginField('num_heads', i32(4))])
     assert p is None and 'missing plugin field' in capi.last_error()
+
+
+# ---------------------------------------------------------------------------------------------- collectives
+def test_allreduce_allgather_single_rank_rccl():
+    """The comm plugins on a 1-rank RCCL communicator (the only world a 1-GPU box allows): exercises the dlopen of
+    librccl, ncclCommInitRank through tllm_comm_init_rank, the communicator lookup by rank set
+    (P/common/plugin.h:181-188) and the enqueue path of P/ncclPlugin/{allreduce,allgather}Plugin.cpp; with one
+    rank both collectives are the identity.  N > 1 is covered on CPU by tests/test_tp_gloo.py."""
+    import ctypes
+    lib = capi.load_library()
+    uid = (ctypes.c_char * 128)()
+    assert lib.tllm_comm_get_unique_id(uid) == 0, capi.last_error()
+    group = (ctypes.c_int32 * 1)(0)
+    assert lib.tllm_comm_init_rank(group, 1, 0, uid) == 0, capi.last_error()
+    try:
+        r = rng(21)
+        x = h(r.standard_normal((3, 4096)))
+        y = torch.zeros_like(x)
+        ar = make_plugin('AllReduce', [('group', i32([0])), ('type_id', i32([capi.HALF]))])
+        run_plugin(ar, [x], [y])
+        assert torch.equal(x, y)
+        ag = make_plugin('AllGather', [('group', i32([0])), ('type_id', i32([capi.HALF]))])
+        z = torch.zeros_like(x)
+        run_plugin(ag, [x], [z])
+        assert torch.equal(x, z)
+        # a group nobody initialised is an error, not a hang or an exit()
+        bad = make_plugin('AllReduce', [('group', i32([0, 1])), ('type_id', i32([capi.HALF]))])
+        with pytest.raises(RuntimeError):
+            run_plugin(bad, [x], [y])
+    finally:
+        assert lib.tllm_comm_destroy_all() == 0

@@ -1,776 +1,15 @@
-// Skinny GEMM / GEMV for decode (M <= 8): the HBM-bound heart of the per-token path.
-//
-//   y[m,n] = epi( scale(n,m) * sum_k pro(x)[m,k] * W[n,k] )
-//
-// One wave owns 2 weight rows per step and streams them with 16-byte non-temporal loads (1 KiB per wave
-// instruction, 4 k-chunks per row = an 8 KiB tile, double-buffered); pro(x) is built once per workgroup in
-// registers and published to LDS (RMSNorm and/or int8 quantisation and/or the split-KV attention merge fused in,
-// so the normalised / quantised activation never goes to HBM); the dot products use v_dot2_f32_f16
-// (fp16 x fp16 -> fp32) or v_dot4_i32_i8 (SmoothQuant, exact int32); reduction over the 64 lanes on the DPP
-// network; residual-add / SwiGLU / quantising epilogues fused.  Persistent grid (<= what the chip holds at once).
-//
-// The kernel is specialised at compile time on (weight type, prologue family, epilogue family, row-count bucket):
-// one generic kernel with run-time switches was 14k instructions and its cold instruction fetch showed up as a
-// ~2 us floor on every launch.
-//
-// Reference semantics: A7 P/gemmPlugin/gemmPlugin.cpp:121-190; A8 K/weightOnlyMatrixVectorMultiplication.cu:136-277
-// (y = sum_k x[k] * (q[k,n] * s[n])); A10 cutlass_extensions/.../epilogue_per_row_per_col_scale.h:279-347
-// (C = cvt(float(acc_i32) * (alpha_col * alpha_row))); A5 PY/functional.py:3195-3219; A6 PY/layers/mlp.py:68-73;
-// A11 K/quantization.cu:31-118, K/layernormKernels.cu:146-183.
-#include "dev_utils.h"
-#include "kernels.h"
+// Dispatcher of the decode GEMV (kernel: gemv_impl.h; one translation unit per weight type).
+#include "gemv_args.h"
 #include "weight_layout.h"
-#include <algorithm>
-#include <map>
+#include <cstdint>
 
 namespace tllm
 {
 namespace kernels
 {
-using namespace dev;
 
 int gemv_tune_r = 0;             // (kept for the C ABI; the kernel is fixed at 2 rows x 4 chunks per tile)
 int gemv_tune_blocks_per_cu = 0; // test/bench override: persistent workgroups per CU (0 = occupancy query)
-
-namespace
-{
-
-constexpr int R = 2, U = 4;
-constexpr int kRedBytes = 256;
-constexpr int kNXV = 6; // 16-byte x vectors a thread keeps in registers: K <= 256 * 8 * 6 = 12288 halfs
-
-enum ProKind
-{
-    PK_COPY = 0,  // x already in the operand type
-    PK_NORM = 1,  // RMSNorm (+ quant for SQ)
-    PK_QUANT = 2, // fp16 -> s8 (SQ)
-    PK_ATTN = 3   // split-KV merge (+ quant for SQ)
-};
-enum EpiKind
-{
-    EK_PLAIN = 0, // none | residual
-    EK_SWIGLU = 1 // swiglu (+ static quant)
-};
-
-struct GemvArgs
-{
-    GemvParams p;
-    int32_t Kp;      // K rounded up to the weight vector width
-    int32_t nchunks; // ceil(Kp / (64 * VEC))
-    int32_t ngroups; // row groups (one per wave-step)
-};
-
-template <int WT>
-struct WTraits;
-template <>
-struct WTraits<W_FP16>
-{
-    static constexpr int VEC = 8;
-    static constexpr bool IS_SQ = false;
-    static constexpr uint32_t ZERO = 0u;
-};
-template <>
-struct WTraits<W_INT8_WOQ>
-{
-    static constexpr int VEC = 16;
-    static constexpr bool IS_SQ = false;
-    static constexpr uint32_t ZERO = 0x80808080u; // q + 128
-};
-template <>
-struct WTraits<W_INT4_WOQ>
-{
-    static constexpr int VEC = 32;
-    static constexpr bool IS_SQ = false;
-    static constexpr uint32_t ZERO = 0x88888888u; // q + 8
-};
-template <>
-struct WTraits<W_INT8_SQ>
-{
-    static constexpr int VEC = 16;
-    static constexpr bool IS_SQ = true;
-    static constexpr uint32_t ZERO = 0u;
-};
-
-// ---- per-16-byte dot products -----------------------------------------------------------------
-__device__ __forceinline__ float dot_fp16(const uint4& w, const uint4& x, float acc)
-{
-    acc = dot2(w.x, x.x, acc);
-    acc = dot2(w.y, x.y, acc);
-    acc = dot2(w.z, x.z, acc);
-    acc = dot2(w.w, x.w, acc);
-    return acc;
-}
-
-// u8 (q+128) weights: 4 bytes -> two fp16 pairs via the 0x6400 | b splice (1024 + b is exact in fp16)
-__device__ __forceinline__ float dot_u8x4(uint32_t w, uint32_t x01, uint32_t x23, float acc)
-{
-    const uint32_t magic = 0x64646464u;
-    const h2_t bias = {(_Float16) 1152.f, (_Float16) 1152.f}; // 1024 + 128
-    const h2_t l = u32_as_h2(__builtin_amdgcn_perm(magic, w, 0x04010400u)) - bias;
-    const h2_t h = u32_as_h2(__builtin_amdgcn_perm(magic, w, 0x04030402u)) - bias;
-    acc = __builtin_amdgcn_fdot2(l, u32_as_h2(x01), acc, false);
-    acc = __builtin_amdgcn_fdot2(h, u32_as_h2(x23), acc, false);
-    return acc;
-}
-
-__device__ __forceinline__ float dot_woq8(const uint4& w, const uint4& xa, const uint4& xb, float acc)
-{
-    acc = dot_u8x4(w.x, xa.x, xa.y, acc);
-    acc = dot_u8x4(w.y, xa.z, xa.w, acc);
-    acc = dot_u8x4(w.z, xb.x, xb.y, acc);
-    acc = dot_u8x4(w.w, xb.z, xb.w, acc);
-    return acc;
-}
-
-// 8 nibbles (layout of weight_layout.h) vs 8 halfs of x (one uint4)
-__device__ __forceinline__ float dot_u4x8(uint32_t w, const uint4& x, float acc)
-{
-    const uint32_t m = 0x64006400u;
-    const uint32_t w8 = w >> 8;
-    const h2_t b0 = {(_Float16) 1032.f, (_Float16) 1032.f}; // 1024 + 8
-    const h2_t s1 = {(_Float16) 0.0625f, (_Float16) 0.0625f};
-    const h2_t b1 = {(_Float16) -72.f, (_Float16) -72.f}; // (1024 + 16 n) / 16 - 72 = n - 8
-    const h2_t e01 = u32_as_h2((w & 0x000f000fu) | m) - b0;
-    const h2_t e23 = u32_as_h2((w & 0x00f000f0u) | m) * s1 + b1;
-    const h2_t e45 = u32_as_h2((w8 & 0x000f000fu) | m) - b0;
-    const h2_t e67 = u32_as_h2((w8 & 0x00f000f0u) | m) * s1 + b1;
-    acc = __builtin_amdgcn_fdot2(e01, u32_as_h2(x.x), acc, false);
-    acc = __builtin_amdgcn_fdot2(e23, u32_as_h2(x.y), acc, false);
-    acc = __builtin_amdgcn_fdot2(e45, u32_as_h2(x.z), acc, false);
-    acc = __builtin_amdgcn_fdot2(e67, u32_as_h2(x.w), acc, false);
-    return acc;
-}
-
-__device__ __forceinline__ int dot_sq(const uint4& w, const uint4& x, int acc)
-{
-    acc = sdot4(w.x, x.x, acc);
-    acc = sdot4(w.y, x.y, acc);
-    acc = sdot4(w.z, x.z, acc);
-    acc = sdot4(w.w, x.w, acc);
-    return acc;
-}
-
-__device__ __forceinline__ float silu_mul_fp16(float g, float u)
-{
-    // fp16 rounding points of the reference graph: inter = fc(x) (fp16) ; a = inter * sigmoid(inter) (fp16) ;
-    // out = a * gate(x) (fp16)   (PY/layers/mlp.py:68-73, PY/functional.py:521-532)
-    const float g16 = h2f(f2h(g));
-    const float u16 = h2f(f2h(u));
-    const float a = h2f(f2h(g16 / (1.f + __expf(-g16))));
-    return h2f(f2h(a * u16));
-}
-
-// ---- the kernel --------------------------------------------------------------------------------
-// LDS map: [0,256) reduction scratch | MB rows of Kp activations (fp16, or s8 for SmoothQuant)
-//
-// Latency structure (the per-launch floor matters: a 7B layer is 4 launches of 17-90 MB, i.e. 3-15 us each at HBM
-// speed).  Everything that does not depend on x is requested at t = 0, in one memory round trip: x / gamma, the first
-// weight tile of every wave, the epilogue operands (scales, residual) of its first row group, the launch-constant
-// scales.  No branches around loads (a lane-dependent `if` makes the compiler fence each load with s_waitcnt + exec
-// masking): out-of-range lanes load a clamped, valid address and the value is replaced by a select.  Then: pro(x) in
-// registers (sum of squares -> ONE barrier -> normalise / quantise) -> LDS -> ONE barrier -> dots -> DPP reduction ->
-// epilogue.  Further tiles are double-buffered, with the next group's epilogue operands requested ahead of the next
-// tile so that waiting for them never drains the weight stream.
-template <int WT, int PK, int EK, int MB>
-__global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
-{
-    using TR = WTraits<WT>;
-    constexpr int VEC = TR::VEC;
-    constexpr bool SQ = TR::IS_SQ;
-    constexpr bool SWIGLU = EK == EK_SWIGLU;
-    constexpr bool X_HALF = !(SQ && PK == PK_COPY); // the input activations are fp16 (else raw s8)
-    using acc_t = typename std::conditional<SQ, int, float>::type;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const GemvParams& p = a.p;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int K = p.K, Kp = a.Kp;
-    float* red = reinterpret_cast<float*>(smem);
-    char* xs = smem + kRedBytes; // [MB][Kp] halfs, or [MB][Kp] s8 for SQ
-    constexpr int XES = SQ ? 1 : 2;
-    const bool q_dyn = SQ && (p.pro == PRO_RMSNORM_QDYN || p.pro == PRO_QDYN || p.pro == PRO_ATTN_QDYN);
-    const bool q_static = SQ && (p.pro == PRO_RMSNORM_QSTATIC || p.pro == PRO_QSTATIC || p.pro == PRO_ATTN_QSTATIC);
-
-    // ------------------------------------------------------------------ weight-tile helpers
-    const char* wbase = reinterpret_cast<const char*>(p.w);
-    const char* wup = p.w_up ? reinterpret_cast<const char*>(p.w_up) : wbase + (int64_t) p.N * p.ldw;
-    const int lane_kbyte = lane * 16;
-    const int64_t last_vec = p.ldw - 16;
-    auto rows_of_group = [&](int g, const char* (&rowptr)[R]) {
-        if constexpr (SWIGLU)
-        {
-            const int o = g < p.N ? g : p.N - 1; // one output per group: gate row o, up row o
-            rowptr[0] = wbase + (int64_t) o * p.ldw;
-            rowptr[1] = wup + (int64_t) o * p.ldw;
-        }
-        else
-        {
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-            {
-                const int row = g * R + r;
-                rowptr[r] = wbase + (int64_t) (row < p.N ? row : p.N - 1) * p.ldw;
-            }
-        }
-    };
-    auto load_tile = [&](const char* const (&rowptr)[R], int c, uint4 (&wv)[U][R]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-            const bool ok = ((c + u) * 64 + lane) * VEC < Kp;
-            int64_t off = (int64_t) (c + u) * 1024 + lane_kbyte;
-            off = off < last_vec ? off : last_vec;
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-            {
-                const uint4 v = ld_nt16(rowptr[r] + off);
-                wv[u][r] = make_uint4(ok ? v.x : TR::ZERO, ok ? v.y : TR::ZERO, ok ? v.z : TR::ZERO, ok ? v.w : TR::ZERO);
-            }
-        }
-    };
-
-    // ------------------------------------------------------------------ t = 0: every x-independent request
-    uint4 xv[kNXV], gv[kNXV];
-    auto load_x_row = [&](int m) {
-        if constexpr (PK == PK_ATTN)
-        {
-            // ctx[h, d] = sum_i e_i o_i[d] / (sum_i e_i l_i + 1e-6),  e_i = exp(m_i - max_i m_i)  (MM/...Template.h:1756)
-            // All partial slots (<= 8) are requested unconditionally and together - addresses do not depend on the
-            // sequence length; slots beyond the active count get weight 0 by a select.
-            constexpr int NSM = 8;
-            const float2* ml = reinterpret_cast<const float2*>(p.attn_ml);
-            const int seq = p.attn_seq_len[m];
-            const int nsm = p.attn_nsmax < NSM ? p.attn_nsmax : NSM;
-#pragma unroll
-            for (int j = 0; j < kNXV; ++j)
-            {
-                xv[j] = make_uint4(0, 0, 0, 0);
-                if (j * 2048 < Kp) // uniform
-                {
-                    const int k = (tid + j * 256) * 8;
-                    const int kc = k < K ? k : K - 8;
-                    const int hh = kc / p.attn_dh, d0 = kc % p.attn_dh;
-                    const int64_t base = ((int64_t) m * p.attn_heads + hh) * p.attn_nsmax;
-                    float2 mls[NSM];
-                    float4 oa[NSM], ob[NSM];
-#pragma unroll
-                    for (int i = 0; i < NSM; ++i)
-                    {
-                        const int ic = i < nsm ? i : 0; // uniform clamp
-                        mls[i] = ml[base + ic];
-                        oa[i] = *reinterpret_cast<const float4*>(p.attn_o + (base + ic) * p.attn_dh + d0);
-                        ob[i] = *reinterpret_cast<const float4*>(p.attn_o + (base + ic) * p.attn_dh + d0 + 4);
-                    }
-                    const int ns = seq / p.attn_tchunk + 1; // active splits
-                    float Mx = -INFINITY;
-#pragma unroll
-                    for (int i = 0; i < NSM; ++i)
-                        Mx = (i < ns && i < nsm) ? fmaxf(Mx, mls[i].x) : Mx;
-                    float L = 0.f;
-                    float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int i = 0; i < NSM; ++i)
-                    {
-                        const bool act = i < ns && i < nsm && mls[i].x != -INFINITY;
-                        const float e = act ? __expf(mls[i].x - Mx) : 0.f;
-                        L += act ? mls[i].y * e : 0.f;
-                        o8[0] += act ? oa[i].x * e : 0.f;
-                        o8[1] += act ? oa[i].y * e : 0.f;
-                        o8[2] += act ? oa[i].z * e : 0.f;
-                        o8[3] += act ? oa[i].w * e : 0.f;
-                        o8[4] += act ? ob[i].x * e : 0.f;
-                        o8[5] += act ? ob[i].y * e : 0.f;
-                        o8[6] += act ? ob[i].z * e : 0.f;
-                        o8[7] += act ? ob[i].w * e : 0.f;
-                    }
-                    const float inv = (k < K) ? 1.f / (L + 1.e-6f) : 0.f;
-                    xv[j] = make_uint4(pack_h2(o8[0] * inv, o8[1] * inv), pack_h2(o8[2] * inv, o8[3] * inv),
-                        pack_h2(o8[4] * inv, o8[5] * inv), pack_h2(o8[6] * inv, o8[7] * inv));
-                }
-            }
-        }
-        else if constexpr (X_HALF)
-        {
-            const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * p.ldx;
-#pragma unroll
-            for (int j = 0; j < kNXV; ++j)
-            {
-                xv[j] = make_uint4(0, 0, 0, 0);
-                if (j * 2048 < Kp) // uniform
-                {
-                    const int k = (tid + j * 256) * 8;
-                    const uint4 v = *reinterpret_cast<const uint4*>(xg + (k < K ? k : K - 8));
-                    xv[j] = make_uint4(k < K ? v.x : 0u, k < K ? v.y : 0u, k < K ? v.z : 0u, k < K ? v.w : 0u);
-                }
-            }
-        }
-        else
-        {
-            // raw s8 activations: 16 values per vector
-            const int8_t* xg = reinterpret_cast<const int8_t*>(p.x) + (int64_t) m * p.ldx;
-#pragma unroll
-            for (int j = 0; j < kNXV; ++j)
-            {
-                xv[j] = make_uint4(0, 0, 0, 0);
-                if (j * 4096 < Kp) // uniform
-                {
-                    const int k = (tid + j * 256) * 16;
-                    const uint4 v = *reinterpret_cast<const uint4*>(xg + (k < K ? k : K - 16));
-                    xv[j] = make_uint4(k < K ? v.x : 0u, k < K ? v.y : 0u, k < K ? v.z : 0u, k < K ? v.w : 0u);
-                }
-            }
-        }
-    };
-    load_x_row(0);
-    if constexpr (PK == PK_NORM)
-    {
-        const uint16_t* gam = reinterpret_cast<const uint16_t*>(p.gamma);
-#pragma unroll
-        for (int j = 0; j < kNXV; ++j)
-        {
-            gv[j] = make_uint4(0, 0, 0, 0);
-            if (j * 2048 < Kp) // uniform
-            {
-                const int k = (tid + j * 256) * 8;
-                gv[j] = *reinterpret_cast<const uint4*>(gam + (k < K ? k : K - 8));
-            }
-        }
-    }
-    const int g0 = blockIdx.x * 4 + wid;
-    const int gstride = gridDim.x * 4;
-    const char* rowptr[R];
-    uint4 wv[U][R];
-    rows_of_group(g0 < a.ngroups ? g0 : 0, rowptr);
-    load_tile(rowptr, 0, wv);
-
-    constexpr int NOUTS = SWIGLU ? 1 : R;         // outputs per row group
-    const int my_o = lane / MB, my_m = lane % MB; // the (output, row) this lane finishes
-    const bool my_active = my_o < NOUTS && my_m < p.M;
-    struct EpiOps
-    {
-        float s0, s1, res;
-    };
-    auto load_ops = [&](int g) {
-        EpiOps e = {1.f, 1.f, 0.f};
-        int n = g * NOUTS + (my_o < NOUTS ? my_o : 0);
-        n = n < p.N ? n : p.N - 1; // clamped: inactive lanes load a valid element and ignore it
-        if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
-        {
-            const uint16_t* sc = reinterpret_cast<const uint16_t*>(p.scale_col);
-            e.s0 = h2f(sc[n]);
-            if constexpr (SWIGLU)
-                e.s1 = h2f(p.scale_col_up ? reinterpret_cast<const uint16_t*>(p.scale_col_up)[n] : sc[p.N + n]);
-        }
-        else if constexpr (SQ)
-        {
-            const float* sc = reinterpret_cast<const float*>(p.scale_col);
-            e.s0 = sc[p.per_channel ? n : 0];
-            if constexpr (SWIGLU)
-            {
-                const float* su = reinterpret_cast<const float*>(p.scale_col_up);
-                e.s1 = su ? su[p.per_channel ? n : 0] : sc[p.per_channel ? p.N + n : 0];
-            }
-        }
-        if constexpr (!SWIGLU)
-        {
-            if (p.epi == EPI_RESIDUAL) // uniform
-                e.res = h2f(reinterpret_cast<const uint16_t*>(p.residual)[(int64_t) (my_m < p.M ? my_m : 0) * p.ldy + n]);
-        }
-        return e;
-    };
-    EpiOps ops_cur = load_ops(g0 < a.ngroups ? g0 : 0);
-    float static_row_scale = 1.f, static_row_scale_up = 1.f, epi_q = 1.f, pro_q = 1.f;
-    if constexpr (SQ)
-    {
-        if (!q_dyn && p.scale_row) // uniform
-            static_row_scale = p.scale_row[(p.per_token && my_m < p.M) ? my_m : 0];
-        static_row_scale_up = (!q_dyn && p.scale_row_up) ? p.scale_row_up[0] : static_row_scale;
-        if (q_static)
-            pro_q = p.act_scale[0];
-    }
-    if constexpr (SWIGLU)
-    {
-        if (p.epi == EPI_SWIGLU_QSTATIC)
-            epi_q = p.epi_scale[0];
-    }
-
-    // ------------------------------------------------------------------ pro(x) -> LDS
-    float row_scale[MB];
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-        row_scale[m] = 1.f;
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-    {
-        if (m >= p.M) // uniform
-            continue;
-        if (m > 0)
-            load_x_row(m);
-        if constexpr (!X_HALF)
-        {
-#pragma unroll
-            for (int j = 0; j < kNXV; ++j)
-            {
-                const int k = (tid + j * 256) * 16;
-                if (k < Kp)
-                    *reinterpret_cast<uint4*>(xs + (size_t) m * Kp + k) = xv[j];
-            }
-            continue;
-        }
-        float inv = 1.f;
-        if constexpr (PK == PK_NORM)
-        {
-            float ss = 0.f;
-#pragma unroll
-            for (int j = 0; j < kNXV; ++j)
-            {
-                const uint32_t ws[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                {
-                    const h2_t h = u32_as_h2(ws[q]);
-                    const float f0 = (float) h.x, f1 = (float) h.y;
-                    ss += f0 * f0 + f1 * f1;
-                }
-            }
-            ss = wave_sum(ss);
-            if (lane == 0)
-                red[m * 4 + wid] = ss;
-            __syncthreads();
-            ss = red[m * 4] + red[m * 4 + 1] + red[m * 4 + 2] + red[m * 4 + 3];
-            inv = 1.0f / sqrtf(ss / (float) K + p.eps);
-        }
-        float amax = 0.f;
-        if (PK == PK_NORM || q_dyn)
-        {
-#pragma unroll
-            for (int j = 0; j < kNXV; ++j)
-            {
-                uint32_t xs4[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-                const uint32_t gs4[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                {
-                    h2_t h = u32_as_h2(xs4[q]);
-                    if constexpr (PK == PK_NORM)
-                    {
-                        const h2_t gg = u32_as_h2(gs4[q]);
-                        const float n0 = h2f(f2h((float) h.x * inv)), n1 = h2f(f2h((float) h.y * inv));
-                        h.x = (_Float16) (n0 * (float) gg.x);
-                        h.y = (_Float16) (n1 * (float) gg.y);
-                        xs4[q] = h2_as_u32(h);
-                    }
-                    amax = fmaxf(amax, fmaxf(fabsf((float) h.x), fabsf((float) h.y)));
-                }
-                xv[j] = make_uint4(xs4[0], xs4[1], xs4[2], xs4[3]);
-            }
-        }
-        float qs = pro_q;
-        if constexpr (SQ)
-        {
-            if (q_dyn) // uniform
-            {
-                amax = wave_max(amax);
-                if (lane == 0)
-                    red[32 + m * 4 + wid] = amax;
-                __syncthreads();
-                amax = fmaxf(fmaxf(red[32 + m * 4], red[32 + m * 4 + 1]), fmaxf(red[32 + m * 4 + 2], red[32 + m * 4 + 3]));
-                amax = fmaxf(amax, h2f(f2h(1e-6f))); // T localMax = 1e-6f (K/quantization.cu:101)
-                qs = 127.f / amax;
-                row_scale[m] = amax / 127.f;
-                if (blockIdx.x == 0 && tid == 0 && p.dyn_scale_out)
-                    p.dyn_scale_out[m] = amax / 127.f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < kNXV; ++j)
-        {
-            const int k = (tid + j * 256) * 8;
-            if (k < Kp)
-            {
-                if constexpr (SQ)
-                {
-                    const uint32_t ws[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-                    uint32_t o[2] = {0, 0};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                    {
-                        const h2_t h = u32_as_h2(ws[q]);
-                        const uint32_t b0 = (uint8_t) f2i8_rni_sat((float) h.x * qs);
-                        const uint32_t b1 = (uint8_t) f2i8_rni_sat((float) h.y * qs);
-                        o[q >> 1] |= (b0 | (b1 << 8)) << (16 * (q & 1));
-                    }
-                    *reinterpret_cast<uint2*>(xs + (size_t) m * Kp + k) = make_uint2(o[0], o[1]);
-                }
-                else
-                    *reinterpret_cast<uint4*>(xs + ((size_t) m * Kp + k) * 2) = xv[j];
-            }
-        }
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && p.x_pro_out && PK != PK_COPY)
-    {
-        for (int m = 0; m < MB && m < p.M; ++m)
-            for (int k = tid; k < K * XES; k += 256)
-                reinterpret_cast<char*>(p.x_pro_out)[(int64_t) m * K * XES + k] = xs[(size_t) m * Kp * XES + k];
-    }
-
-    // ------------------------------------------------------------------ main loop: persistent waves, double buffer
-    const int tiles_per_group = (a.nchunks + U - 1) / U;
-    const int ngroups_mine = g0 < a.ngroups ? (a.ngroups - g0 + gstride - 1) / gstride : 0;
-    const int ntiles = ngroups_mine * tiles_per_group;
-    float my_row_scale = static_row_scale, my_row_scale_up = static_row_scale_up;
-    if (q_dyn)
-    {
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-            if (m == my_m)
-                my_row_scale = my_row_scale_up = row_scale[m];
-    }
-
-    acc_t acc[R][MB];
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-            acc[r][m] = 0;
-
-    uint4 wv2[U][R];
-    int t_issue = 1, gi_i = 0, ci_i = 1; // tile 0 is already in flight in `wv`
-    if (ci_i == tiles_per_group)
-    {
-        ci_i = 0;
-        gi_i = 1;
-    }
-    int gi_p = 0, ci_p = 0;
-
-    auto step = [&](uint4 (&cur)[U][R], uint4 (&nxt)[U][R]) {
-        const bool last = ci_p == tiles_per_group - 1;
-        const int g = g0 + gi_p * gstride;
-        const int n = g * NOUTS + (my_o < NOUTS ? my_o : 0);
-        const bool fin = last && my_active && n < p.N;
-        const int64_t oidx = (int64_t) my_m * p.ldy + n;
-        // (1) the next group's epilogue operands, (2) the next tile
-        EpiOps ops_nxt = ops_cur;
-        if (last)
-            ops_nxt = load_ops(g + gstride < a.ngroups ? g + gstride : g);
-        if (t_issue < ntiles)
-        {
-            if (ci_i == 0)
-                rows_of_group(g0 + gi_i * gstride, rowptr);
-            load_tile(rowptr, ci_i * U, nxt);
-            ++t_issue;
-            if (++ci_i == tiles_per_group)
-            {
-                ci_i = 0;
-                ++gi_i;
-            }
-        }
-        // (3) dot products of the current tile
-        const int c = ci_p * U;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-        {
-            int k0 = ((c + u) * 64 + lane) * VEC;
-            k0 = k0 < Kp ? k0 : Kp - VEC; // out-of-range lanes: the weight vector is the neutral element
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-            {
-                const char* xr = xs + ((size_t) m * Kp + k0) * XES;
-                if constexpr (WT == W_FP16)
-                {
-                    const uint4 xa = *reinterpret_cast<const uint4*>(xr);
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        acc[r][m] = dot_fp16(cur[u][r], xa, acc[r][m]);
-                }
-                else if constexpr (WT == W_INT8_WOQ)
-                {
-                    const uint4 xa = *reinterpret_cast<const uint4*>(xr);
-                    const uint4 xb = *reinterpret_cast<const uint4*>(xr + 16);
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        acc[r][m] = dot_woq8(cur[u][r], xa, xb, acc[r][m]);
-                }
-                else if constexpr (WT == W_INT4_WOQ)
-                {
-                    const uint4* xp = reinterpret_cast<const uint4*>(xr);
-                    const uint4 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                    {
-                        float tt = acc[r][m];
-                        tt = dot_u4x8(cur[u][r].x, x0, tt);
-                        tt = dot_u4x8(cur[u][r].y, x1, tt);
-                        tt = dot_u4x8(cur[u][r].z, x2, tt);
-                        tt = dot_u4x8(cur[u][r].w, x3, tt);
-                        acc[r][m] = tt;
-                    }
-                }
-                else
-                {
-                    const uint4 xa = *reinterpret_cast<const uint4*>(xr);
-#pragma unroll
-                    for (int r = 0; r < R; ++r)
-                        acc[r][m] = dot_sq(cur[u][r], xa, acc[r][m]);
-                }
-            }
-        }
-        if (!last)
-        {
-            ++ci_p;
-            return;
-        }
-        ci_p = 0;
-        ++gi_p;
-        // (4) cross-lane reduction (every lane gets every total), then lane (o * MB + m) finishes output o of row m
-        float v0 = 0.f, v1 = 0.f;
-        int ai = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-            {
-                const acc_t tot = wave_sum(acc[r][m]);
-                acc[r][m] = 0;
-                if (r < NOUTS && lane == r * MB + m)
-                {
-                    ai = (int) tot;
-                    v0 = (float) tot;
-                }
-                if (SWIGLU && r == 1 && lane == m)
-                    v1 = (float) tot;
-            }
-        const EpiOps e = ops_cur;
-        ops_cur = ops_nxt;
-        if (!fin)
-            return;
-        const float r0 = v0 * (e.s0 * my_row_scale);
-        if constexpr (SWIGLU)
-        {
-            const float o16 = silu_mul_fp16(r0, v1 * (e.s1 * my_row_scale_up));
-            if (p.epi == EPI_SWIGLU)
-                reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(o16);
-            else
-                reinterpret_cast<int8_t*>(p.y)[oidx] = f2i8_rni_sat(o16 * epi_q);
-        }
-        else
-        {
-            if (p.epi == EPI_RESIDUAL)
-                reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(h2f(f2h(r0)) + e.res);
-            else if (p.out_dtype == DT_HALF)
-                reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(r0);
-            else if (p.out_dtype == DT_FLOAT)
-                reinterpret_cast<float*>(p.y)[oidx] = r0;
-            else
-                reinterpret_cast<int32_t*>(p.y)[oidx] = SQ ? ai : (int32_t) r0;
-        }
-    };
-
-    for (int t = 0; t < ntiles;)
-    {
-        step(wv, wv2);
-        if (++t >= ntiles)
-            break;
-        step(wv2, wv);
-        ++t;
-    }
-}
-
-template <int WT, int PK, int EK, int MB>
-int launch_inst(const GemvArgs& a, hipStream_t stream)
-{
-    auto kfn = gemv_kernel<WT, PK, EK, MB>;
-    const size_t smem = kRedBytes + (size_t) MB * a.Kp * (WT == W_INT8_SQ ? 1 : 2);
-    if (smem > 160 * 1024)
-    {
-        set_error("gemv: K=%d x M=%d does not fit LDS", a.p.K, a.p.M);
-        return -1;
-    }
-    static bool attr_done = false;
-    if (smem > 64 * 1024 && !attr_done)
-    {
-        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    // persistent grid: no more workgroups than the chip holds at once, every wave the same number of row groups
-    static int cus = 0;
-    static std::map<size_t, int> occ_cache;
-    if (!cus)
-    {
-        int dev = 0;
-        (void) hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
-    auto it = occ_cache.find(smem);
-    if (it == occ_cache.end())
-    {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 256, smem) != hipSuccess || nb < 1)
-            nb = 2;
-        it = occ_cache.emplace(smem, nb > 8 ? 8 : nb).first;
-    }
-    int blocks = (a.ngroups + 3) / 4;
-    const int max_blocks = cus * (gemv_tune_blocks_per_cu > 0 ? gemv_tune_blocks_per_cu : it->second);
-    if (blocks > max_blocks)
-    {
-        const int waves = max_blocks * 4;
-        const int groups_per_wave = (a.ngroups + waves - 1) / waves;
-        blocks = (a.ngroups + 4 * groups_per_wave - 1) / (4 * groups_per_wave);
-    }
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), smem, stream, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
-    {
-        set_error("gemv launch failed: %s", hipGetErrorString(e));
-        return -1;
-    }
-    return 0;
-}
-
-template <int WT, int PK, int EK>
-int launch_mb(const GemvArgs& a, hipStream_t stream)
-{
-    if (a.p.M <= 1)
-        return launch_inst<WT, PK, EK, 1>(a, stream);
-    if (a.p.M <= 2)
-        return launch_inst<WT, PK, EK, 2>(a, stream);
-    if (a.p.M <= 4)
-        return launch_inst<WT, PK, EK, 4>(a, stream);
-    return launch_inst<WT, PK, EK, 8>(a, stream);
-}
-
-template <int WT>
-int launch_wt(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream)
-{
-    constexpr bool SQ = WT == W_INT8_SQ;
-    if (swiglu)
-    {
-        switch (pk)
-        {
-        case PK_COPY: return launch_mb<WT, PK_COPY, EK_SWIGLU>(a, stream);
-        case PK_NORM: return launch_mb<WT, PK_NORM, EK_SWIGLU>(a, stream);
-        default: break;
-        }
-        set_error("gemv: SwiGLU epilogue is built with the copy / RMSNorm prologues only");
-        return -1;
-    }
-    switch (pk)
-    {
-    case PK_COPY: return launch_mb<WT, PK_COPY, EK_PLAIN>(a, stream);
-    case PK_NORM: return launch_mb<WT, PK_NORM, EK_PLAIN>(a, stream);
-    case PK_QUANT:
-        if constexpr (SQ)
-            return launch_mb<WT, PK_QUANT, EK_PLAIN>(a, stream);
-        break;
-    case PK_ATTN: return launch_mb<WT, PK_ATTN, EK_PLAIN>(a, stream);
-    default: break;
-    }
-    set_error("gemv: unsupported prologue for this weight type");
-    return -1;
-}
-
-} // namespace
 
 int launch_gemv(const GemvParams& p, hipStream_t stream)
 {
@@ -831,9 +70,9 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     // activations: 16-byte vectors kept in registers by 256 threads
     const bool raw_s8 = sq && p.pro == PRO_NONE;
     const int xvec = raw_s8 ? 16 : 8;
-    if ((p.K % xvec) || p.K > 256 * xvec * kNXV)
+    if ((p.K % xvec) || p.K > 256 * xvec * kNXVMax)
     {
-        set_error("gemv: K=%d must be a multiple of %d and <= %d", p.K, xvec, 256 * xvec * kNXV);
+        set_error("gemv: K=%d must be a multiple of %d and <= %d", p.K, xvec, 256 * xvec * kNXVMax);
         return -1;
     }
     if (pk != PK_ATTN && ((reinterpret_cast<uintptr_t>(p.x) & 15) || ((p.ldx * (raw_s8 ? 1 : 2)) & 15)))
@@ -858,10 +97,10 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     a.ngroups = swiglu ? p.N : (p.N + R - 1) / R;
     switch (p.wtype)
     {
-    case W_FP16: return launch_wt<W_FP16>(a, pk, swiglu, stream);
-    case W_INT8_WOQ: return launch_wt<W_INT8_WOQ>(a, pk, swiglu, stream);
-    case W_INT4_WOQ: return launch_wt<W_INT4_WOQ>(a, pk, swiglu, stream);
-    default: return launch_wt<W_INT8_SQ>(a, pk, swiglu, stream);
+    case W_FP16: return launch_gemv_fp16(a, pk, swiglu, stream);
+    case W_INT8_WOQ: return launch_gemv_woq8(a, pk, swiglu, stream);
+    case W_INT4_WOQ: return launch_gemv_woq4(a, pk, swiglu, stream);
+    default: return launch_gemv_sq(a, pk, swiglu, stream);
     }
 }
 

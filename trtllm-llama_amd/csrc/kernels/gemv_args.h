@@ -1,0 +1,50 @@
+// Shared between the GEMV dispatcher (gemv.hip) and the per-weight-type kernel translation units (gemv_impl.h).
+#pragma once
+#include "kernels.h"
+#include <hip/hip_runtime.h>
+
+namespace tllm
+{
+namespace kernels
+{
+namespace gemv_detail
+{
+constexpr int R = 2, U = 4;
+constexpr int kRedBytes = 256;
+constexpr int kNXVMax = 6; // 16-byte x vectors a thread keeps in registers: K <= 256 * 8 * 6 = 12288 halfs
+constexpr int kNXVSmall = 2; // bucket for K <= 4096 halfs (every 7B hidden-size GEMV): 32 fewer VGPRs -> one more wave/SIMD
+
+enum ProKind
+{
+    PK_COPY = 0,  // x already in the operand type
+    PK_NORM = 1,  // RMSNorm (+ quant for SQ)
+    PK_QUANT = 2, // fp16 -> s8 (SQ)
+    PK_ATTN = 3   // split-KV merge (+ quant for SQ)
+};
+enum EpiKind
+{
+    EK_PLAIN = 0, // none | residual
+    EK_SWIGLU = 1 // swiglu (+ static quant)
+};
+
+struct GemvArgs
+{
+    GemvParams p;
+    int32_t Kp;      // K rounded up to the weight vector width
+    int32_t nchunks; // ceil(Kp / (64 * VEC))
+    int32_t ngroups; // row groups (one per wave-step)
+};
+
+} // namespace gemv_detail
+using namespace gemv_detail;
+
+extern int gemv_tune_r;
+extern int gemv_tune_blocks_per_cu;
+
+int launch_gemv_fp16(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
+int launch_gemv_woq8(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
+int launch_gemv_woq4(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
+int launch_gemv_sq(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
+
+} // namespace kernels
+} // namespace tllm
