@@ -129,6 +129,9 @@ int32_t tllm_gemv(const tllm_gemv_params_t* p, tllm_stream_t stream);
 void tllm_gemv_set_rows_per_wave(int32_t r);
 /* Test/bench knob: persistent workgroups per CU (0 = occupancy query). */
 void tllm_gemv_set_blocks_per_cu(int32_t n);
+/* Test/bench knob: tile shape of the LDS-DMA staged MFMA GEMM (0 = heuristic; 1 = 128x128, 2 = 256x256,
+ * 3 = 256x192, 4 = 128x256). */
+void tllm_gemm_set_tile_cfg(int32_t cfg);
 
 /* Kernel-level entry for the prefill GEMMs (kernels/gemm_mfma.hip; M <= 8 goes to the skinny GEMM):
  * C[m,n] = epi(sum_k A[m,k] W[n,k]); wtype / layouts / scales as tllm_gemv_params_t.  Used by the MFMA-utilisation

@@ -33,6 +33,10 @@ __device__ __forceinline__ float h2f(uint16_t bits)
 
 __device__ __forceinline__ uint16_t f2h(float f)
 {
+    // The fp32 value is the contract's rounding point: without the (empty) asm the backend may fold a preceding
+    // fmul into v_fma_mixlo_f16, i.e. round the exact product straight to fp16 - one rounding instead of the
+    // reference's two (fp32 then fp16), 1 ulp off on rare ties (seen in the SmoothQuant GEMM epilogue).
+    asm("" : "+v"(f));
     _Float16 h = (_Float16) f; // v_cvt_f16_f32, round-to-nearest-even
     uint16_t b;
     __builtin_memcpy(&b, &h, 2);

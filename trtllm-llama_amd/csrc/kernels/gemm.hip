@@ -1,6 +1,7 @@
 // GEMM entry point of the Gemm / SmoothQuantGemm / WeightOnlyQuantMatmul plugins.
 //   M <= 8  -> the streaming GEMV (gemv.hip), the decode path;
-//   M  > 8  -> MFMA tiles (gemm_mfma.hip) when the shape is tile-aligned, else 8-row GEMV slabs.
+//   M  > 8  -> MFMA tiles: LDS-DMA staged (gemm_glds.hip: SQ / fp16, K-bytes % 128 == 0), else register staged with
+//              in-flight dequantisation (gemm_mfma.hip: weight-only types, odd K), else 8-row GEMV slabs.
 #include "kernels.h"
 
 namespace tllm
@@ -9,6 +10,7 @@ namespace kernels
 {
 
 int launch_gemm_mfma(const GemmParams& p, hipStream_t stream); // gemm_mfma.hip; returns 1 when the shape is unsupported
+int launch_gemm_glds(const GemmParams& p, hipStream_t stream); // gemm_glds.hip (SQ / fp16, LDS-DMA staged); same convention
 
 static int gemv_slab(const GemmParams& p, int m0, int rows, hipStream_t stream)
 {
@@ -41,7 +43,10 @@ int launch_gemm(const GemmParams& p, hipStream_t stream)
         return 0;
     if (p.M > 8)
     {
-        const int r = launch_gemm_mfma(p, stream);
+        int r = launch_gemm_glds(p, stream);
+        if (r <= 0)
+            return r;
+        r = launch_gemm_mfma(p, stream);
         if (r <= 0)
             return r;
     }

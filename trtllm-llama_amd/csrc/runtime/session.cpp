@@ -39,6 +39,7 @@ namespace kernels
 {
 extern int gemv_tune_r;
 extern int gemv_tune_blocks_per_cu;
+extern int gemm_tune_cfg;
 }
 } // namespace tllm
 
@@ -1317,6 +1318,11 @@ void tllm_gemv_set_rows_per_wave(int32_t r)
 void tllm_gemv_set_blocks_per_cu(int32_t n)
 {
     tllm::kernels::gemv_tune_blocks_per_cu = n;
+}
+
+void tllm_gemm_set_tile_cfg(int32_t cfg)
+{
+    tllm::kernels::gemm_tune_cfg = cfg;
 }
 
 } // extern "C"

@@ -26,6 +26,23 @@ struct Case
     int wtype, pro, epi, out_dtype, N, K;
 };
 
+// xorshift-style hash per 32-bit word; mode 1 = two fp16 values with exponent clamped to [2^-3, 2) (sign random)
+__global__ void fill_rand(uint32_t* p, size_t n, uint32_t seed, int fp16_mode)
+{
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+    {
+        uint32_t x = (uint32_t) i * 2654435761u ^ seed;
+        x ^= x >> 16;
+        x *= 0x7feb352du;
+        x ^= x >> 15;
+        x *= 0x846ca68bu;
+        x ^= x >> 16;
+        if (fp16_mode)
+            x = (x & 0x83ff83ffu) | 0x30003000u | ((x >> 3) & 0x0c000c00u); // exponent field 12..15 -> 2^-3 .. 2^0
+        p[i] = x;
+    }
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1)
@@ -95,17 +112,34 @@ int main(int argc, char** argv)
     {
         // prefill-shaped GEMMs: M = 1024, the four LLaMA-7B layer shapes
         struct GC { const char* name; int wtype, N, K; };
-        std::vector<GC> gcs = {{"sq   qkv ", 3, 3 * D, D}, {"sq   o   ", 3, D, D}, {"sq   fc  ", 3, I, D}, {"sq   down", 3, D, I},
-                               {"fp16 qkv ", 0, 3 * D, D}, {"fp16 fc  ", 0, I, D}, {"fp16 down", 0, D, I},
+        std::vector<GC> gcs = {{"sq   qkv ", 3, 3 * D, D}, {"sq   o   ", 3, D, D}, {"sq   fc  ", 3, I, D}, {"sq   fc|g", 3, 2 * I, D},
+                               {"sq   down", 3, D, I}, {"fp16 qkv ", 0, 3 * D, D}, {"fp16 fc  ", 0, I, D}, {"fp16 down", 0, D, I},
                                {"woq8 qkv ", 1, 3 * D, D}, {"woq4 qkv ", 2, 3 * D, D}};
         const int Mg = argc > 4 ? atoi(argv[4]) : 1024;
         void *a, *c;
         CK(hipMalloc(&a, (size_t) Mg * I * 2));
         CK(hipMemset(a, 0x3c, (size_t) Mg * I * 2));
-        CK(hipMalloc(&c, (size_t) Mg * 3 * D * 4));
-        printf("%-12s %6s %9s %10s %9s\n", "gemm", "M", "us", "TOP/s", "frac_peak");
+        CK(hipMalloc(&c, (size_t) Mg * 2 * I * 4));
+        // uniform random operand bytes (power / clocks depend on the data: zero or constant operands run ~19 % faster,
+        // MI355X_MICROARCH.md; quote the random-data number).  fp16 operands: random mantissa, exponent kept small.
+        hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, st, (uint32_t*) pool, pool_bytes / 4, 0x9e3779b9u, 0);
+        hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, st, (uint32_t*) a, (size_t) Mg * I * 2 / 4, 0x85ebca6bu, 0);
+        const int cfg_lo = argc > 5 ? atoi(argv[5]) : 0, cfg_hi = argc > 6 ? atoi(argv[6]) : cfg_lo;
+        printf("%-12s %4s %6s %9s %10s %9s\n", "gemm", "cfg", "M", "us", "TOP/s", "frac_peak");
+        for (int cfg = cfg_lo; cfg <= cfg_hi; ++cfg)
         for (auto& g : gcs)
         {
+            if (cfg > 0 && g.wtype != 3 && g.wtype != 0)
+                continue;
+            tllm_gemm_set_tile_cfg(cfg);
+            if (g.wtype == 0 || g.wtype == 1 || g.wtype == 2) // fp16 activations: keep exponents sane (|x| < 2)
+                hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, st, (uint32_t*) a, (size_t) Mg * I * 2 / 4, 0x85ebca6bu, 1);
+            else
+                hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, st, (uint32_t*) a, (size_t) Mg * I * 2 / 4, 0x85ebca6bu, 0);
+            if (g.wtype == 0)
+                hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, st, (uint32_t*) pool, (size_t) g.N * g.K * 2 / 4, 0x9e3779b9u, 1);
+            else
+                hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, st, (uint32_t*) pool, (size_t) g.N * g.K / 4, 0x9e3779b9u, 0);
             tllm_gemm_params_t q;
             memset(&q, 0, sizeof(q));
             q.wtype = g.wtype;
@@ -140,7 +174,7 @@ int main(int argc, char** argv)
             const double us = ms * 1e3 / iters;
             const double tops = 2.0 * Mg * g.N * g.K / us / 1e6;
             const double peak = g.wtype == 3 ? 5000.0 : 2500.0; // dense int8 / fp16 MFMA peaks, TOP/s (MI355X_MICROARCH.md)
-            printf("%-12s %6d %9.2f %10.1f %9.3f\n", g.name, Mg, us, tops, tops / peak);
+            printf("%-12s %4d %6d %9.2f %10.1f %9.3f\n", g.name, cfg, Mg, us, tops, tops / peak);
         }
         return 0;
     }
