@@ -195,6 +195,41 @@ def test_gemm_fp16(m, n, k):
     np.testing.assert_allclose(as_f32(out), O.gemm_fp16(as_f32(x), as_f32(w)), rtol=2e-3, atol=2e-3)
 
 
+# ---------------------------------------------------------------------------------------------- prefill GEMM tiles
+@pytest.mark.parametrize('cfg', list(range(1, 13)))
+def test_prefill_gemm_every_tile_shape(cfg):
+    """Every tile shape of the LDS-DMA staged MFMA GEMM (kernels/gemm_glds.hip; tllm_gemm_set_tile_cfg) on a problem
+    with ragged M / N edges and several K-tiles: SmoothQuant exact (int32 accumulation is order-independent, the
+    epilogue is float(acc) * (s_col * s_row) -> fp16), fp16 within the fp16 GEMM tolerance."""
+    lib = capi.load_library()
+    lib.tllm_gemm_set_tile_cfg.argtypes = [__import__('ctypes').c_int32]
+    lib.tllm_gemm_set_tile_cfg.restype = None
+    lib.tllm_gemm_set_tile_cfg(cfg)
+    try:
+        torch.manual_seed(cfg)
+        m, n, k = 300, 456, 1152
+        a = torch.randint(-128, 128, (m, k), dtype=torch.int8)
+        w = torch.randint(-128, 128, (n, k), dtype=torch.int8)
+        sa = (torch.randint(1, 13, (m, 1)).float() * 1e-2)
+        sb = (torch.randint(1, 13, (1, n)).float() * 1e-2)
+        for out_dtype, tcode, tdt in (('float16', capi.HALF, torch.float16), ('int32', capi.INT32, torch.int32)):
+            p = make_plugin('SmoothQuantGemm', [('has_per_channel_scaling', i32(1)), ('has_per_token_scaling', i32(1)),
+                                                ('type_id', i32([tcode]))])
+            out = torch.empty((m, n), dtype=tdt, device='cuda')
+            run_plugin(p, [a.cuda(), w.cuda(), sa.cuda(), sb.cuda()], [out])
+            ref = O.sq_gemm(a.numpy(), w.numpy(), sa.numpy(), sb.numpy(), out_dtype)
+            got = out.cpu().numpy() if out_dtype == 'int32' else as_f32(out)
+            np.testing.assert_array_equal(got, ref)
+        r = rng(40 + cfg)
+        x, wf = h(r.standard_normal((m, 320))), h(r.standard_normal((n, 320)) / np.sqrt(320))
+        p = make_plugin('Gemm', [('transa', i32(0)), ('transb', i32(1)), ('type_id', i32([capi.HALF]))])
+        out = torch.empty((m, n), dtype=torch.float16, device='cuda')
+        run_plugin(p, [x, wf], [out])
+        np.testing.assert_allclose(as_f32(out), O.gemm_fp16(as_f32(x), as_f32(wf)), rtol=2e-3, atol=2e-3)
+    finally:
+        lib.tllm_gemm_set_tile_cfg(0)
+
+
 # ---------------------------------------------------------------------------------------------- attention
 def attention_plugin(H, Dh, int8_kv, rot=None, neox=1):
     return make_plugin('GPTAttention', [
@@ -297,7 +332,7 @@ def test_kv_cache_append_bit_exact(int8_kv):
 
 
 @pytest.mark.parametrize('int8_kv', [0, 1])
-@pytest.mark.parametrize('H,Dh,S', [(4, 128, 90), (2, 32, 128), (4, 64, 33)])
+@pytest.mark.parametrize('H,Dh,S', [(4, 128, 90), (2, 32, 128), (4, 64, 33), (4, 128, 300), (2, 64, 257), (2, 128, 1024)])
 def test_context_attention_vs_oracle(int8_kv, H, Dh, S):
     r = rng(200 + S)
     B, smax = 2, S + 8

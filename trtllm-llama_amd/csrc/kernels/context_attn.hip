@@ -5,8 +5,9 @@
 // int8 quant), cuBLAS QK^T (fp32 out), invokeMaskedSoftmax, cuBLAS PV, invokeTransposeQKV.
 // Here: (1) one pass applies RoPE to q,k in place in the packed QKV buffer (the reference rewrites it too,
 // K/unfusedAttentionKernels.cu:1401-1403) and writes RoPE'd K and raw V into the cache [B,2,H,Smax,Dh]
-// (int8: sat(rni(x * s)); padded rows are written as zero); (2) a flash-style pass — one wave per query row,
-// online softmax, no score matrix — reads K/V straight from the packed buffer (L2-resident per head).
+// (int8: sat(rni(x * s)); padded rows are written as zero); (2) a flash-style pass, online softmax, no score matrix:
+// MFMA tiles for head sizes 64 / 128 when the caller provides the V^T scratch (see context_attn_mfma_kernel), else
+// one wave per query row reading K/V straight from the packed buffer.
 // Numerics as the decode kernel: fp32 dot / softmax / accumulation, probabilities rounded to fp16, one
 // rounding to fp16 at the end; keys j > i or j >= input_len[b] are excluded (the reference adds -10000, whose
 // exp underflows to the same 0).
@@ -246,11 +247,276 @@ __global__ __launch_bounds__(256) void context_attn_kernel(const ContextAttnPara
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// MFMA (flash-style) context attention, DH in {64, 128}  (SURVEY 8f rank 3).
+//
+// Workgroup = 4 waves = 128 consecutive queries of one (batch, head); wave w owns 32 of them.  Keys / values advance in
+// blocks of 64.  Operand roles are chosen so that everything the softmax needs is lane-local:
+//   S^T[key, q]  = K[key, :] . Q^T[:, q]     MFMA 32x32x16 f16:  A = K rows (LDS), B = Q (registers, loaded once)
+//       -> lane (q = lane & 31, half = lane >> 5) holds 2 x 16 scores of ITS query: row max / sum are in-register plus
+//          one exchange with lane ^ 32; the running max, the rescale factor and 1/l are per-lane scalars;
+//   O^T[d, q]   += V^T[d, keys] . P^T[keys, q]:                  A = V^T rows (LDS), B = P^T = the score registers
+//          converted to fp16 in place - no LDS round trip for P.
+// The C-layout of S^T puts MFMA row m = 8a + 4*half + c in register 4a + c; feeding K row pi(m) (pi swaps bits 2 and 3)
+// to MFMA row m makes register r of half h hold key 16 (r >> 3) + 8 h + (r & 7): exactly the 8 consecutive keys the
+// B operand of the PV product wants, and the V^T fragment is one 16-byte LDS read.
+// V^T comes from a scratch the transpose kernel below fills ([B, H, DH, Spad] fp16, keys contiguous), so both tiles
+// are 128-byte-row images staged by LDS-DMA exactly like the GEMM's (gemm_glds.hip), double-buffered.
+// Numerics: fp32 scores / softmax / accumulation, probabilities rounded to fp16 for the PV product, normaliser
+// 1 / (l + 1e-6), one rounding of the result to fp16 - the same rounding points as the wave-per-query kernel above
+// (online softmax over 64-key blocks instead of 16-key ones).
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void glds16(const void* gptr, uint32_t lds_byte)
+{
+    // inline asm on purpose: see gemm_glds.hip (the builtin makes hipcc drain the DMA before the next ds_read)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
+}
+
+__device__ __forceinline__ int swz128(int row, int c16)
+{
+    return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4);
+}
+
+// V [B, S, 3*H*DH] (the v part of the packed QKV buffer) -> V^T scratch [B, H, DH, spad]; keys >= S are zero.
+// grid (spad / 64, H, B), 256 threads.
+template <int DH>
+__global__ __launch_bounds__(256) void v_transpose_kernel(const ContextAttnParams p, int spad)
+{
+    constexpr int PITCH = DH + 2; // halfs; odd number of dwords -> the column reads below are conflict-free
+    __shared__ uint16_t tile[64 * PITCH];
+    const int kv0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int H = p.num_heads, S = p.seq;
+    const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.qkv) + (int64_t) b * S * 3 * H * DH + (int64_t) (2 * H + h) * DH;
+    constexpr int CPR = DH / 8; // 16-byte pieces per key row
+    for (int i = threadIdx.x; i < 64 * CPR; i += 256)
+    {
+        const int key = i / CPR, c = i % CPR;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (kv0 + key < S)
+            v = *reinterpret_cast<const uint4*>(vb + (int64_t) (kv0 + key) * 3 * H * DH + c * 8);
+        uint32_t* d = reinterpret_cast<uint32_t*>(tile + key * PITCH + c * 8);
+        d[0] = v.x;
+        d[1] = v.y;
+        d[2] = v.z;
+        d[3] = v.w;
+    }
+    __syncthreads();
+    uint16_t* vt = reinterpret_cast<uint16_t*>(p.workspace) + ((int64_t) (b * H + h) * DH) * spad + kv0;
+    for (int i = threadIdx.x; i < DH * 8; i += 256)
+    {
+        const int d = i % DH, g = i / DH; // 8 keys g * 8 .. + 8 of column d
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w[j] = (uint32_t) tile[(g * 8 + 2 * j) * PITCH + d] | ((uint32_t) tile[(g * 8 + 2 * j + 1) * PITCH + d] << 16);
+        *reinterpret_cast<uint4*>(vt + (int64_t) d * spad + g * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// grid (ceil(S / 128), H, B), 256 threads; heavy (late) query blocks first.
+template <int DH>
+__global__ __launch_bounds__(256) void context_attn_mfma_kernel(const ContextAttnParams p, int spad)
+{
+    constexpr int NSUB = DH / 64;              // 128-byte sub-tiles of a K row
+    constexpr int KST = DH / 16;               // k-steps of the QK product
+    constexpr int DT = DH / 32;                // 32-row tiles of O^T / V^T
+    constexpr int K_BYTES = 64 * DH * 2;       // K tile  [NSUB][64][128 B]
+    constexpr int STAGE = K_BYTES + DH * 128;  // + V^T tile [DH][128 B]
+    constexpr int CHUNKS = STAGE / 1024, CPW = CHUNKS / 4;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qb = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int H = p.num_heads, S = p.seq;
+    const int q0 = qb * 128 + wid * 32; // first query of this wave
+    const int ql = lane & 31, hf = lane >> 5;
+    const int q = q0 + ql;
+    const int len = p.input_lengths[b];
+    const int64_t rs = (int64_t) 3 * H * DH * 2; // bytes per token row of the packed QKV buffer
+    const char* qkv = reinterpret_cast<const char*>(p.qkv) + (int64_t) b * S * rs;
+    const char* vt = reinterpret_cast<const char*>(p.workspace) + ((int64_t) (b * H + h) * DH) * spad * 2;
+
+    // Q fragments (B operand): lane (q, half) holds d = 16 s + 8 half .. + 8 for every k-step s
+    uint4 qf[KST];
+    {
+        const char* qrow = qkv + (int64_t) (q < S ? q : S - 1) * rs + (int64_t) h * DH * 2;
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+            qf[s] = *reinterpret_cast<const uint4*>(qrow + (16 * s + 8 * hf) * 2);
+    }
+
+    const int kv_end = (qb * 128 + 128 < S ? qb * 128 + 128 : S); // causal: keys <= the block's last query
+    const int nkb = (kv_end + 63) / 64;
+    const uint32_t lds_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void*) lds;
+    auto issue = [&](int t) {
+        const int kv0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < CPW; ++i)
+        {
+            const int c = i * 4 + wid;
+            const int r8 = lane >> 3;
+            const char* src;
+            if (c < 8 * NSUB)
+            {
+                const int sub = c / 8, row = (c % 8) * 8 + r8;
+                const int col = (lane & 7) ^ ((row >> 1) & 7);
+                const int key = kv0 + row < S ? kv0 + row : S - 1;
+                src = qkv + (int64_t) key * rs + (int64_t) (H + h) * DH * 2 + sub * 128 + col * 16;
+            }
+            else
+            {
+                const int d = (c - 8 * NSUB) * 8 + r8;
+                const int col = (lane & 7) ^ ((d >> 1) & 7);
+                src = vt + ((int64_t) d * spad + kv0) * 2 + col * 16;
+            }
+            glds16(src, lds_base + (t & 1) * STAGE + c * 1024);
+        }
+    };
+
+    f32x16_t oacc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            oacc[i][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int krow = (ql & ~12) | ((ql & 4) << 1) | ((ql & 8) >> 1); // pi(ql): bits 2 and 3 swapped
+
+    issue(0);
+    for (int t = 0; t < nkb; ++t)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nkb)
+            issue(t + 1);
+        const int kv0 = t * 64;
+        if (kv0 > q0 + 31) // every key of this block is in the future of every query of this wave (wave-uniform)
+            continue;
+        const char* Ks = lds + (t & 1) * STAGE;
+        const char* Vs = Ks + K_BYTES;
+        f32x16_t sacc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sacc[nt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+        {
+            f16x8_t bq;
+            __builtin_memcpy(&bq, &qf[s], 16);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+            {
+                const uint4 kk = *reinterpret_cast<const uint4*>(
+                    Ks + (s >> 2) * (64 * 128) + swz128(nt * 32 + krow, (2 * s + hf) & 7));
+                f16x8_t ak;
+                __builtin_memcpy(&ak, &kk, 16);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ak, bq, sacc[nt], 0, 0, 0);
+            }
+        }
+        // scale, causal mask, block max
+        float mt = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+            {
+                const int key = kv0 + nt * 32 + 16 * (r >> 3) + 8 * hf + (r & 7);
+                const float v = key <= q ? sacc[nt][r] * p.inv_sqrt_dh : -INFINITY;
+                sacc[nt][r] = v;
+                mt = fmaxf(mt, v);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mn = fmaxf(m, mt);
+        const float alpha = (m == -INFINITY) ? 0.f : __expf(m - mn);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                oacc[i][r] *= alpha;
+        // probabilities -> fp16 B fragments (8 consecutive keys per register octet), PV product
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+        {
+            f16x8_t bp;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                const float sv = sacc[s2 >> 1][8 * (s2 & 1) + j];
+                const float pr = (sv == -INFINITY) ? 0.f : __expf(sv - m);
+                l += pr;
+                bp[j] = (_Float16) pr;
+            }
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+            {
+                const uint4 vv = *reinterpret_cast<const uint4*>(Vs + swz128(i * 32 + ql, 2 * s2 + hf));
+                f16x8_t av;
+                __builtin_memcpy(&av, &vv, 16);
+                oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bp, oacc[i], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise, transpose through LDS, store whole rows.  oacc[i][r]: d = 32 i + 8 (r >> 2) + 4 half + (r & 3)
+    l += __shfl_xor(l, 32, 64);
+    const float inv = (q < len) ? 1.f / (l + 1.e-6f) : 0.f; // padding queries produce zero rows
+    constexpr int PITCH = DH * 2 + 16;
+    __syncthreads(); // every wave is done with the operand stages
+    char* scr = lds + wid * (32 * PITCH);
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+        {
+            const uint32_t w0 = pack_h2(oacc[i][4 * g] * inv, oacc[i][4 * g + 1] * inv);
+            const uint32_t w1 = pack_h2(oacc[i][4 * g + 2] * inv, oacc[i][4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(scr + ql * PITCH + (32 * i + 8 * g + 4 * hf) * 2) = make_uint2(w0, w1);
+        }
+    constexpr int PPR = DH / 8; // 16-byte pieces per output row
+    uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) + (int64_t) b * S * H * DH + (int64_t) h * DH;
+#pragma unroll
+    for (int i = lane; i < 32 * PPR; i += 64)
+    {
+        const int row = i / PPR, pc = i % PPR;
+        const uint4 v = *reinterpret_cast<const uint4*>(scr + row * PITCH + pc * 16);
+        if (q0 + row < S)
+            *reinterpret_cast<uint4*>(outp + (int64_t) (q0 + row) * H * DH + pc * 8) = v;
+    }
+}
+
 template <int DH>
 int launch_dh(const ContextAttnParams& p, hipStream_t stream)
 {
     hipLaunchKernelGGL((rope_kv_write_kernel<DH>), dim3(p.seq, p.num_heads, p.batch), dim3(64), 0, stream, p);
-    hipLaunchKernelGGL((context_attn_kernel<DH>), dim3((p.seq + 3) / 4, p.num_heads, p.batch), dim3(256), 0, stream, p);
+    bool mfma = false;
+    if constexpr (DH == 64 || DH == 128)
+    {
+        if (p.workspace && p.seq >= 64)
+        {
+            mfma = true;
+            const int spad = (p.seq + 63) / 64 * 64;
+            hipLaunchKernelGGL((v_transpose_kernel<DH>), dim3(spad / 64, p.num_heads, p.batch), dim3(256), 0, stream, p, spad);
+            constexpr size_t smem = 2 * (size_t) (64 * DH * 2 + DH * 128);
+            auto kfn = context_attn_mfma_kernel<DH>;
+            static bool attr_done = false;
+            if (!attr_done)
+            {
+                if (smem > 64 * 1024)
+                    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(kfn, dim3((p.seq + 127) / 128, p.num_heads, p.batch), dim3(256), smem, stream, p, spad);
+        }
+    }
+    if (!mfma)
+        hipLaunchKernelGGL((context_attn_kernel<DH>), dim3((p.seq + 3) / 4, p.num_heads, p.batch), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
     {
@@ -261,6 +527,12 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
 }
 
 } // namespace
+
+size_t context_attention_workspace_size(int batch, int num_heads, int head_size, int seq)
+{
+    // V^T scratch of the MFMA path: [B, H, Dh, roundup(S, 64)] fp16
+    return (size_t) batch * num_heads * head_size * ((seq + 63) / 64 * 64) * 2;
+}
 
 int launch_context_attention(const ContextAttnParams& p, hipStream_t stream)
 {

@@ -37,7 +37,6 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BKB = 128; // bytes of K per tile row per K-tile
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -52,28 +51,47 @@ __device__ __forceinline__ void glds16(const void* gptr, uint32_t lds_byte)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
 }
 
+// byte offset of 16-byte piece c16 of tile row `row`: XOR swizzle so that the 16 lanes of a ds_read_b128 phase
+// (16 consecutive rows, same k-piece) hit 16 different 16-byte bank groups
+template <int BKB>
 __device__ __forceinline__ int swz(int row, int c16)
 {
-    return row * BKB + ((c16 ^ ((row >> 1) & 7)) << 4);
+    if constexpr (BKB == 128)
+        return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4);
+    else
+        return row * 64 + ((c16 ^ ((row >> 2) & 3)) << 4);
 }
 
-template <int WT, int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmParams p)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WT, int WM, int WN, int MT, int NT, int KG, int BKB, int S>
+__global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const GemmParams p)
 {
     constexpr bool SQ = WT == W_INT8_SQ;
     constexpr int ES = SQ ? 1 : 2; // bytes per A / W element
-    constexpr int NW = WM * WN, NTHR = 64 * NW;
+    constexpr int NW = WM * WN * KG;              // KG groups of WM x WN waves split the k-steps of every stage
+    constexpr int KSTEPS = BKB / 32 / KG;         // k-steps per stage per group
+    static_assert(KG == 1 || (KG == 2 && BKB == 128 && MT % 2 == 0), "K-groups: 2, on 128-byte stages");
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-    constexpr int ROWS = BM + BN;              // tile rows of [A; W]
-    constexpr int CHUNKS = ROWS / 8;           // 1 KiB DMA instructions per K-tile
-    static_assert(CHUNKS % NW == 0, "tile rows must split evenly over the waves");
-    constexpr int CPW = CHUNKS / NW;           // DMA instructions per wave per K-tile
-    constexpr int BUF = ROWS * BKB;            // bytes per LDS buffer
+    constexpr int ROWS = BM + BN;                 // tile rows of [A; W]
+    constexpr int RPC = 1024 / BKB;               // tile rows per 1 KiB DMA instruction (8 | 16)
+    constexpr int PPR = BKB / 16;                 // 16-byte pieces per row (8 | 4)
+    constexpr int CHUNKS = ROWS / RPC;            // DMA instructions per stage
+    constexpr int CPW = (CHUNKS + NW - 1) / NW;   // ... per wave (the last one may be missing on the high waves)
+    constexpr bool RAGGED = CHUNKS % NW != 0;
+    constexpr int STAGE = ROWS * BKB;             // bytes per LDS stage
+    constexpr int D = S - 1;                      // stages in flight ahead of the one being computed
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform, and the compiler knows it (LDS-DMA base)
-    const int wm = wid / WN, wn = wid % WN;
+    const int kg = wid / (WM * WN), wq = wid % (WM * WN);
+    const int wm = wq / WN, wn = wq % WN;
     // XCD-aware tile order: consecutive workgroup ids go to different XCDs (round-robin dispatch); give each XCD a
     // contiguous range of tiles so that the tiles sharing an A row-panel / W column-panel share an L2
     const int nwg = gridDim.x;
@@ -88,16 +106,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmParam
     const int M = p.M, N = p.N;
     const int ntile = (p.K * ES) / BKB;
 
-    // ---- DMA source addresses: chunk c (8 tile rows) -> lane l: row c * 8 + (l >> 3), LDS slot l & 7
+    // ---- DMA source addresses: chunk c (RPC tile rows) -> lane l: row c * RPC + l / PPR, LDS piece l % PPR
     const char* a_base = reinterpret_cast<const char*>(p.a);
     const char* w_base = reinterpret_cast<const char*>(p.w);
     const char* src[CPW];
+    const bool short_wave = RAGGED && (CPW - 1) * NW + wid >= CHUNKS; // this wave has CPW - 1 DMA instructions
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
     {
-        const int c = i * NW + wid;
-        const int row = c * 8 + (lane >> 3);
-        const int col = (lane & 7) ^ ((row >> 1) & 7);
+        int c = i * NW + wid;
+        c = c < CHUNKS ? c : CHUNKS - 1;
+        const int row = c * RPC + lane / PPR;
+        const int col = BKB == 128 ? (lane & 7) ^ ((row >> 1) & 7) : (lane & 3) ^ ((row >> 2) & 3);
         if (row < BM)
         {
             const int gr = m0 + row < M ? m0 + row : M - 1;
@@ -110,12 +130,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmParam
         }
     }
     const uint32_t lds_base = (uint32_t) (uintptr_t) (lds_void_t*) lds;
-    auto issue = [&](int t, int buf) {
+    auto issue = [&](int t) {
+        const int stg = t % S;
 #pragma unroll
         for (int i = 0; i < CPW; ++i)
         {
             const int c = i * NW + wid;
-            glds16(src[i] + (int64_t) t * BKB, lds_base + buf * BUF + c * 1024);
+            if (!RAGGED || i < CPW - 1 || !short_wave) // wave-uniform
+                glds16(src[i] + (int64_t) t * BKB, lds_base + stg * STAGE + c * 1024);
         }
     };
 
@@ -130,27 +152,39 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmParam
                 acc[i][j][r] = 0;
 
     const int fr = lane & 31, fk = lane >> 5;
-    issue(0, 0);
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+        if (t < ntile)
+            issue(t);
     for (int t = 0; t < ntile; ++t)
     {
-        const int buf = t & 1;
-        // tile t has landed (own DMA: vmcnt(0); everyone's: barrier) and nobody still reads buffer buf ^ 1
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // stage t has landed: own DMA by the counted wait (the D - 1 younger stages stay in flight), everyone's by the
+        // barrier; the same barrier says nobody still reads stage t - 1, whose buffer the next DMA overwrites
+        if (t + D - 1 < ntile)
+        {
+            if (short_wave)
+                wait_vmcnt<(D - 1) * (CPW - 1)>();
+            else
+                wait_vmcnt<(D - 1) * CPW>();
+        }
+        else
+            wait_vmcnt<0>();
         __syncthreads();
-        if (t + 1 < ntile)
-            issue(t + 1, buf ^ 1);
-        const char* As = lds + buf * BUF;
+        if (t + D < ntile)
+            issue(t + D);
+        const char* As = lds + (t % S) * STAGE;
         const char* Bs = As + BM * BKB;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int k2 = 0; k2 < KSTEPS; ++k2)
         {
+            const int ks = kg * KSTEPS + k2;
             uint4 af[MT], bf[NT];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                af[i] = *reinterpret_cast<const uint4*>(As + swz((wm * MT + i) * 32 + fr, ks * 2 + fk));
+                af[i] = *reinterpret_cast<const uint4*>(As + swz<BKB>((wm * MT + i) * 32 + fr, ks * 2 + fk));
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                bf[j] = *reinterpret_cast<const uint4*>(Bs + swz((wn * NT + j) * 32 + fr, ks * 2 + fk));
+                bf[j] = *reinterpret_cast<const uint4*>(Bs + swz<BKB>((wn * NT + j) * 32 + fr, ks * 2 + fk));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -171,6 +205,47 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmParam
                     }
                 }
         }
+    }
+
+    // ---- K-groups: exchange halves through LDS (int32 sums are exact in any order), then group g finalises the
+    // MFMA rows i in [g * MT / 2, (g + 1) * MT / 2)
+    int i_lo = 0, i_hi = MT;
+    if constexpr (KG == 2)
+    {
+        constexpr int HALF = MT / 2;
+        static_assert((size_t) HALF * NT * 16 * 4 * 64 * WM * WN <= (size_t) S * STAGE, "exchange buffer must fit the stages");
+        using elem_t = typename std::conditional<SQ, int, float>::type;
+        elem_t* xch = reinterpret_cast<elem_t*>(lds) + wq * 64 + lane; // [reg][wave-in-group][lane]
+        constexpr int RS = WM * WN * 64;                                // elements per register slot
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+        {
+            // group 1 - g hands its partial sums of the rows that group g finalises
+            __syncthreads();
+            if (kg == 1 - g)
+            {
+#pragma unroll
+                for (int i = 0; i < HALF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            xch[((i * NT + j) * 16 + r) * RS] = acc[g * HALF + i][j][r];
+            }
+            __syncthreads();
+            if (kg == g)
+            {
+#pragma unroll
+                for (int i = 0; i < HALF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[g * HALF + i][j][r] += xch[((i * NT + j) * 16 + r) * RS];
+            }
+        }
+        i_lo = kg * HALF;
+        i_hi = i_lo + HALF;
     }
 
     // ---- epilogue.  acc[i][j][r]: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -197,6 +272,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmParam
 #pragma unroll
         for (int i = 0; i < MT; ++i)
         {
+            if (i < i_lo || i >= i_hi) // wave-uniform (K-groups)
+                continue;
             const int row_base = m0 + (wm * MT + i) * 32;
 #pragma unroll
             for (int j = 0; j < NT; ++j)
@@ -235,7 +312,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmParam
         for (int j = 0; j < NT; ++j)
         {
             const int col = wave_n0 + j * 32 + (lane & 31);
-            if (col >= N)
+            if (col >= N || i < i_lo || i >= i_hi)
                 continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
@@ -271,12 +348,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const GemmParam
         }
 }
 
-template <int WT, int WM, int WN, int MT, int NT>
+template <int WT, int WM, int WN, int MT, int NT, int KG, int BKB, int S>
 int launch_cfg(const GemmParams& p, hipStream_t stream)
 {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-    constexpr size_t smem = 2 * (size_t) (BM + BN) * BKB;
-    auto kfn = gemm_glds_kernel<WT, WM, WN, MT, NT>;
+    constexpr size_t smem = (size_t) S * (BM + BN) * BKB;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static_assert(smem >= (size_t) WM * WN * KG * 32 * (NT * 64 + 16), "epilogue scratch must fit the operand stages");
+    auto kfn = gemm_glds_kernel<WT, WM, WN, MT, NT, KG, BKB, S>;
     static bool attr_done = false;
     if (!attr_done)
     {
@@ -285,7 +364,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream)
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(64 * WM * WN), smem, stream, p);
+    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(64 * WM * WN * KG), smem, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
     {
@@ -295,22 +374,35 @@ int launch_cfg(const GemmParams& p, hipStream_t stream)
     return 0;
 }
 
-// tile shapes: id -> (BM, BN, workgroups resident per CU)
+// production tile shapes: id -> (BM, BN); the ids index launch_wt's table, the other ids there are the measured
+// alternatives kept for the microbench sweep (prefill GEMM)
 struct Shape
 {
-    int id, bm, bn, per_cu;
+    int id, bm, bn;
 };
-constexpr Shape kShapes[] = {{1, 128, 128, 2}, {2, 256, 256, 1}, {3, 256, 192, 1}, {4, 128, 256, 1}};
+constexpr Shape kShapes[] = {{8, 128, 128}, {6, 256, 192}, {2, 256, 256}, {4, 128, 256}};
+constexpr int kNumCfg = 12;
 
 template <int WT>
 int launch_wt(const GemmParams& p, int cfg, hipStream_t stream)
 {
     switch (cfg)
     {
-    case 1: return launch_cfg<WT, 2, 2, 2, 2>(p, stream);
-    case 2: return launch_cfg<WT, 2, 4, 4, 2>(p, stream);
-    case 3: return launch_cfg<WT, 4, 2, 2, 3>(p, stream);
-    default: return launch_cfg<WT, 2, 2, 2, 4>(p, stream);
+    // production shapes:        waves  MFMA tiles  BKB stages
+    case 1: return launch_cfg<WT, 2, 2, 2, 2, 1, 64, 4>(p, stream);  // 128 x 128, 64 KB  -> 2 workgroups per CU
+    case 2: return launch_cfg<WT, 2, 4, 4, 2, 1, 64, 4>(p, stream);  // 256 x 256, 128 KB
+    case 3: return launch_cfg<WT, 4, 2, 2, 3, 1, 64, 5>(p, stream);  // 256 x 192, 140 KB
+    case 4: return launch_cfg<WT, 2, 2, 2, 4, 1, 64, 4>(p, stream);  // 128 x 256, 96 KB
+    // experiments
+    case 5: return launch_cfg<WT, 2, 2, 2, 2, 1, 128, 2>(p, stream); // 128 x 128, one stage ahead
+    case 6: // 256 x 192, one stage ahead
+        return launch_cfg<WT, 4, 2, 2, 3, 1, 128, 2>(p, stream);
+    case 7: return launch_cfg<WT, 2, 4, 2, 1, 1, 64, 4>(p, stream);  // 128 x 128 on 8 waves
+    case 8: return launch_cfg<WT, 2, 2, 2, 2, 1, 128, 4>(p, stream); // 128 x 128, 128-byte stages, 3 ahead (1 per CU)
+    case 9: return launch_cfg<WT, 2, 2, 4, 3, 1, 128, 2>(p, stream); // 256 x 192 on 4 waves (128 x 96 per wave)
+    case 10: return launch_cfg<WT, 2, 2, 4, 4, 1, 128, 2>(p, stream); // 256 x 256 on 4 waves (128 x 128 per wave)
+    case 11: return launch_cfg<WT, 2, 2, 4, 3, 2, 128, 2>(p, stream); // 256 x 192, 2 K-groups of 4 waves (128 x 96 per wave)
+    default: return launch_cfg<WT, 2, 2, 2, 2, 2, 128, 2>(p, stream);  // 128 x 128, 2 K-groups of 4 waves (64 x 64 per wave)
     }
 }
 
@@ -324,12 +416,12 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
         return 1;
     const int es = sq ? 1 : 2;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || ((p.lda * es) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)
-        || (p.ldw & 15) || ((p.K * es) % BKB) || p.K <= 0 || p.M < 32)
+        || (p.ldw & 15) || ((p.K * es) % 128) || p.K <= 0 || p.M < 32)
         return 1;
     if (!sq && p.out_dtype == DT_INT32)
         return 1;
     int cfg = gemm_tune_cfg;
-    if (cfg <= 0 || cfg > 4)
+    if (cfg <= 0 || cfg > kNumCfg)
     {
         // fewest workgroup rounds over 256 CUs, then the largest tile (fewest operand re-reads through L2)
         static int cus = 0;
@@ -345,7 +437,7 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
         {
             const int64_t tiles = (int64_t) ((p.M + s.bm - 1) / s.bm) * ((p.N + s.bn - 1) / s.bn);
             // time ~ tiles on the busiest CU x tile area; the small tile pays ~15 % for its lower MFMA : LDS ratio
-            const double cost = (double) ((tiles + cus - 1) / cus) * s.bm * s.bn * (s.id == 1 ? 1.15 : 1.0);
+            const double cost = (double) ((tiles + cus - 1) / cus) * s.bm * s.bn * (s.bm * s.bn == 128 * 128 ? 1.15 : 1.0);
             if (cost < best)
             {
                 best = cost;

@@ -189,7 +189,9 @@ struct ContextAttnParams
     const float* rope_table = nullptr;
     int32_t rope_table_len = 0;
     void* out = nullptr; // fp16 [B, S, H*Dh]; rows >= input_len[b] are zero
+    void* workspace = nullptr; // context_attention_workspace_size() bytes; NULL -> the (slow) wave-per-query kernel
 };
+size_t context_attention_workspace_size(int batch, int num_heads, int head_size, int seq);
 int launch_context_attention(const ContextAttnParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
@@ -209,6 +211,7 @@ struct GemmParams
     int32_t per_channel = 0, per_token = 0;
     void* c = nullptr;
     int64_t ldc = 0;
+    int32_t debug = 0; // microbench only: 1 = no DMA after the prologue, 2 = no waits / barriers (results invalid)
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 

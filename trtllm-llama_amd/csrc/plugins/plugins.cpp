@@ -196,7 +196,10 @@ public:
     {
         const int B = in[0].dims.d[0];
         const int Smax = in[1].dims.d[3];
-        return mmha_workspace_size(B, c.num_heads, c.head_size, Smax) + 256;
+        // max(context, generation), like the reference (gptAttentionPlugin.cpp:132-144)
+        const size_t gen = mmha_workspace_size(B, c.num_heads, c.head_size, Smax) + 256;
+        const size_t ctx = context_attention_workspace_size(B, c.num_heads, c.head_size, in[0].dims.d[1]) + 256;
+        return gen > ctx ? gen : ctx;
     }
 
     int enqueue(const Desc* inDesc, const Desc* outDesc, const void* const* in, void* const* out, void* ws,
@@ -256,6 +259,7 @@ public:
             p.rope_table = table;
             p.rope_table_len = table_len;
             p.out = out[0];
+            p.workspace = ws; // V^T scratch of the MFMA path (NULL -> wave-per-query kernel)
             return launch_context_attention(p, stream) ? 1 : 0;
         }
         if (S != 1)

@@ -160,6 +160,7 @@ struct tllm_session
     float* logits_local = nullptr;
     void* last_hidden = nullptr;
     void* mmha_ws = nullptr;
+    void* ctx_ws = nullptr; // V^T scratch of the MFMA context attention
     int32_t *ids_in = nullptr, *cur_ids = nullptr, *out_ids = nullptr, *seq_len = nullptr, *in_len = nullptr,
             *masked = nullptr, *finished = nullptr, *last_tok = nullptr;
     const float* rope = nullptr;
@@ -478,6 +479,7 @@ struct tllm_session
             c.rope_table = rope;
             c.rope_table_len = rope_len;
             c.out = ctx;
+            c.workspace = ctx_ws;
             RUN(launch_context_attention(c, st));
             const void* d_in = ctx;
             if (sq)
@@ -922,6 +924,7 @@ int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_inp
     RUN(s->dalloc(&s->logits_local, (size_t) B * s->Vr * 4));
     RUN(s->dalloc(&s->logits, (size_t) B * s->Vr * s->tp * 4));
     RUN(s->dalloc(&s->last_hidden, (size_t) B * D * 2));
+    RUN(s->dalloc(&s->ctx_ws, context_attention_workspace_size(B, s->Hr, s->Dh, S) + 256));
     RUN(s->dalloc(&s->mmha_ws, mmha_workspace_size(B, s->Hr, s->Dh, Smax) + 256));
     HIP_OK(hipMemset(s->mmha_ws, 0, mmha_workspace_size(B, s->Hr, s->Dh, Smax) + 256));
     RUN(s->dalloc(&s->ids_in, M * 4));

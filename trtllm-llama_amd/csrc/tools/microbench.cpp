@@ -131,7 +131,7 @@ int main(int argc, char** argv)
         {
             if (cfg > 0 && g.wtype != 3 && g.wtype != 0)
                 continue;
-            tllm_gemm_set_tile_cfg(cfg);
+            tllm_gemm_set_tile_cfg(cfg | (getenv("MB_GEMM_DBG") ? atoi(getenv("MB_GEMM_DBG")) << 8 : 0));
             if (g.wtype == 0 || g.wtype == 1 || g.wtype == 2) // fp16 activations: keep exponents sane (|x| < 2)
                 hipLaunchKernelGGL(fill_rand, dim3(4096), dim3(256), 0, st, (uint32_t*) a, (size_t) Mg * I * 2 / 4, 0x85ebca6bu, 1);
             else
