@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--context', type=int, default=1024)
     ap.add_argument('--layers', type=int, default=32, help='debug only: fewer layers (the result line says so)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prefill', dest='prefill', action='store_false', help='skip the prefill (TTFT) and SQ-GEMM MFMA reports')
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
     ap.add_argument('--cpu-tokens', type=int, default=0, help='CPU-baseline decode steps (0 = sized to ~20 s)')
     ap.add_argument('--cpu-threads', type=int, default=0)
@@ -160,10 +161,70 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     sbytes = {'sq': 4, 'woq8': 2, 'woq4': 2, 'fp16': 0}[mode]  # per-output-channel scale
     # gate|up GEMV, algorithmic HBM bytes per launch: both weight matrices + their scales + x + gamma + the output row
     res['gate_up_bytes'] = 2 * Ir * D * wbytes + 2 * Ir * sbytes + D * 2 + D * 2 + Ir * (1 if mode == 'sq' else 2)
+    # time-to-first-token: the real context phase (MFMA GEMMs + flash attention + KV write) on a random 1024-token
+    # prompt - reported beside the decode metric, not part of it
+    if args.prefill and mode == args.config:
+        import numpy as np
+        ids = np.random.default_rng(1).integers(3, cfg['vocab_size'], (1, args.context)).astype(np.int32)
+        lens = np.array([args.context], np.int32)
+        sess.context(ids, lens, stream=stream)  # warm-up
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            sess.context(ids, lens, stream=stream)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        res['prefill_ms'] = min(ts) * 1e3
     sess.close()
     del weights
     torch.cuda.empty_cache()
     return res
+
+
+def sq_gemm_mfma_report(torch, dev, M=1024):
+    """BASELINE.json's second target: the SmoothQuant GEMM at the prefill shapes (M = 1024) as
+    a fraction of the dense int8 MFMA peak (5 POP/s).  Random int8 operands (constant operands clock ~19 % higher and
+    flatter the number), 20 launches per shape timed with one event pair on torch's current stream."""
+    import ctypes
+
+    from tensorrt_llm.plugin import capi
+    lib = capi.load_library()
+
+    class GemmParams(ctypes.Structure):
+        _fields_ = [('wtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32), ('M', ctypes.c_int32), ('N', ctypes.c_int32),
+                    ('K', ctypes.c_int32), ('a', ctypes.c_void_p), ('lda', ctypes.c_int64), ('w', ctypes.c_void_p),
+                    ('ldw', ctypes.c_int64), ('scale_col', ctypes.c_void_p), ('scale_row', ctypes.c_void_p),
+                    ('per_channel', ctypes.c_int32), ('per_token', ctypes.c_int32), ('c', ctypes.c_void_p),
+                    ('ldc', ctypes.c_int64)]
+
+    lib.tllm_gemm.argtypes = [ctypes.POINTER(GemmParams), ctypes.c_void_p]
+    lib.tllm_gemm.restype = ctypes.c_int32
+    D, I = LLAMA_7B['hidden_size'], LLAMA_7B['inter_size']
+    shapes = {'qkv': (3 * D, D), 'o_proj': (D, D), 'gate_or_up': (I, D), 'down': (D, I)}
+    out = {}
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, (N, K) in shapes.items():
+        a = torch.randint(-128, 128, (M, K), dtype=torch.int8, device=dev)
+        w = torch.randint(-128, 128, (N, K), dtype=torch.int8, device=dev)
+        sc = torch.full((N, ), 1e-3, dtype=torch.float32, device=dev)
+        sr = torch.full((M, ), 1e-2, dtype=torch.float32, device=dev)
+        c = torch.empty((M, N), dtype=torch.float16, device=dev)
+        q = GemmParams(3, 1, M, N, K, a.data_ptr(), K, w.data_ptr(), K, sc.data_ptr(), sr.data_ptr(), 1, 1, c.data_ptr(), N)
+        for _ in range(3):
+            if lib.tllm_gemm(ctypes.byref(q), stream):
+                raise RuntimeError(capi.last_error())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 20
+        e0.record()
+        for _ in range(iters):
+            lib.tllm_gemm(ctypes.byref(q), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        tops = 2.0 * M * N * K / us / 1e6
+        out[name] = {'M': M, 'N': N, 'K': K, 'us': us, 'TOP/s': tops, 'frac_of_5POPs': tops / 5000.0}
+    return out
 
 
 def _default_cpu_threads():
@@ -350,6 +411,14 @@ def main():
                  'profile_ms_per_step': {k: v[0] / prof_steps for k, v in prof.items()},
                  'launches_per_step': {k: v[1] / prof_steps for k, v in prof.items()}},
     }
+    if 'prefill_ms' in res:
+        line['prefill'] = {'context': args.context, 'ms': res['prefill_ms'],
+                           'prompt_tokens_per_s': args.context / (res['prefill_ms'] * 1e-3)}
+    if args.prefill and args.config == 'sq' and world == 1:
+        try:
+            line['sq_gemm_mfma'] = sq_gemm_mfma_report(torch, dev)
+        except Exception as e:  # the decode metric must not depend on the side report
+            line['sq_gemm_mfma'] = {'error': repr(e)}
     if fp16 is not None:
         line['fp16_tokens_per_s'] = fp16['tokens_per_s']
         line['int8_over_fp16'] = res['tokens_per_s'] / fp16['tokens_per_s']
