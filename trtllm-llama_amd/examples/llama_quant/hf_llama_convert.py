@@ -1,0 +1,192 @@
+"""HF LLaMA checkpoint -> FT-format directory with optional int8-KV-cache scales and SmoothQuant int8 weights
+(T/examples/llama_quant/hf_llama_convert.py; same command line, same output files).
+
+    python hf_llama_convert.py -i <hf dir> -o <out dir> -tp 1 -sq 0.5 --calibrate-kv-cache -t float16
+
+What differs from the reference, on purpose:
+  * activation statistics of q/k/v are taken from q_proj, k_proj and v_proj each (the reference reuses q_proj's for
+    all three, hf_llama_convert.py:332-344) and calibration runs once (the reference runs it twice or three times,
+    :292-303);
+  * SmoothQuant is APPLIED: the smoother of the QKV / gate|up inputs is folded into the preceding RMSNorm weight, the
+    smoother of the o_proj / down_proj inputs into the rows of v_proj / up_proj that produce those channels (exact:
+    attention output is linear in V, the SwiGLU product is linear in `up`).  The reference computes the smoothers,
+    rescales the activation ranges, and never touches the weights (its smooth_gemm works on temporary copies);
+  * calibration data: `--calib-ids file.npy` (int token ids [n, L]) or seeded random prompts; the lambada download of the
+    reference is used only when `--dataset-cache-dir` is given and `datasets` can load it offline;
+  * runs on CPU when there is no GPU.
+"""
+import argparse
+import configparser
+import dataclasses
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from convert import split_and_save_weight
+from smoothquant import capture_activation_range, smooth_gemm
+
+
+@dataclasses.dataclass(frozen=True)
+class ProgArgs:
+    out_dir: str
+    in_file: str
+    tensor_parallelism: int = 1
+    processes: int = 2
+    calibrate_kv_cache: bool = False
+    smoothquant: float = None
+    model: str = 'llama'
+    storage_type: str = 'float16'
+    dataset_cache_dir: str = None
+    calib_ids: str = None
+    calib_samples: int = 32
+    calib_len: int = 512
+
+    @staticmethod
+    def parse(args=None) -> 'ProgArgs':
+        p = argparse.ArgumentParser(formatter_class=argparse.RawTextHelpFormatter)
+        p.add_argument('--out-dir', '-o', type=str, required=True, help='file name of output directory')
+        p.add_argument('--in-file', '-i', type=str, required=True, help='HF checkpoint directory')
+        p.add_argument('--tensor-parallelism', '-tp', type=int, default=1, help='Requested tensor parallelism for inference')
+        p.add_argument('--processes', '-p', type=int, default=2, help='(kept for command-line compatibility; conversion is serial)')
+        p.add_argument('--calibrate-kv-cache', '-kv', action='store_true',
+                       help='Generate scaling factors for KV cache. Used for storing KV cache in int8.')
+        p.add_argument('--smoothquant', '-sq', type=float, default=None,
+                       help='Set the alpha parameter (see https://arxiv.org/pdf/2211.10438.pdf) to Smoothquant the model, '
+                       'and output int8 weights. A good first try is 0.5. Must be in [0, 1]')
+        p.add_argument('--model', default='llama', type=str)
+        p.add_argument('--storage-type', '-t', type=str, default='float16', choices=['float32', 'float16'])
+        p.add_argument('--dataset-cache-dir', type=str, default=None, help='cache dir to load the hugging face dataset (lambada)')
+        p.add_argument('--calib-ids', type=str, default=None, help='.npy of int token ids [n, L] used for calibration')
+        p.add_argument('--calib-samples', type=int, default=32)
+        p.add_argument('--calib-len', type=int, default=512)
+        return ProgArgs(**vars(p.parse_args(args)))
+
+
+def calibration_samples(args: ProgArgs, vocab_size: int):
+    """Token-id prompts for the activation statistics."""
+    if args.calib_ids:
+        ids = np.load(args.calib_ids)
+        return [torch.from_numpy(np.asarray(r, dtype=np.int64))[None, :] for r in ids]
+    if args.dataset_cache_dir:
+        try:
+            from datasets import load_dataset
+            from transformers import LlamaTokenizer
+            ds = load_dataset('lambada', split='validation', cache_dir=args.dataset_cache_dir)
+            tok = LlamaTokenizer.from_pretrained(args.in_file)
+            return [tok(ds[i]['text'], return_tensors='pt', max_length=args.calib_len, truncation=True).input_ids
+                    for i in range(min(512, len(ds)))]
+        except Exception as e:  # offline box: fall through to the synthetic prompts
+            print(f'[hf_llama_convert] lambada unavailable ({e!r}); calibrating on seeded random prompts')
+    g = torch.Generator().manual_seed(0)
+    L = min(args.calib_len, 512)
+    return [torch.randint(3, vocab_size, (1, L), generator=g) for _ in range(args.calib_samples)]
+
+
+@torch.no_grad()
+def smooth_llama_model(sd, act_range, alpha, num_layers, num_heads, num_kv_heads):
+    """Apply SmoothQuant to the float32 state dict `sd` in place and keep `act_range` consistent with it."""
+    assert num_kv_heads == num_heads, 'folding the o_proj smoother into v_proj needs one V head per Q head'
+    for l in range(num_layers):
+        p = f'model.layers.{l}.'
+        q, k, v, o = (sd[p + f'self_attn.{n}_proj.weight'] for n in 'qkvo')
+        gate, up, down = (sd[p + f'mlp.{n}_proj.weight'] for n in ('gate', 'up', 'down'))
+        # QKV input <- input_layernorm
+        s = smooth_gemm([q, k, v], act_range[p + 'self_attn.q_proj']['x'], sd[p + 'input_layernorm.weight'], None, alpha)
+        for n in 'qkv':
+            act_range[p + f'self_attn.{n}_proj']['x'] = act_range[p + f'self_attn.{n}_proj']['x'] / s.float()
+        # gate / up input <- post_attention_layernorm
+        s = smooth_gemm([gate, up], act_range[p + 'mlp.gate_proj']['x'], sd[p + 'post_attention_layernorm.weight'], None, alpha)
+        for n in ('gate', 'up'):
+            act_range[p + f'mlp.{n}_proj']['x'] = act_range[p + f'mlp.{n}_proj']['x'] / s.float()
+        # o_proj input = attention output, linear in V: channel j <- row j of v_proj
+        s = smooth_gemm([o], act_range[p + 'self_attn.o_proj']['x'], None, None, alpha)
+        v.div_(s.to(v.dtype).view(-1, 1))
+        act_range[p + 'self_attn.o_proj']['x'] = act_range[p + 'self_attn.o_proj']['x'] / s.float()
+        act_range[p + 'self_attn.v_proj']['y'] = act_range[p + 'self_attn.v_proj']['y'] / s.float()
+        # down_proj input = silu(gate) * up, linear in up: channel j <- row j of up_proj
+        s = smooth_gemm([down], act_range[p + 'mlp.down_proj']['x'], None, None, alpha)
+        up.div_(s.to(up.dtype).view(-1, 1))
+        act_range[p + 'mlp.down_proj']['x'] = act_range[p + 'mlp.down_proj']['x'] / s.float()
+        act_range[p + 'mlp.up_proj']['y'] = act_range[p + 'mlp.up_proj']['y'] / s.float()
+        # weight ranges (per output channel) of the modified matrices
+        for n, w in (('self_attn.q_proj', q), ('self_attn.k_proj', k), ('self_attn.v_proj', v), ('self_attn.o_proj', o),
+                     ('mlp.gate_proj', gate), ('mlp.up_proj', up), ('mlp.down_proj', down)):
+            act_range[p + n]['w'] = w.abs().clip(1e-8, None).amax(dim=1).float()
+
+
+@torch.no_grad()
+def hf_llama_converter(args: ProgArgs):
+    from transformers import LlamaForCausalLM
+    infer_tp = args.tensor_parallelism
+    saved_dir = Path(args.out_dir) / f'{infer_tp}-gpu'
+    saved_dir.mkdir(parents=True, exist_ok=True)
+    device = 'cuda' if torch.cuda.is_available() else 'cpu'
+    model = LlamaForCausalLM.from_pretrained(args.in_file, torch_dtype=torch.float32).to(device).eval()
+    hf_config = vars(model.config)
+    num_layers = hf_config['num_hidden_layers']
+    num_heads = hf_config['num_attention_heads']
+    num_kv_heads = hf_config.get('num_key_value_heads') or num_heads
+    multi_query_mode = False
+
+    int8_outputs = None
+    if args.calibrate_kv_cache:
+        int8_outputs = 'kv_cache_only'
+    if args.smoothquant is not None:
+        int8_outputs = 'all'
+    act_range = {}
+    if int8_outputs is not None:
+        act_range = capture_activation_range(model, calibration_samples(args, hf_config['vocab_size']), num_samples=512)
+        act_range = {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in act_range.items()}
+
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    if args.smoothquant is not None:
+        smooth_llama_model(sd, act_range, args.smoothquant, num_layers, num_heads, num_kv_heads)
+
+    config = configparser.ConfigParser()
+    config['llama'] = {}
+    for key in vars(args):
+        config['llama'][key] = f'{vars(args)[key]}'
+    for k, v in hf_config.items():
+        config['llama'][k] = f'{v}'.replace('%', '%%')
+    config['llama']['storage_dtype'] = args.storage_type
+    config['llama']['multi_query_mode'] = str(multi_query_mode)
+    with open(saved_dir / 'config.ini', 'w') as f:
+        config.write(f)
+
+    storage = np.float16 if args.storage_type == 'float16' else np.float32
+    cfg = {'int8_outputs': int8_outputs, 'multi_query_mode': multi_query_mode}
+    npw = lambda name: sd[name].numpy()
+    for l in range(num_layers):
+        p = f'model.layers.{l}.'
+        # QKV in FT shape [hidden, 3, out]
+        qkv = np.stack([npw(p + f'self_attn.{n}_proj.weight').T for n in 'qkv'], axis=1)
+        qkv_range = None
+        if act_range:
+            r = [act_range[p + f'self_attn.{n}_proj'] for n in 'qkv']
+            qkv_range = {'x': r[0]['x'], 'y': torch.cat([t['y'] for t in r]), 'w': torch.cat([t['w'] for t in r])}
+        split_and_save_weight(0, saved_dir, infer_tp, p + 'attention.query_key_value.weight', qkv, storage, qkv_range, cfg)
+        for ft, hf in (('attention.dense', 'self_attn.o_proj'), ('mlp.down_proj', 'mlp.down_proj'),
+                       ('mlp.gate_proj', 'mlp.gate_proj'), ('mlp.up_proj', 'mlp.up_proj')):
+            split_and_save_weight(0, saved_dir, infer_tp, p + ft + '.weight', npw(p + hf + '.weight').T, storage,
+                                  act_range.get(p + hf) if act_range else None, cfg)
+        for n in ('input_layernorm', 'post_attention_layernorm'):
+            split_and_save_weight(0, saved_dir, infer_tp, p + n + '.weight', npw(p + n + '.weight'), storage, None, cfg)
+    npw('model.embed_tokens.weight').astype(np.float16).tofile(saved_dir / 'model.wte.weight.bin')
+    npw('model.norm.weight').astype(np.float16).tofile(saved_dir / 'model.final_layernorm.weight.bin')
+    head = sd['lm_head.weight'] if 'lm_head.weight' in sd else sd['model.embed_tokens.weight']
+    head.numpy().astype(np.float16).tofile(saved_dir / 'model.lm_head.weight.bin')
+    return saved_dir
+
+
+def run_conversion(args: ProgArgs):
+    print('\n=============== Arguments ===============')
+    for key, value in vars(args).items():
+        print(f'{key}: {value}')
+    print('========================================')
+    return hf_llama_converter(args)
+
+
+if __name__ == '__main__':
+    run_conversion(ProgArgs.parse())

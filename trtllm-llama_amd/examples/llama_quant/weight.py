@@ -16,6 +16,7 @@ from pathlib import Path
 import numpy as np
 
 import tensorrt_llm
+from tensorrt_llm.parameter import Parameter
 from tensorrt_llm._utils import str_dtype_to_np
 from tensorrt_llm.plugin import capi
 from tensorrt_llm.quantization import QuantMode
@@ -139,23 +140,37 @@ def load_from_ft_llama(tensorrt_llm_llama, dir_path, rank=0, tensor_parallel=1, 
     m.lm_head.weight.value = np.ascontiguousarray(split(head, tensor_parallel, rank))
 
     def set_sq(module, base, out_full, in_full, kind):
-        """kind: 'qkv' | 'col' (output split) | 'row' (input split).  Files hold [in, out] int8 (write_int8)."""
+        """kind: 'qkv' | 'col' (output split) | 'row' (input split).  Files hold [in, out] int8 (convert.py::write_int8);
+        QKV is [in, 3, out / tp] per rank (reference converter) or [in, 3, out] whole (older directories)."""
         suffix = 'int8.col' if per_ch else 'int8'
+        tp = tensor_parallel
         if kind == 'qkv':
-            w = need(f'{base}.weight.{suffix}.bin', [in_full, 3, out_full // 3], np.int8)  # [in, 3, out]
-            w = np.ascontiguousarray(w.transpose(1, 2, 0).reshape(out_full, in_full))  # [3*out, in]
-            w = split_qkv(w, tensor_parallel, rank)
+            w = fromfile(f'{base}.weight.{suffix}.{rank}.bin', [in_full, 3, out_full // 3 // tp], np.int8)
+            if w is not None:
+                w = np.ascontiguousarray(w.transpose(1, 2, 0).reshape(out_full // tp, in_full))  # [3*out/tp, in]
+            else:
+                w = need(f'{base}.weight.{suffix}.bin', [in_full, 3, out_full // 3], np.int8)
+                w = split_qkv(np.ascontiguousarray(w.transpose(1, 2, 0).reshape(out_full, in_full)), tp, rank)
         elif kind == 'col':
-            w = need(f'{base}.weight.{suffix}.{rank}.bin', [in_full, out_full // tensor_parallel], np.int8).T
+            w = need(f'{base}.weight.{suffix}.{rank}.bin', [in_full, out_full // tp], np.int8).T
         else:
-            w = need(f'{base}.weight.{suffix}.{rank}.bin', [in_full // tensor_parallel, out_full], np.int8).T
+            w = need(f'{base}.weight.{suffix}.{rank}.bin', [in_full // tp, out_full], np.int8).T
         module.weight.value = np.ascontiguousarray(w)
         key = 'scale_w_quant_orig' if per_tok else 'scale_y_accum_quant'
-        if per_ch:
-            if kind == 'qkv':
-                s = need(f'{base}.{key}.col.bin', None, np.float32).reshape(-1, 1)
-                s = split_qkv(s, tensor_parallel, rank).reshape(1, -1)
-            elif kind == 'col':
+        if kind == 'qkv':
+            # one factor per output channel, or ("per tensor") one for each of Q, K and V stored broadcast to [3, out]:
+            # either way the plugin gets a per-channel vector, [1, 3 * out / tp] in (q, k, v) order
+            s = fromfile(f'{base}.{key}.col.{rank}.bin', None, np.float32) if per_ch else None
+            if s is None:
+                s = need(f'{base}.{key}.col.bin' if per_ch else f'{base}.{key}.bin', None, np.float32)
+                s = split(s.reshape(3, -1), tp, rank, dim=1)
+            s = s.reshape(1, -1)
+            if s.shape[1] != out_full // tp:  # a genuinely scalar file
+                s = np.full((1, out_full // tp), s.reshape(-1)[0], np.float32)
+            if tuple(module.per_channel_scale.shape) != s.shape:
+                module.per_channel_scale = Parameter(shape=s.shape, dtype='float32')
+        elif per_ch:
+            if kind == 'col':
                 s = need(f'{base}.{key}.col.{rank}.bin', None, np.float32).reshape(1, -1)
             else:
                 s = need(f'{base}.{key}.col.bin', None, np.float32).reshape(1, -1)
