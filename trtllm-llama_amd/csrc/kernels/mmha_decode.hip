@@ -3,13 +3,20 @@
 // Reference: masked_multihead_attention_kernel, MM/decoderMaskedMultiheadAttentionTemplate.h:1195-2183
 // (one CTA per (head, batch); 32 CTAs at B=1 cannot feed 256 CUs; its multi-block mode, :2019-2181, splits the
 // KV range over gridDim.z CTAs and lets the last CTA to arrive — an atomic counter — rescale and reduce).
-// Here the KV range of every (batch, head) is always split over workgroups of 4 waves (grid = splits x H x B).
+// Here the KV range of every (batch, head) is always split over workgroups of 4 waves (grid = splits x H x B;
+// 256-token splits at the 7B decode shape = 160 workgroups at L ~ 1100).
 // A group of Dh/8 lanes owns one cache row per load instruction (16 B per lane for fp16, 8 B for int8) and
-// keeps NIT rows of K and of V in flight, all requested before anything else is computed; scores with
-// v_dot2_f32_f16 + a DPP sum inside the lane group; an independent softmax partial {max, sum, out[Dh]} per lane
-// group (no cross-group shuffles), merged per workgroup through LDS, published per split, and the last
-// workgroup of a (batch, head) to arrive (agent-scope release / atomic ticket / acquire) merges the splits
-// (flash-decoding) and writes the fp16 context.
+// keeps NIT rows of K and of V in flight, all requested before anything else is computed and with NO branch
+// around any load (out-of-range rows load a clamped address and are dropped by a select: a lane-dependent `if`
+// makes hipcc fence every load with s_waitcnt vmcnt(0) + exec masking); scores with v_dot2_f32_f16 + a DPP sum
+// inside the lane group; the int8 cache is widened with a byte splice to exact integers and the scale is folded
+// into the dot product; an independent softmax partial {max, sum, out[Dh]} per lane group (no cross-group
+// shuffles), merged per workgroup through LDS and published per split as (m, l) + un-normalised fp32 o.
+// The splits of a (batch, head) are merged either by mmha_combine_kernel (plugin path) or, in the fused decode
+// step, by the prologue of the O-projection GEMV (gemv_impl.h, PK_ATTN) - one launch and one HBM round trip
+// less.  (A last-arriver / atomic-ticket merge and a one-workgroup-per-head variant were measured at 23 us and
+// 22-35 us against 7 us for this form and dropped.)  RoPE coefficients come from a 512-byte row the sampler
+// prepared for this step (GreedyParams::rope_row_out), so nothing chases length -> position -> table.
 //
 // Numerics follow SURVEY Appendix A.1: RoPE in fp32 -> fp16; int8 cache store = sat(rni(float(k16) * s)),
 // load = fp16(float(q8) * s^-1); q.k products fp32-accumulated, * inv_sqrt_dh in fp32; masked positions are
