@@ -121,6 +121,40 @@ def test_generate_graph_equals_eager():
     np.testing.assert_array_equal(outs[1][:, S:S + 6], np.stack(want, 1))
 
 
+def test_tp_collectives_inside_the_captured_graph_single_rank():
+    """The tensor-parallel exchange steps (64 all-reduces + 1 all-gather per 7B step) are RCCL calls enqueued on the
+    session's stream and captured into the step's hipGraph.  A 1-GPU box cannot run 2 ranks, but it can run the very
+    same call sequence on a 1-rank communicator (`force_comm`): eager == graph == the run without collectives."""
+    import ctypes
+    from tensorrt_llm.plugin import capi
+    lib = capi.load_library()
+    uid = (ctypes.c_char * 128)()
+    assert lib.tllm_comm_get_unique_id(uid) == 0, capi.last_error()
+    assert lib.tllm_comm_init_rank((ctypes.c_int32 * 1)(0), 1, 0, uid) == 0, capi.last_error()
+    try:
+        t, w = load_tiny()
+        ids, lens = t['ids'], t['input_lengths']
+        B, S = ids.shape
+        outs = {}
+        for name, cfg, graph in (('plain', {}, True), ('comm_eager', {'force_comm': 1}, False), ('comm_graph', {'force_comm': 1}, True)):
+            s = NativeSession(dict(TINY_CFG, quant_mode=0, **cfg))
+            for k, v in w.items():
+                s.set_tensor(k, v)
+            s.finalize()
+            s.setup(B, S, 40)
+            if graph:
+                outs[name] = s.generate(ids, lens, 40, end_id=-1)  # context, 1 eager step, then 32-step graph chunks
+            else:
+                s.context(ids, lens)
+                s.step(39, use_graph=False)
+                outs[name] = s.output_ids()
+            s.close()
+        np.testing.assert_array_equal(outs['comm_eager'], outs['plain'])
+        np.testing.assert_array_equal(outs['comm_graph'], outs['plain'])
+    finally:
+        assert lib.tllm_comm_destroy_all() == 0
+
+
 def synth_model(seed, L=2, H=4, D=256, I=512, V=512):
     r = np.random.default_rng(seed)
     xav = lambda n, k: r.uniform(-1, 1, (n, k)) * np.sqrt(6.0 / (n + k)) * 2

@@ -149,6 +149,7 @@ struct tllm_session
     Linear head;
     bool finalized = false;
     std::vector<int32_t> group;
+    bool force_comm = false; // tests: run the TP collectives on a 1-rank communicator too (RCCL inside the captured graph)
 
     // ---- runtime state (setup)
     int B = 0, max_in = 0, max_new = 0, Smax = 0;
@@ -428,7 +429,7 @@ struct tllm_session
 
     int allreduce(void* buf, int64_t n, hipStream_t st)
     {
-        if (tp == 1)
+        if (tp == 1 && !force_comm)
             return 0;
         return timed(PC_COMM, st, [&] { return comm::all_reduce_sum(group, buf, buf, n, TLLM_HALF, st) ? 1 : 0; });
     }
@@ -542,7 +543,7 @@ struct tllm_session
             nullptr, st);
         gemv_cls = PC_GEMV_LAYER;
         RUN(head_rc);
-        if (tp > 1)
+        if (tp > 1 || force_comm)
         {
             if (comm::all_gather(group, logits_local, logits, (int64_t) B * Vr, TLLM_FLOAT, st))
                 return 1;
@@ -553,7 +554,7 @@ struct tllm_session
     int run_sampler(int advance, hipStream_t st)
     {
         GreedyParams gp;
-        gp.logits = tp > 1 ? logits : logits_local;
+        gp.logits = (tp > 1 || force_comm) ? logits : logits_local;
         gp.batch = B;
         gp.vocab_part = Vr;
         gp.nparts = tp;
@@ -691,6 +692,7 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->rank = geti("tp_rank", 0);
     s->quant_mode = geti("quant_mode", 0);
     s->neox = geti("neox_rotary_style", 1);
+    s->force_comm = geti("force_comm", 0) != 0;
     if (kv.count("rms_norm_eps"))
         s->eps = (float) atof(kv["rms_norm_eps"].c_str());
     if (kv.count("weight_only_precision"))
