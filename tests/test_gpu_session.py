@@ -216,3 +216,40 @@ def test_quantised_paths_vs_oracle(mode, int8_kv):
     fp = QO.run_fp16_model(cfg, w, ids, lens, NEW, feed_ids=out[:, S:S + NEW])[0]
     tol = {'woq8': 0.15, 'woq4': 1.5, 'sq_static': 0.6, 'sq_static_pc': 0.6, 'sq_dyn': 0.4, 'sq_dyn_pc': 0.4}[mode]
     assert np.abs(got[0] - fp[0]).max() < tol * scale + (0.2 * scale if int8_kv else 0)
+
+
+@pytest.mark.parametrize('mode,int8_kv', [('fp16', 0), ('sq_static_pc', 1), ('woq4', 1)])
+def test_one_layer_at_7b_dimensions_vs_oracle(mode, int8_kv):
+    """BASELINE.json's full layer size (D = 4096, 32 heads of 128, I = 11008; the bench configuration is
+    sq_static_pc + int8 KV): one decoder layer + head, context of a ragged batch and 3 generation steps (eager and
+    graph) against the oracle on identical weights and scales.  Exercises the kernels at exactly the shapes bench.py
+    times - 8 KiB GEMV tiles over K = 4096 / 11008, the 256 x 192 / 128 x 128 prefill GEMM tiles need M >= 32 and are
+    covered by test_prefill_gemm_every_tile_shape; here the context GEMMs run at M = 2 * 20."""
+    cfg, w = synth_model(23, L=1, H=32, D=4096, I=11008, V=512)
+    B, S, NEW = 2, 20, 4
+    r = np.random.default_rng(9)
+    ids = r.integers(3, cfg['vocab_size'], (B, S)).astype(np.int32)
+    lens = np.array([S, 13], np.int32)
+    for b in range(B):
+        ids[b, lens[b]:] = 2
+    qmodel = QO.quantise_model(cfg, w, mode, int8_kv, calib_ids=ids, calib_lens=lens)
+    s = NativeSession(dict(cfg, quant_mode=qmodel['quant_mode']))
+    for k, v in qmodel['engine_tensors'].items():
+        s.set_tensor(k, v)
+    s.finalize()
+    s.setup(B, S, NEW)
+    s.context(ids, lens)
+    got = [s.logits()]
+    s.step(1, use_graph=False)
+    got.append(s.logits())
+    s.step(2, use_graph=True)
+    got.append(s.logits())
+    out = s.output_ids()
+    s.close()
+    ref_logits, _ = QO.run_model(qmodel, ids, lens, NEW, feed_ids=out[:, S:S + NEW])
+    scale = max(np.abs(ref_logits[0]).max(), 1.0)
+    sq = mode.startswith('sq')
+    for g, rr in ((got[0], ref_logits[0]), (got[1], ref_logits[1]), (got[2], ref_logits[3])):
+        assert np.isfinite(g).all()
+        np.testing.assert_allclose(g, rr, atol=(8e-2 if sq else 3e-2) * scale)
+        assert np.abs(g - rr).mean() < (1.2e-2 if sq else 5e-3) * scale
