@@ -105,8 +105,7 @@ const char* tllm_last_error(void);
  * (PY/functional.py:2826-2893, PY/quantization/functional.py:12-212, PY/layers/linear.py:13-35).
  * Registered names (P/api/InferPlugin.cpp:153-168 subset):
  *   "GPTAttention", "Gemm", "SmoothQuantGemm", "WeightOnlyQuantMatmul", "QuantizeTensor",
- *   "QuantizePerToken", "AllReduce", "AllGather"
- *   ("LayernormQuantization" is not on the LLaMA path - LLaMA normalises with RMSNorm - and is not registered)
+ *   "QuantizePerToken", "LayernormQuantization", "AllReduce", "AllGather"
  * plus the MI355X additions that the reference composes out of TensorRT pointwise layers:
  *   "Rmsnorm", "RmsnormQuantization", "SwiGLU"
  * Field names / types / defaults are the reference's; an unknown or missing field makes creation

@@ -105,6 +105,35 @@ def test_rmsnorm_quantization(dyn):
         np.testing.assert_allclose(s.cpu().numpy(), so, rtol=1e-2)  # test_smooth_quant_layer_norm.py:110-114
 
 
+@pytest.mark.parametrize('dyn', [0, 1])
+@pytest.mark.parametrize('diff_sq', [0, 1])
+@pytest.mark.parametrize('shape', [(5, 768), (3, 4096), (2, 100)])
+def test_layernorm_quantization(dyn, diff_sq, shape):
+    """The reference's LayernormQuantization plugin (fields eps / use_diff_of_squares / dyn_act_scaling / type_id,
+    inputs x, weight, bias, scale): its own test accepts +-1 LSB (test_smooth_quant_layer_norm.py:103-108)."""
+    r = rng(30 + shape[1])
+    x = h(r.standard_normal(shape) * 2 + 0.5)
+    g = h(1 + 0.1 * r.standard_normal(shape[-1]))
+    b = h(0.1 * r.standard_normal(shape[-1]))
+    scale = torch.tensor([31.0], dtype=torch.float32, device='cuda')
+    p = make_plugin('LayernormQuantization', [('eps', f32(1e-5)), ('use_diff_of_squares', i32([diff_sq])),
+                                               ('dyn_act_scaling', i32([dyn])), ('type_id', i32([capi.HALF]))])
+    q = torch.empty(shape, dtype=torch.int8, device='cuda')
+    outs = [q]
+    if dyn:
+        s = torch.empty(shape[:-1] + (1, ), dtype=torch.float32, device='cuda')
+        outs.append(s)
+    run_plugin(p, [x, g, b, scale], outs)
+    qo, so = O.layernorm_quant(as_f32(x), as_f32(g), as_f32(b), 1e-5, None if dyn else 31.0, bool(diff_sq))
+    d = np.abs(q.cpu().numpy().astype(np.int32) - qo.astype(np.int32))
+    assert d.max() <= 1 and np.mean(d == 0) > 0.98
+    if dyn:
+        np.testing.assert_allclose(s.cpu().numpy(), so, rtol=1e-2)
+    # serialisation round trip keeps the kind
+    p2 = capi.Plugin.deserialize('LayernormQuantization', p.serialize())
+    assert p2 is not None and p2.plugin_type == 'LayernormQuantization' and p2.num_outputs == (2 if dyn else 1)
+
+
 def test_swiglu():
     r = rng(4)
     a, b = h(r.standard_normal((3, 11008)) * 3), h(r.standard_normal((3, 11008)))

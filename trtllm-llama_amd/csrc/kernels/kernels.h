@@ -109,6 +109,9 @@ struct RmsnormParams
     int8_t* q = nullptr;              // optional s8 [M, N]
     const float* static_scale = nullptr; // f32 [1] -> static quant
     float* dyn_scale_out = nullptr;      // f32 [M] -> per-token dynamic quant (amax / 127)
+    // LayerNorm flavour (LayernormQuantization plugin, K/layernormKernels.cu:61-205): y = fp16((x - mean) * rstd * gamma + beta)
+    int32_t layernorm = 0, use_diff_of_squares = 1;
+    const void* beta = nullptr; // fp16 [N]
 };
 int launch_rmsnorm(const RmsnormParams& p, hipStream_t stream);
 

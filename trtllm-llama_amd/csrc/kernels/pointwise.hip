@@ -30,6 +30,8 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f)
 // quant tail: K/layernormKernels.cu:146-183 (normalise -> round to fp16 -> quantise; amax floor 1e-6 in T).
 // One workgroup per row; the row lives in LDS between the passes.
 // ---------------------------------------------------------------------------------------------
+// VEC = 8: 16-byte accesses (N % 8 == 0, 16-byte aligned rows); VEC = 1: any N.
+template <int VEC>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const RmsnormParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -40,34 +42,101 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const RmsnormParams p)
     const uint16_t* res = p.residual ? reinterpret_cast<const uint16_t*>(p.residual) + (int64_t) m * N : nullptr;
     uint16_t* so = p.sum_out ? reinterpret_cast<uint16_t*>(p.sum_out) + (int64_t) m * N : nullptr;
     const uint16_t* g = reinterpret_cast<const uint16_t*>(p.gamma);
+    const uint16_t* be = reinterpret_cast<const uint16_t*>(p.beta);
+    using vec_t = typename std::conditional<VEC == 8, uint4, uint16_t>::type;
+    auto unpack = [](const vec_t& v, uint16_t* e) {
+        if constexpr (VEC == 8)
+        {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                e[2 * j] = (uint16_t) (w[j] & 0xffffu);
+                e[2 * j + 1] = (uint16_t) (w[j] >> 16);
+            }
+        }
+        else
+            e[0] = v;
+    };
+    auto pack = [](const uint16_t* e) {
+        if constexpr (VEC == 8)
+            return make_uint4(e[0] | ((uint32_t) e[1] << 16), e[2] | ((uint32_t) e[3] << 16), e[4] | ((uint32_t) e[5] << 16),
+                e[6] | ((uint32_t) e[7] << 16));
+        else
+            return e[0];
+    };
 
-    float ss = 0.f;
-    for (int k = tid; k < N; k += 256)
+    float ss = 0.f, sum = 0.f;
+    for (int k = tid * VEC; k < N; k += 256 * VEC)
     {
-        uint16_t b = x[k];
+        uint16_t e[VEC], r[VEC];
+        unpack(*reinterpret_cast<const vec_t*>(x + k), e);
         if (res)
         {
-            b = f2h(h2f(b) + h2f(res[k]));
-            so[k] = b;
+            unpack(*reinterpret_cast<const vec_t*>(res + k), r);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)
+                e[j] = f2h(h2f(e[j]) + h2f(r[j]));
+            *reinterpret_cast<vec_t*>(so + k) = pack(e);
         }
-        row[k] = b;
-        const float f = h2f(b);
-        ss += f * f;
+        *reinterpret_cast<vec_t*>(row + k) = pack(e);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+        {
+            const float f = h2f(e[j]);
+            ss += f * f;
+            sum += f;
+        }
     }
-    ss = block_sum(ss, red);
-    const float inv = 1.0f / sqrtf(ss / (float) N + p.eps);
+    float inv, mean = 0.f;
+    if (p.layernorm)
+    {
+        mean = block_sum(sum, red) / (float) N;
+        float var;
+        if (p.use_diff_of_squares)
+            var = block_sum(ss, red) / (float) N - mean * mean;
+        else
+        {
+            float sd = 0.f;
+            for (int k = tid; k < N; k += 256)
+            {
+                const float d = h2f(row[k]) - mean;
+                sd += d * d;
+            }
+            var = block_sum(sd, red) / (float) N;
+        }
+        inv = rsqrtf(fmaxf(var, 0.f) + p.eps);
+    }
+    else
+    {
+        ss = block_sum(ss, red);
+        inv = 1.0f / sqrtf(ss / (float) N + p.eps);
+    }
 
     uint16_t* y = p.y ? reinterpret_cast<uint16_t*>(p.y) + (int64_t) m * N : nullptr;
     int8_t* q = p.q ? p.q + (int64_t) m * N : nullptr;
     float amax = 0.f;
-    for (int k = tid; k < N; k += 256)
+    for (int k = tid * VEC; k < N; k += 256 * VEC)
     {
-        const float n16 = h2f(f2h(h2f(row[k]) * inv));
-        const uint16_t yb = f2h(n16 * h2f(g[k]));
-        row[k] = yb;
+        uint16_t e[VEC], ge[VEC], bb[VEC];
+        unpack(*reinterpret_cast<const vec_t*>(row + k), e);
+        unpack(*reinterpret_cast<const vec_t*>(g + k), ge);
+        if (p.layernorm)
+            unpack(*reinterpret_cast<const vec_t*>(be + k), bb);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+        {
+            uint16_t yb;
+            if (p.layernorm)
+                yb = f2h((h2f(e[j]) - mean) * inv * h2f(ge[j]) + h2f(bb[j])); // one rounding (layernormKernels.cu:146-160)
+            else
+                yb = f2h(h2f(f2h(h2f(e[j]) * inv)) * h2f(ge[j]));
+            e[j] = yb;
+            amax = fmaxf(amax, fabsf(h2f(yb)));
+        }
+        *reinterpret_cast<vec_t*>(row + k) = pack(e);
         if (y)
-            y[k] = yb;
-        amax = fmaxf(amax, fabsf(h2f(yb)));
+            *reinterpret_cast<vec_t*>(y + k) = pack(e);
     }
     if (!q)
         return;
@@ -84,8 +153,24 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const RmsnormParams p)
     {
         qs = p.static_scale[0];
     }
-    for (int k = tid; k < N; k += 256)
-        q[k] = f2i8_rni_sat(h2f(row[k]) * qs);
+    if constexpr (VEC == 8)
+    {
+        for (int k = tid * 8; k < N; k += 256 * 8)
+        {
+            uint16_t e[8];
+            unpack(*reinterpret_cast<const uint4*>(row + k), e);
+            uint32_t o[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j >> 2] |= ((uint32_t) (uint8_t) f2i8_rni_sat(h2f(e[j]) * qs)) << (8 * (j & 3));
+            *reinterpret_cast<uint2*>(q + k) = make_uint2(o[0], o[1]);
+        }
+    }
+    else
+    {
+        for (int k = tid; k < N; k += 256)
+            q[k] = f2i8_rni_sat(h2f(row[k]) * qs);
+    }
 }
 
 // A11 static per-tensor quantiser.  K/quantization.cu:31-64: q = sat(rni(float(x) * scale)).
@@ -142,20 +227,43 @@ __global__ __launch_bounds__(256) void quantize_per_token_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void swiglu_kernel(uint16_t* y, const uint16_t* a, const uint16_t* b, int64_t n)
+// 8 halfs (16 bytes) per thread per iteration when n % 8 == 0 and the pointers are 16-byte aligned (VEC = 8).
+template <int VEC, typename F>
+__device__ __forceinline__ void binary_h16(uint16_t* y, const uint16_t* a, const uint16_t* b, int64_t n, F f)
 {
-    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x * VEC;
+    for (int64_t i = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < n; i += stride)
     {
-        const float g = h2f(a[i]);
-        const float s = h2f(f2h(g / (1.f + __expf(-g))));
-        y[i] = f2h(s * h2f(b[i]));
+        if constexpr (VEC == 8)
+        {
+            const uint4 va = *reinterpret_cast<const uint4*>(a + i), vb = *reinterpret_cast<const uint4*>(b + i);
+            const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = (uint32_t) f((uint16_t) (wa[j] & 0xffffu), (uint16_t) (wb[j] & 0xffffu))
+                    | ((uint32_t) f((uint16_t) (wa[j] >> 16), (uint16_t) (wb[j] >> 16)) << 16);
+            *reinterpret_cast<uint4*>(y + i) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        else
+            y[i] = f(a[i], b[i]);
     }
 }
 
+template <int VEC>
+__global__ __launch_bounds__(256) void swiglu_kernel(uint16_t* y, const uint16_t* a, const uint16_t* b, int64_t n)
+{
+    binary_h16<VEC>(y, a, b, n, [](uint16_t ga, uint16_t ub) {
+        const float g = h2f(ga);
+        const float s = h2f(f2h(g / (1.f + __expf(-g))));
+        return f2h(s * h2f(ub));
+    });
+}
+
+template <int VEC>
 __global__ __launch_bounds__(256) void add_kernel(uint16_t* y, const uint16_t* a, const uint16_t* b, int64_t n)
 {
-    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
-        y[i] = f2h(h2f(a[i]) + h2f(b[i]));
+    binary_h16<VEC>(y, a, b, n, [](uint16_t x, uint16_t z) { return f2h(h2f(x) + h2f(z)); });
 }
 
 __global__ __launch_bounds__(256) void embedding_kernel(
@@ -424,7 +532,18 @@ int launch_rmsnorm(const RmsnormParams& p, hipStream_t stream)
         set_error("rmsnorm: N=%d too large", p.N);
         return -1;
     }
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3(p.M), dim3(256), smem, stream, p);
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec = !(p.N & 7) && al16(p.x) && al16(p.gamma) && al16(p.residual) && al16(p.sum_out) && al16(p.y) && al16(p.beta)
+        && (reinterpret_cast<uintptr_t>(p.q) & 7) == 0;
+    if (p.layernorm && !p.beta)
+    {
+        set_error("layernorm: bias is required");
+        return -1;
+    }
+    if (vec)
+        hipLaunchKernelGGL(rmsnorm_kernel<8>, dim3(p.M), dim3(256), smem, stream, p);
+    else
+        hipLaunchKernelGGL(rmsnorm_kernel<1>, dim3(p.M), dim3(256), smem, stream, p);
     return check_launch("rmsnorm");
 }
 
@@ -466,12 +585,21 @@ int launch_quantize_per_token(int8_t* dst, const void* src, int32_t src_dtype, i
     return check_launch("quantize_per_token");
 }
 
+static bool vec8_ok(int64_t n, const void* y, const void* a, const void* b)
+{
+    return !(n & 7) && !((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15);
+}
+
 int launch_swiglu(void* y, const void* a, const void* b, int64_t n, hipStream_t stream)
 {
     if (n <= 0)
         return 0;
-    hipLaunchKernelGGL(swiglu_kernel, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(y),
-        reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(b), n);
+    if (vec8_ok(n, y, a, b))
+        hipLaunchKernelGGL(swiglu_kernel<8>, dim3(grid_for(n / 8)), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(y),
+            reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(b), n);
+    else
+        hipLaunchKernelGGL(swiglu_kernel<1>, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(y),
+            reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(b), n);
     return check_launch("swiglu");
 }
 
@@ -479,8 +607,12 @@ int launch_add(void* y, const void* a, const void* b, int64_t n, hipStream_t str
 {
     if (n <= 0)
         return 0;
-    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(y),
-        reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(b), n);
+    if (vec8_ok(n, y, a, b))
+        hipLaunchKernelGGL(add_kernel<8>, dim3(grid_for(n / 8)), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(y),
+            reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(b), n);
+    else
+        hipLaunchKernelGGL(add_kernel<1>, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(y),
+            reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(b), n);
     return check_launch("add");
 }
 

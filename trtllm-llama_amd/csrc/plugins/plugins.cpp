@@ -677,11 +677,12 @@ public:
 };
 
 // ================================================================================================
-// Rmsnorm / RmsnormQuantization — the RMSNorm analogue of LayernormQuantization
+// Rmsnorm / RmsnormQuantization / LayernormQuantization — the reference's plugin plus its RMSNorm analogue
 // (P/layernormQuantizationPlugin/layernormQuantizationPlugin.cpp:124-166; SURVEY "fact 1": LLaMA needs RMSNorm).
 //   Rmsnorm:              inputs x fp16 [M.., N], weight fp16 [N]                    -> y fp16
 //   RmsnormQuantization:  inputs x, weight, scale f32 [1] (ignored when dyn_act_scaling)
 //                         -> q s8 [M.., N] (+ f32 [M.., 1] dynamic scales when dyn_act_scaling)
+//   LayernormQuantization: inputs x, weight, bias, scale f32 [1]; fields eps, use_diff_of_squares, dyn_act_scaling, type_id
 // fields: eps f32, (dyn_act_scaling i32,) type_id i32
 // ================================================================================================
 class RmsnormPlugin : public Plugin
@@ -689,6 +690,20 @@ class RmsnormPlugin : public Plugin
 public:
     float eps = 1e-6f;
     int32_t quant = 0, dyn = 0, type_id = TLLM_HALF;
+    int32_t layernorm = 0, diff_of_squares = 1; // LayernormQuantization: inputs x, weight, bias, scale
+    static Plugin* create_layernorm_quant(const Fields& f)
+    {
+        // fields of PY/quantization/functional.py:92-108
+        f.expect_only({"eps", "use_diff_of_squares", "dyn_act_scaling", "type_id"});
+        auto* p = new RmsnormPlugin;
+        p->quant = 1;
+        p->layernorm = 1;
+        p->eps = f.f32("eps");
+        p->diff_of_squares = f.i32("use_diff_of_squares");
+        p->dyn = f.i32("dyn_act_scaling");
+        p->type_id = f.i32("type_id");
+        return check(p);
+    }
     static Plugin* create_plain(const Fields& f)
     {
         f.expect_only({"eps", "type_id"});
@@ -718,22 +733,25 @@ public:
     }
     static Plugin* deserialize_plain(Reader& r) { return deser(r, 0); }
     static Plugin* deserialize_quant(Reader& r) { return deser(r, 1); }
-    static Plugin* deser(Reader& r, int quant)
+    static Plugin* deserialize_layernorm_quant(Reader& r) { return deser(r, 1, 1); }
+    static Plugin* deser(Reader& r, int quant, int layernorm = 0)
     {
         auto* p = new RmsnormPlugin;
         p->eps = r.get<float>();
         p->quant = r.get<int32_t>();
         p->dyn = r.get<int32_t>();
         p->type_id = r.get<int32_t>();
+        p->layernorm = r.get<int32_t>();
+        p->diff_of_squares = r.get<int32_t>();
         r.done();
-        if (p->quant != quant)
+        if (p->quant != quant || p->layernorm != layernorm)
         {
             delete p;
             throw std::runtime_error("Rmsnorm: serialised kind mismatch");
         }
         return p;
     }
-    const char* type() const override { return quant ? "RmsnormQuantization" : "Rmsnorm"; }
+    const char* type() const override { return layernorm ? "LayernormQuantization" : (quant ? "RmsnormQuantization" : "Rmsnorm"); }
     int nbOutputs() const override { return quant && dyn ? 2 : 1; }
     int outputDims(int idx, const Dims* in, int nin, Dims* out) const override
     {
@@ -750,9 +768,10 @@ public:
     {
         if (!linear_fmt(io[pos]))
             return false;
-        if (pos < 2)
+        const int nparam = layernorm ? 3 : 2; // x, weight(, bias)
+        if (pos < nparam)
             return io[pos].type == type_id;
-        if (quant && pos == 2)
+        if (quant && pos == nparam)
             return io[pos].type == TLLM_FLOAT;
         return io[pos].type == outputDtype(pos - nin, nullptr, 0);
     }
@@ -764,6 +783,10 @@ public:
         p.x = in[0];
         p.gamma = in[1];
         p.eps = eps;
+        p.layernorm = layernorm;
+        p.use_diff_of_squares = diff_of_squares;
+        if (layernorm)
+            p.beta = in[2];
         if (!quant)
             p.y = out[0];
         else
@@ -772,7 +795,7 @@ public:
             if (dyn)
                 p.dyn_scale_out = static_cast<float*>(out[1]);
             else
-                p.static_scale = static_cast<const float*>(in[2]);
+                p.static_scale = static_cast<const float*>(in[layernorm ? 3 : 2]);
         }
         return launch_rmsnorm(p, stream) ? 1 : 0;
     }
@@ -782,6 +805,8 @@ public:
         w.put(quant);
         w.put(dyn);
         w.put(type_id);
+        w.put(layernorm);
+        w.put(diff_of_squares);
     }
     Plugin* clone() const override { return new RmsnormPlugin(*this); }
 };
@@ -911,6 +936,7 @@ const std::vector<Creator>& registry()
         {"QuantizePerToken", &QuantizePerTokenPlugin::create, &QuantizePerTokenPlugin::deserialize},
         {"Rmsnorm", &RmsnormPlugin::create_plain, &RmsnormPlugin::deserialize_plain},
         {"RmsnormQuantization", &RmsnormPlugin::create_quant, &RmsnormPlugin::deserialize_quant},
+        {"LayernormQuantization", &RmsnormPlugin::create_layernorm_quant, &RmsnormPlugin::deserialize_layernorm_quant},
         {"SwiGLU", &SwiGLUPlugin::create, &SwiGLUPlugin::deserialize},
         {"AllReduce", &CollectivePlugin::create_ar, &CollectivePlugin::deserialize_ar},
         {"AllGather", &CollectivePlugin::create_ag, &CollectivePlugin::deserialize_ag},
