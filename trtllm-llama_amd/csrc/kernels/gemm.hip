@@ -37,18 +37,39 @@ static int gemv_slab(const GemmParams& p, int m0, int rows, hipStream_t stream)
     return launch_gemv(g, stream);
 }
 
-int launch_gemm(const GemmParams& p, hipStream_t stream)
+int launch_gemm(const GemmParams& pin, hipStream_t stream)
 {
-    if (p.M <= 0)
+    if (pin.M <= 0)
         return 0;
+    if (pin.residual && pin.out_dtype != DT_HALF)
+    {
+        set_error("gemm: the fused residual needs fp16 output");
+        return -1;
+    }
+    if (pin.M > 8)
+    {
+        const int r = launch_gemm_glds(pin, stream); // fuses the residual in its epilogue
+        if (r <= 0)
+            return r;
+    }
+    // the other paths write the plain product; the residual (if any) is added by a pointwise pass afterwards
+    GemmParams p = pin;
+    p.residual = nullptr;
+    if (pin.residual && (pin.ldc != pin.N || pin.residual == pin.c))
+    {
+        set_error("gemm: a strided or in-place residual is only supported by the LDS-DMA kernel (SQ / fp16, K bytes %% 128 == 0, M >= 32)");
+        return -1;
+    }
+    auto finish = [&](int rc) {
+        if (rc == 0 && pin.residual)
+            return launch_add(pin.c, pin.c, pin.residual, (int64_t) pin.M * pin.N, stream);
+        return rc;
+    };
     if (p.M > 8)
     {
-        int r = launch_gemm_glds(p, stream);
+        const int r = launch_gemm_mfma(p, stream);
         if (r <= 0)
-            return r;
-        r = launch_gemm_mfma(p, stream);
-        if (r <= 0)
-            return r;
+            return finish(r);
     }
     for (int m0 = 0; m0 < p.M; m0 += 8)
     {
@@ -56,7 +77,7 @@ int launch_gemm(const GemmParams& p, hipStream_t stream)
         if (gemv_slab(p, m0, rows, stream))
             return -1;
     }
-    return 0;
+    return finish(0);
 }
 
 } // namespace kernels

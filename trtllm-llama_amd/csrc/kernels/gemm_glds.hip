@@ -261,7 +261,8 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
             sc[j] = p.per_channel ? reinterpret_cast<const float*>(p.scale_col)[col < N ? col : N - 1]
                                   : reinterpret_cast<const float*>(p.scale_col)[0];
     }
-    const bool vec_out = p.out_dtype == DT_HALF && !(p.ldc & 7) && !(N & 7) && !(reinterpret_cast<uintptr_t>(p.c) & 15);
+    const bool vec_out = p.out_dtype == DT_HALF && !(p.ldc & 7) && !(N & 7) && !(reinterpret_cast<uintptr_t>(p.c) & 15)
+        && !(reinterpret_cast<uintptr_t>(p.residual) & 15);
     if (vec_out)
     {
         // fp16 rows through a wave-private LDS scratch: [32 rows][NT * 32 halfs], pitch chosen so that the two lane
@@ -298,10 +299,24 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
             for (int s = lane; s < 32 * PIECES; s += 64)
             {
                 const int rr = s / PIECES, pc = s % PIECES;
-                const uint4 v = *reinterpret_cast<const uint4*>(scr + rr * PITCH + pc * 16);
+                uint4 v = *reinterpret_cast<const uint4*>(scr + rr * PITCH + pc * 16);
                 const int grow = row_base + rr, gcol = wave_n0 + pc * 8;
                 if (grow < M && gcol < N)
-                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.c) + (int64_t) grow * p.ldc + gcol) = v;
+                {
+                    const int64_t o = (int64_t) grow * p.ldc + gcol;
+                    if (p.residual)
+                    {
+                        const uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.residual) + o);
+                        const uint32_t a4[4] = {v.x, v.y, v.z, v.w}, b4[4] = {rv.x, rv.y, rv.z, rv.w};
+                        uint32_t o4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o4[e] = (uint32_t) f2h(h2f((uint16_t) (a4[e] & 0xffffu)) + h2f((uint16_t) (b4[e] & 0xffffu)))
+                                | ((uint32_t) f2h(h2f((uint16_t) (a4[e] >> 16)) + h2f((uint16_t) (b4[e] >> 16))) << 16);
+                        v = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+                    }
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.c) + o) = v;
+                }
             }
         }
         return;
@@ -420,6 +435,8 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
         return 1;
     if (!sq && p.out_dtype == DT_INT32)
         return 1;
+    if (p.residual && (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)))
+        return 1; // the fused residual lives in the vector epilogue
     int cfg = gemm_tune_cfg;
     if (cfg <= 0 || cfg > kNumCfg)
     {

@@ -123,6 +123,8 @@ int launch_quantize_per_token(int8_t* dst, const void* src, int32_t src_dtype, i
 
 // A6 standalone SwiGLU: y = fp16(silu(a) * b), a,b fp16 [n].
 int launch_swiglu(void* y, const void* a, const void* b, int64_t n, hipStream_t stream);
+// the same, quantised on the way out: q = sat(rni(float(fp16(silu(a) * b)) * scale[0])) (static per-tensor SmoothQuant)
+int launch_swiglu_quant(int8_t* q, const void* a, const void* b, int64_t n, const float* scale, hipStream_t stream);
 // elementwise fp16 add: y = a + b
 int launch_add(void* y, const void* a, const void* b, int64_t n, hipStream_t stream);
 // A16 embedding gather: out[t, :] = table[ids[t], :] (fp16), ids int32; out-of-range id -> zeros.
@@ -214,7 +216,7 @@ struct GemmParams
     int32_t per_channel = 0, per_token = 0;
     void* c = nullptr;
     int64_t ldc = 0;
-    int32_t debug = 0; // microbench only: 1 = no DMA after the prologue, 2 = no waits / barriers (results invalid)
+    const void* residual = nullptr; // optional fp16 [M, ldc]: C = fp16(fp16(gemm) + residual) (may alias c); fp16 output only
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 

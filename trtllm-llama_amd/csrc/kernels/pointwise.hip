@@ -261,6 +261,36 @@ __global__ __launch_bounds__(256) void swiglu_kernel(uint16_t* y, const uint16_t
 }
 
 template <int VEC>
+__global__ __launch_bounds__(256) void swiglu_quant_kernel(int8_t* q, const uint16_t* a, const uint16_t* b, int64_t n, const float* scale)
+{
+    const float qs = scale[0];
+    const int64_t stride = (int64_t) gridDim.x * blockDim.x * VEC;
+    for (int64_t i = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * VEC; i < n; i += stride)
+    {
+        auto one = [&](uint16_t ga, uint16_t ub) {
+            const float g = h2f(ga);
+            const float s = h2f(f2h(g / (1.f + __expf(-g))));
+            return (uint32_t) (uint8_t) f2i8_rni_sat(h2f(f2h(s * h2f(ub))) * qs);
+        };
+        if constexpr (VEC == 8)
+        {
+            const uint4 va = *reinterpret_cast<const uint4*>(a + i), vb = *reinterpret_cast<const uint4*>(b + i);
+            const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+            uint32_t o[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                o[j >> 1] |= one((uint16_t) (wa[j] & 0xffffu), (uint16_t) (wb[j] & 0xffffu)) << (16 * (j & 1));
+                o[j >> 1] |= one((uint16_t) (wa[j] >> 16), (uint16_t) (wb[j] >> 16)) << (16 * (j & 1) + 8);
+            }
+            *reinterpret_cast<uint2*>(q + i) = make_uint2(o[0], o[1]);
+        }
+        else
+            q[i] = (int8_t) one(a[i], b[i]);
+    }
+}
+
+template <int VEC>
 __global__ __launch_bounds__(256) void add_kernel(uint16_t* y, const uint16_t* a, const uint16_t* b, int64_t n)
 {
     binary_h16<VEC>(y, a, b, n, [](uint16_t x, uint16_t z) { return f2h(h2f(x) + h2f(z)); });
@@ -601,6 +631,19 @@ int launch_swiglu(void* y, const void* a, const void* b, int64_t n, hipStream_t 
         hipLaunchKernelGGL(swiglu_kernel<1>, dim3(grid_for(n)), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(y),
             reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(b), n);
     return check_launch("swiglu");
+}
+
+int launch_swiglu_quant(int8_t* q, const void* a, const void* b, int64_t n, const float* scale, hipStream_t stream)
+{
+    if (n <= 0)
+        return 0;
+    if (!(n & 7) && !((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) && !(reinterpret_cast<uintptr_t>(q) & 7))
+        hipLaunchKernelGGL(swiglu_quant_kernel<8>, dim3(grid_for(n / 8)), dim3(256), 0, stream, q,
+            reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(b), n, scale);
+    else
+        hipLaunchKernelGGL(swiglu_quant_kernel<1>, dim3(grid_for(n)), dim3(256), 0, stream, q,
+            reinterpret_cast<const uint16_t*>(a), reinterpret_cast<const uint16_t*>(b), n, scale);
+    return check_launch("swiglu_quant");
 }
 
 int launch_add(void* y, const void* a, const void* b, int64_t n, hipStream_t stream)

@@ -406,9 +406,10 @@ struct tllm_session
 
     // context: plain GEMM on M rows (activation already in the operand type)
     int gemm(const Linear& L, int M, const void* a, const float* scale_row, int per_tok, void* c, int out_dtype,
-        hipStream_t st)
+        hipStream_t st, const void* residual = nullptr)
     {
         GemmParams g;
+        g.residual = residual;
         g.wtype = L.wtype;
         g.out_dtype = out_dtype;
         g.M = M;
@@ -491,9 +492,20 @@ struct tllm_session
                     RUN(launch_quantize_tensor(q8, ctx, DT_HALF, (int64_t) M * Dr, L.attn_qscale, st));
                 d_in = q8;
             }
-            RUN(gemm(L.dense, M, d_in, sq && per_token ? qscale : nullptr, sq && per_token, tmp, DT_HALF, st));
-            RUN(allreduce(tmp, (int64_t) M * D, st));
-            RUN(launch_add(x, x, tmp, (int64_t) M * D, st));
+            const bool fuse_res = tp == 1 && !force_comm && M >= 32 && (L.dense.wtype == W_INT8_SQ || L.dense.wtype == W_FP16)
+                && (L.dense.K * (L.dense.wtype == W_FP16 ? 2 : 1)) % 128 == 0 && (L.proj.K * (L.proj.wtype == W_FP16 ? 2 : 1)) % 128 == 0
+                && D % 8 == 0;
+            if (fuse_res)
+            {
+                // x <- x + O(ctx): residual fused into the GEMM epilogue (same rounding: fp16(gemm) then fp16(sum))
+                RUN(gemm(L.dense, M, d_in, sq && per_token ? qscale : nullptr, sq && per_token, x, DT_HALF, st, x));
+            }
+            else
+            {
+                RUN(gemm(L.dense, M, d_in, sq && per_token ? qscale : nullptr, sq && per_token, tmp, DT_HALF, st));
+                RUN(allreduce(tmp, (int64_t) M * D, st));
+                RUN(launch_add(x, x, tmp, (int64_t) M * D, st));
+            }
             // --- MLP block
             r = RmsnormParams();
             r.M = M;
@@ -516,19 +528,31 @@ struct tllm_session
             RUN(launch_rmsnorm(r, st));
             RUN(gemm(L.fc, M, a_in, sq && per_token ? qscale : nullptr, sq && per_token, g, DT_HALF, st));
             RUN(gemm(L.gate, M, a_in, sq && per_token ? qscale : nullptr, sq && per_token, u, DT_HALF, st));
-            RUN(launch_swiglu(inter_buf, g, u, (int64_t) M * Ir, st));
             const void* p_in = inter_buf;
-            if (sq)
+            if (sq && !per_token)
             {
-                if (per_token)
-                    RUN(launch_quantize_per_token(q8, inter_buf, DT_HALF, M, Ir, qscale, st));
-                else
-                    RUN(launch_quantize_tensor(q8, inter_buf, DT_HALF, (int64_t) M * Ir, L.mlp_qscale, st));
+                RUN(launch_swiglu_quant(q8, g, u, (int64_t) M * Ir, L.mlp_qscale, st)); // SwiGLU and its quantiser in one pass
                 p_in = q8;
             }
-            RUN(gemm(L.proj, M, p_in, sq && per_token ? qscale : nullptr, sq && per_token, tmp, DT_HALF, st));
-            RUN(allreduce(tmp, (int64_t) M * D, st));
-            RUN(launch_add(x, x, tmp, (int64_t) M * D, st));
+            else
+            {
+                RUN(launch_swiglu(inter_buf, g, u, (int64_t) M * Ir, st));
+                if (sq)
+                {
+                    RUN(launch_quantize_per_token(q8, inter_buf, DT_HALF, M, Ir, qscale, st));
+                    p_in = q8;
+                }
+            }
+            if (fuse_res)
+            {
+                RUN(gemm(L.proj, M, p_in, sq && per_token ? qscale : nullptr, sq && per_token, x, DT_HALF, st, x));
+            }
+            else
+            {
+                RUN(gemm(L.proj, M, p_in, sq && per_token ? qscale : nullptr, sq && per_token, tmp, DT_HALF, st));
+                RUN(allreduce(tmp, (int64_t) M * D, st));
+                RUN(launch_add(x, x, tmp, (int64_t) M * D, st));
+            }
         }
         // head: last real token of every sequence -> ln_f -> lm_head -> fp32 logits  (Q/llama_model.py:272-279)
         RUN(launch_gather_last_token(last_hidden, x, last_tok, B, S, D, st));
