@@ -126,8 +126,6 @@ typedef struct
 } tllm_gemv_params_t;
 
 int32_t tllm_gemv(const tllm_gemv_params_t* p, tllm_stream_t stream);
-/* Test/bench knob: rows of W per wave (0 = heuristic). */
-void tllm_gemv_set_rows_per_wave(int32_t r);
 /* Test/bench knob: persistent workgroups per CU (0 = occupancy query). */
 void tllm_gemv_set_blocks_per_cu(int32_t n);
 /* Test/bench knob: tile shape of the LDS-DMA staged MFMA GEMM (0 = heuristic; 1 = 128x128, 2 = 256x256,

@@ -8,7 +8,6 @@ namespace tllm
 namespace kernels
 {
 
-int gemv_tune_r = 0;             // (kept for the C ABI; the kernel is fixed at 2 rows x 4 chunks per tile)
 int gemv_tune_blocks_per_cu = 0; // test/bench override: persistent workgroups per CU (0 = occupancy query)
 
 int launch_gemv(const GemvParams& p, hipStream_t stream)

@@ -38,7 +38,6 @@ struct GemvArgs
 } // namespace gemv_detail
 using namespace gemv_detail;
 
-extern int gemv_tune_r;
 extern int gemv_tune_blocks_per_cu;
 
 int launch_gemv_fp16(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);

@@ -37,7 +37,6 @@ namespace tllm
 {
 namespace kernels
 {
-extern int gemv_tune_r;
 extern int gemv_tune_blocks_per_cu;
 extern int gemm_tune_cfg;
 }
@@ -1337,11 +1336,6 @@ int32_t tllm_gemm(const tllm_gemm_params_t* q, tllm_stream_t stream)
     g.c = q->c;
     g.ldc = q->ldc;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(stream)) ? 1 : 0;
-}
-
-void tllm_gemv_set_rows_per_wave(int32_t r)
-{
-    tllm::kernels::gemv_tune_r = r;
 }
 
 void tllm_gemv_set_blocks_per_cu(int32_t n)

@@ -1,6 +1,6 @@
 // Kernel sweep harness (GPU box only): times the fused skinny GEMM of the generation step on the LLaMA-7B shapes
 // through the C ABI, rotating over enough weight copies to defeat the 256 MiB Infinity Cache.
-//   build/microbench [rows_per_wave]
+//   build/microbench 0 <blocks_per_cu|0> [<case filter> | gemm [M [cfg_lo [cfg_hi]]]]
 #include "../../../include/tllm_runtime_api.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -45,8 +45,7 @@ __global__ void fill_rand(uint32_t* p, size_t n, uint32_t seed, int fp16_mode)
 
 int main(int argc, char** argv)
 {
-    if (argc > 1)
-        tllm_gemv_set_rows_per_wave(atoi(argv[1]));
+    // argv[1] is unused (kept so that older command lines keep their positions)
     if (argc > 2)
         tllm_gemv_set_blocks_per_cu(atoi(argv[2]));
     const char* only = argc > 3 ? argv[3] : nullptr;

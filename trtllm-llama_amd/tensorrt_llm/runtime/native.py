@@ -57,8 +57,6 @@ def _lib():
     lib.tllm_session_time_kernel.restype = c.c_int32
     lib.tllm_session_destroy.argtypes = [c.c_void_p]
     lib.tllm_session_destroy.restype = None
-    lib.tllm_gemv_set_rows_per_wave.argtypes = [c.c_int32]
-    lib.tllm_gemv_set_rows_per_wave.restype = None
     _bound = True
     return lib
 
