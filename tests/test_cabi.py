@@ -1,0 +1,123 @@
+"""The drop-in boundary without a GPU: the library loads, exports every symbol include/*.h declares, and the host-side
+logic of the plugin contract (registry, field parsing, shape / dtype / format negotiation, serialisation, error
+strings) behaves like the reference's IPluginCreator / IPluginV2DynamicExt.  No compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tensorrt_llm.plugin import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADERS = [os.path.join(ROOT, 'include', h) for h in ('tllm_plugin_api.h', 'tllm_runtime_api.h')]
+
+
+def declared_functions():
+    names = []
+    for h in HEADERS:
+        text = open(h).read()
+        text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)  # comments
+        for m in re.finditer(r'^[A-Za-z_][\w\s\*]*?\b((?:tllm_|initLib|getInfer)\w+)\s*\(', text, flags=re.M):
+            names.append(m.group(1))
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 40 and 'tllm_plugin_enqueue' in names and 'tllm_session_generate' in names \
+        and 'initLibNvInferPlugins' in names
+    lib = ctypes.CDLL(os.path.join(ROOT, 'trtllm-llama_amd', 'tensorrt_llm', 'libs',
+                                   'libnvinfer_plugin_tensorrt_llm.so'), mode=ctypes.RTLD_GLOBAL)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, f'declared in include/*.h but not exported: {missing}'
+
+
+def test_init_is_idempotent_and_registry_lists_the_contract():
+    lib = capi.load_library()
+    assert lib.initLibNvInferPlugins(None, b'tensorrt_llm') and lib.initLibNvInferPlugins(None, b'tensorrt_llm')
+    lib.tllm_plugin_registry_size.restype = ctypes.c_int32
+    lib.tllm_plugin_registry_name.restype = ctypes.c_char_p
+    lib.tllm_plugin_registry_name.argtypes = [ctypes.c_int32]
+    names = {lib.tllm_plugin_registry_name(i).decode() for i in range(lib.tllm_plugin_registry_size())}
+    assert names == {'GPTAttention', 'Gemm', 'SmoothQuantGemm', 'WeightOnlyQuantMatmul', 'QuantizeTensor', 'QuantizePerToken',
+                     'LayernormQuantization', 'Rmsnorm', 'RmsnormQuantization', 'SwiGLU', 'AllReduce', 'AllGather'}
+
+
+i32 = lambda v: np.array(v, dtype=np.int32)
+i8 = lambda v: np.array(v, dtype=np.int8)
+f32 = lambda v: np.array(v, dtype=np.float32)
+
+
+def attention_fields(**over):
+    # names, types and order of T/tensorrt_llm/functional.py:2833-2891
+    f = dict(num_heads=i32(32), head_size=i32(128), unidirectional=i32(1), q_scaling=f32(1.0), rotary_embedding_dim=i32(128),
+             neox_rotary_style=i8(1), context_fmha_type=i8(0), multi_block_mode=i8(0), multi_query_mode=i8(0),
+             int8_kv_cache=i32(1), fp8_kv_cache=i32(0), remove_input_padding=i8(0), mask_type=i32(1), paged_kv_cache=i32(0),
+             type_id=i32(capi.HALF), in_flight_batching=i32(0))
+    f.update(over)
+    return [capi.PluginField(k, v) for k, v in f.items()]
+
+
+def test_creation_contract_missing_unknown_and_unbuilt_fields():
+    assert capi.Plugin.create('GPTAttention', attention_fields()) is not None
+    # wrong version / namespace / name -> no creator
+    assert capi.Plugin.create('GPTAttention', attention_fields(), version='2') is None
+    assert capi.Plugin.create('GPTAttention', attention_fields(), namespace='other') is None
+    assert capi.Plugin.create('NoSuchPlugin', []) is None and 'NoSuchPlugin' in capi.last_error()
+    # missing field -> NULL (reference: std::optional::value() throws, gptAttentionPlugin.cpp:506-510)
+    assert capi.Plugin.create('GPTAttention', attention_fields()[:-1]) is None and 'in_flight_batching' in capi.last_error()
+    # unknown field
+    assert capi.Plugin.create('GPTAttention', attention_fields() + [capi.PluginField('bogus', i32(1))]) is None
+    # options of the contract that are not built are rejected, not ignored
+    for k, v in (('multi_query_mode', i8(1)), ('fp8_kv_cache', i32(1)), ('paged_kv_cache', i32(1)),
+                 ('in_flight_batching', i32(1)), ('remove_input_padding', i8(1))):
+        assert capi.Plugin.create('GPTAttention', attention_fields(**{k: v})) is None, k
+        assert capi.last_error()
+    # head sizes the reference asserts (functional.py:2831)
+    assert capi.Plugin.create('GPTAttention', attention_fields(head_size=i32(100))) is None
+
+
+def test_shape_dtype_format_negotiation_and_serialisation_round_trip():
+    p = capi.Plugin.create('GPTAttention', attention_fields())
+    assert p.plugin_type == 'GPTAttention' and p.num_outputs == 2
+    B, S, H, Dh, Smax = 2, 16, 32, 128, 48
+    shapes = [[B, S, 3 * H * Dh], [B, 2, H, Smax, Dh], [B], [2], [B, Smax], [B], [S], [B, 1, Smax], [1], [1]]
+    assert p.output_dims(0, shapes) == [B, S, H * Dh]       # context
+    assert p.output_dims(1, shapes) == [B, 2, H, Smax, Dh]  # present_key_value has the cache's shape
+    blob = p.serialize()
+    q = capi.Plugin.deserialize('GPTAttention', blob)
+    assert q is not None and q.serialize() == blob and q.clone().serialize() == blob
+    assert capi.Plugin.deserialize('GPTAttention', blob[:-1]) is None  # length is asserted (P/common/plugin.h:90-101)
+    assert capi.Plugin.deserialize('Gemm', blob) is None
+
+    sq = capi.Plugin.create('SmoothQuantGemm', [capi.PluginField('has_per_channel_scaling', i32(1)),
+                                                 capi.PluginField('has_per_token_scaling', i32(1)),
+                                                 capi.PluginField('type_id', i32([capi.HALF]))])
+    assert sq.output_dims(0, [[7, 5, 4096], [12288, 4096], [7, 5, 1], [1, 12288]]) == [7, 5, 12288]
+    # the int8 weight may arrive through an fp32 port [N, K/4] (PY/quantization/layer.py:91-99)
+    assert sq.output_dims(0, [[35, 4096], [12288, 1024], [35, 1], [1, 12288]]) == [35, 12288]
+    woq = capi.Plugin.create('WeightOnlyQuantMatmul', [capi.PluginField('type_id', i32([capi.HALF])),
+                                                        capi.PluginField('weight_type_id', i32(2))])
+    assert woq.output_dims(0, [[3, 4096], [4096, 11008 // 8], [11008]]) == [3, 11008]  # int4: fp32 view [K, N/8]
+    ar = capi.Plugin.create('AllReduce', [capi.PluginField('group', i32([0, 1, 2, 3])), capi.PluginField('type_id', i32([capi.HALF]))])
+    assert ar.output_dims(0, [[4, 4096]]) == [4, 4096] and capi.Plugin.deserialize('AllReduce', ar.serialize()) is not None
+    ag = capi.Plugin.create('AllGather', [capi.PluginField('group', i32([0, 1])), capi.PluginField('type_id', i32([capi.FLOAT]))])
+    assert ag.output_dims(0, [[2, 16000]]) == [2, 2, 16000] or ag.output_dims(0, [[2, 16000]]) == [4, 16000]
+
+
+def test_session_configuration_errors_are_reported_not_fatal():
+    lib = capi.load_library()
+    lib.tllm_session_create.restype = ctypes.c_void_p
+    lib.tllm_session_create.argtypes = [ctypes.c_char_p]
+    assert not lib.tllm_session_create(b'num_layers=2\nnum_heads=3\nhidden_size=64\ninter_size=24\nvocab_size=128\n')
+    assert 'heads' in capi.last_error()
+    assert not lib.tllm_session_create(b'num_layers=2\n') and capi.last_error()
+    h = lib.tllm_session_create(b'num_layers=1\nnum_heads=2\nhidden_size=64\ninter_size=24\nvocab_size=128\ntp_size=2\ntp_rank=1\n')
+    assert h
+    lib.tllm_session_finalize.argtypes = [ctypes.c_void_p]
+    lib.tllm_session_finalize.restype = ctypes.c_int32
+    assert lib.tllm_session_finalize(h) != 0 and 'vocab_embedding' in capi.last_error()  # first missing tensor is named
+    lib.tllm_session_destroy.argtypes = [ctypes.c_void_p]
+    lib.tllm_session_destroy(h)
