@@ -209,59 +209,85 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         if constexpr (PK == PK_ATTN)
         {
             // ctx[h, d] = sum_i e_i o_i[d] / (sum_i e_i l_i + 1e-6),  e_i = exp(m_i - max_i m_i)  (MM/...Template.h:1756)
-            // All partial slots (<= 8) are requested unconditionally and together - addresses do not depend on the
-            // sequence length; slots beyond the active count get weight 0 by a select.
-            constexpr int NSM = 8;
+            // Every partial of every vector this thread owns is requested before the first value is looked at (one
+            // memory round trip); addresses do not depend on the sequence length, slots beyond the active count get
+            // weight 0 by a select.  NS = compile-time slot count (registers: NS x 10 per vector).
             const float2* ml = reinterpret_cast<const float2*>(p.attn_ml);
             const int seq = p.attn_seq_len[m];
-            const int nsm = p.attn_nsmax < NSM ? p.attn_nsmax : NSM;
+            auto merge = [&](auto ns_tag) {
+                constexpr int NS = decltype(ns_tag)::value;
+                constexpr int NV = kNXV < 2 ? kNXV : 2; // vectors merged together (K <= 4096: all of them)
+                const int nsm = p.attn_nsmax < NS ? p.attn_nsmax : NS;
 #pragma unroll
-            for (int j = 0; j < kNXV; ++j)
-            {
-                xv[j] = make_uint4(0, 0, 0, 0);
-                if (j * 2048 < Kp) // uniform
+                for (int j0 = 0; j0 < kNXV; j0 += NV)
                 {
-                    const int k = (tid + j * 256) * 8;
-                    const int kc = k < K ? k : K - 8;
-                    const int hh = kc / p.attn_dh, d0 = kc % p.attn_dh;
-                    const int64_t base = ((int64_t) m * p.attn_heads + hh) * p.attn_nsmax;
-                    float2 mls[NSM];
-                    float4 oa[NSM], ob[NSM];
+                    float2 mls[NV][NS];
+                    float4 oa[NV][NS], ob[NV][NS];
 #pragma unroll
-                    for (int i = 0; i < NSM; ++i)
+                    for (int jj = 0; jj < NV; ++jj)
                     {
-                        const int ic = i < nsm ? i : 0; // uniform clamp
-                        mls[i] = ml[base + ic];
-                        oa[i] = *reinterpret_cast<const float4*>(p.attn_o + (base + ic) * p.attn_dh + d0);
-                        ob[i] = *reinterpret_cast<const float4*>(p.attn_o + (base + ic) * p.attn_dh + d0 + 4);
+                        const int j = j0 + jj;
+                        xv[j] = make_uint4(0, 0, 0, 0);
+                        if (j * 2048 < Kp) // uniform
+                        {
+                            const int k = (tid + j * 256) * 8;
+                            const int kc = k < K ? k : K - 8;
+                            const int hh = kc / p.attn_dh, d0 = kc % p.attn_dh;
+                            const int64_t base = ((int64_t) m * p.attn_heads + hh) * p.attn_nsmax;
+#pragma unroll
+                            for (int i = 0; i < NS; ++i)
+                            {
+                                const int ic = i < nsm ? i : 0; // uniform clamp
+                                // (m, l) as ONE 8-byte load: as two floats hipcc fetches l in a second, dependent round trip
+                                const uint64_t mlbits = *reinterpret_cast<const uint64_t*>(ml + base + ic);
+                                mls[jj][i].x = __uint_as_float((uint32_t) mlbits);
+                                mls[jj][i].y = __uint_as_float((uint32_t) (mlbits >> 32));
+                                oa[jj][i] = *reinterpret_cast<const float4*>(p.attn_o + (base + ic) * p.attn_dh + d0);
+                                ob[jj][i] = *reinterpret_cast<const float4*>(p.attn_o + (base + ic) * p.attn_dh + d0 + 4);
+                            }
+                        }
                     }
+                    __builtin_amdgcn_sched_barrier(0); // all requests are in flight before any value is consumed
                     const int ns = seq / p.attn_tchunk + 1; // active splits
-                    float Mx = -INFINITY;
 #pragma unroll
-                    for (int i = 0; i < NSM; ++i)
-                        Mx = (i < ns && i < nsm) ? fmaxf(Mx, mls[i].x) : Mx;
-                    float L = 0.f;
-                    float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int i = 0; i < NSM; ++i)
+                    for (int jj = 0; jj < NV; ++jj)
                     {
-                        const bool act = i < ns && i < nsm && mls[i].x != -INFINITY;
-                        const float e = act ? __expf(mls[i].x - Mx) : 0.f;
-                        L += act ? mls[i].y * e : 0.f;
-                        o8[0] += act ? oa[i].x * e : 0.f;
-                        o8[1] += act ? oa[i].y * e : 0.f;
-                        o8[2] += act ? oa[i].z * e : 0.f;
-                        o8[3] += act ? oa[i].w * e : 0.f;
-                        o8[4] += act ? ob[i].x * e : 0.f;
-                        o8[5] += act ? ob[i].y * e : 0.f;
-                        o8[6] += act ? ob[i].z * e : 0.f;
-                        o8[7] += act ? ob[i].w * e : 0.f;
+                        const int j = j0 + jj;
+                        if (j * 2048 < Kp) // uniform
+                        {
+                            const int k = (tid + j * 256) * 8;
+                            float Mx = -INFINITY;
+#pragma unroll
+                            for (int i = 0; i < NS; ++i)
+                                Mx = (i < ns && i < nsm) ? fmaxf(Mx, mls[jj][i].x) : Mx;
+                            float L = 0.f;
+                            float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int i = 0; i < NS; ++i)
+                            {
+                                const bool act = i < ns && i < nsm && mls[jj][i].x != -INFINITY;
+                                const float e = act ? __expf(mls[jj][i].x - Mx) : 0.f;
+                                L += act ? mls[jj][i].y * e : 0.f;
+                                o8[0] += act ? oa[jj][i].x * e : 0.f;
+                                o8[1] += act ? oa[jj][i].y * e : 0.f;
+                                o8[2] += act ? oa[jj][i].z * e : 0.f;
+                                o8[3] += act ? oa[jj][i].w * e : 0.f;
+                                o8[4] += act ? ob[jj][i].x * e : 0.f;
+                                o8[5] += act ? ob[jj][i].y * e : 0.f;
+                                o8[6] += act ? ob[jj][i].z * e : 0.f;
+                                o8[7] += act ? ob[jj][i].w * e : 0.f;
+                            }
+                            const float inv = (k < K) ? 1.f / (L + 1.e-6f) : 0.f;
+                            xv[j] = make_uint4(pack_h2(o8[0] * inv, o8[1] * inv), pack_h2(o8[2] * inv, o8[3] * inv),
+                                pack_h2(o8[4] * inv, o8[5] * inv), pack_h2(o8[6] * inv, o8[7] * inv));
+                        }
                     }
-                    const float inv = (k < K) ? 1.f / (L + 1.e-6f) : 0.f;
-                    xv[j] = make_uint4(pack_h2(o8[0] * inv, o8[1] * inv), pack_h2(o8[2] * inv, o8[3] * inv),
-                        pack_h2(o8[4] * inv, o8[5] * inv), pack_h2(o8[6] * inv, o8[7] * inv));
                 }
-            }
+            };
+            if (p.attn_nsmax <= 6) // uniform
+                merge(std::integral_constant<int, 6>());
+            else
+                merge(std::integral_constant<int, 8>());
         }
         else if constexpr (X_HALF)
         {
