@@ -339,22 +339,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-        # TP communicator for the plugin library: rank 0's unique id -> everyone (replaces the MPI bootstrap)
-        import ctypes
-
-        from tensorrt_llm.plugin import capi
-        lib = capi.load_library()
-        idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            raw = (ctypes.c_char * 128)()
-            if lib.tllm_comm_get_unique_id(raw):
-                raise SystemExit(capi.last_error())
-            idbuf.copy_(torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8))
-        dist.broadcast(idbuf, 0)
-        raw = (ctypes.c_char * 128).from_buffer_copy(bytes(idbuf.cpu().numpy().tobytes()))
-        group = (ctypes.c_int32 * world)(*range(world))
-        if lib.tllm_comm_init_rank(group, world, rank, raw):
-            raise SystemExit(capi.last_error())
+        # TP communicator for the plugin library: rank 0's RCCL unique id -> everyone (replaces the MPI bootstrap), then
+        # the one-shot peer-to-peer all-reduce if - and only if - it reproduces RCCL's sums on this node
+        from tensorrt_llm import Mapping
+        from tensorrt_llm.parallel import enable_p2p_allreduce, ensure_tp_communicator
+        mapping = Mapping(world, rank)
+        ensure_tp_communicator(mapping)
+        allreduce_path = 'p2p' if enable_p2p_allreduce(mapping) else 'rccl'
+    else:
+        allreduce_path = None
 
     res = run_config(torch, dist, args, args.config, rank, world, dev)
     fp16 = None
@@ -401,7 +394,7 @@ def main():
         'data': 'synthetic',
         'config': {'workload': f'LLaMA-7B ({args.layers} layers) {names[args.config]}, batch 1, context {args.context} '
                                f'(synthetic KV), greedy decode, TP={world}', 'global_batch': 1,
-                   'seq_len': args.context, 'parallelism': f'tp{world}'},
+                   'seq_len': args.context, 'parallelism': f'tp{world}', 'allreduce': allreduce_path},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                      # name as rocprofv3 prints it: gemv_kernel<WT, PK_NORM = 1, EK_SWIGLU = 1, MB = 1, NXV = 2>

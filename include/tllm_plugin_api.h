@@ -166,6 +166,23 @@ int32_t tllm_comm_get_unique_id(void* id128);
 int32_t tllm_comm_init_rank(const int32_t* group, int32_t groupSize, int32_t rank, const void* id128);
 int32_t tllm_comm_destroy_all(void);
 
+/* One-shot peer-to-peer all-reduce (fp16 sum, in place) for the 8 KB partial sums of the tensor-parallel decode step:
+ * every rank writes its vector into a slot of every peer's inbox over xGMI, raises a flag, and adds the slots up in rank
+ * order (bit-identical on all ranks) - one hop instead of a ring (no reference counterpart, the
+ * reference calls ncclAllReduce: P/ncclPlugin/allreducePlugin.cpp:93).
+ *   create : allocates this rank's inbox (uncached device memory, 2 x world x max_bytes) and returns its 64-byte
+ *            hipIpcMemHandle_t in `handle64`;
+ *   attach : `handles` = the world x 64 bytes of every rank's handle in rank order (exchanged by the caller, like the
+ *            unique id);
+ *   enable : lets the AllReduce plugin and the session use it for fp16 vectors of at most max_bytes (after the caller
+ *            has validated it against the RCCL result on every rank; default off = RCCL);
+ *   all_reduce : direct entry (tests); spins are bounded, tllm_comm_p2p_error() returns non-zero after a time-out. */
+int32_t tllm_comm_p2p_create(int32_t world, int32_t rank, int64_t max_bytes, void* handle64);
+int32_t tllm_comm_p2p_attach(const void* handles);
+void tllm_comm_p2p_enable(int32_t on);
+int32_t tllm_comm_p2p_all_reduce(void* buf, int64_t count, tllm_stream_t stream);
+int32_t tllm_comm_p2p_error(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Weight pre-processing for the weight-only plugins.  Replaces the torch ops of
  * T/cpp/tensorrt_llm/thop/weightOnlyQuantOp.cpp:143-236,343-371 that the loaders call

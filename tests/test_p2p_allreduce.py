@@ -1,0 +1,88 @@
+"""One-shot peer-to-peer all-reduce (include/tllm_plugin_api.h: tllm_comm_p2p_*).  A 1-GPU box cannot host two RCCL
+ranks, but two PROCESSES can share the GPU and map each other's inbox with hipIpc - the same handle exchange, kernel,
+flag protocol and generation alternation that N GPUs run over xGMI (what differs there is the transport, which the
+caller validates against RCCL before enabling the path: tensorrt_llm/parallel.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_iter, sizes, q):
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'trtllm-llama_amd'))
+    from tensorrt_llm.plugin import capi
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        lib = capi.load_library()
+        lib.tllm_comm_p2p_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]
+        lib.tllm_comm_p2p_attach.argtypes = [ctypes.c_void_p]
+        lib.tllm_comm_p2p_all_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        h = (ctypes.c_char * 64)()
+        assert lib.tllm_comm_p2p_create(world, rank, 64 * 1024, h) == 0, capi.last_error()
+        mine = torch.frombuffer(bytearray(h.raw), dtype=torch.uint8)
+        allh = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        blob = b''.join(bytes(t.numpy().tobytes()) for t in allh)
+        assert lib.tllm_comm_p2p_attach(ctypes.create_string_buffer(blob, len(blob))) == 0, capi.last_error()
+        stream = torch.cuda.current_stream().cuda_stream
+        ok = True
+        for it in range(n_iter):
+            n = sizes[it % len(sizes)]
+            # every rank can rebuild every rank's input: seeded by (iteration, rank)
+            xs = [np.random.default_rng(1000 * it + r).standard_normal(n).astype(np.float16) for r in range(world)]
+            want = np.sum(np.stack([x.astype(np.float32) for x in xs]), axis=0, dtype=np.float32).astype(np.float16)
+            t = torch.from_numpy(xs[rank].copy()).cuda()
+            assert lib.tllm_comm_p2p_all_reduce(t.data_ptr(), n, stream) == 0, capi.last_error()
+            if it % 16 == 15 or it == n_iter - 1:  # no host sync in between: ranks run ahead of each other
+                torch.cuda.synchronize()
+            got = t.cpu().numpy()
+            # fp32 accumulation in rank order, one rounding: exact against the same computation on the host
+            ok = ok and np.array_equal(got, want)
+        torch.cuda.synchronize()
+        err = lib.tllm_comm_p2p_error()
+        q.put((rank, ok, err))
+        dist.barrier()
+        lib.tllm_comm_destroy_all()
+    except BaseException as e:
+        q.put((rank, False, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_p2p_allreduce_between_processes_on_one_gpu(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    sizes = [4096, 8, 8192, 32768, 520]  # B x D of the decode step, odd sizes, the 64 KB limit
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 200, sizes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, err in res:
+        assert err == 0, f'rank {rank}: a spin timed out (epoch {err})'
+        assert ok, f'rank {rank}: wrong sums'

@@ -220,6 +220,22 @@ struct GemmParams
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 
+// One-shot peer-to-peer sum all-reduce of an fp16 vector, in place (kernels/p2p_allreduce.hip; plugins/p2p.cpp owns the
+// inboxes).  peer[r]: base of rank r's region as mapped in THIS process: [2 gens][world][slot_bytes] data, then flags.
+struct P2PParams
+{
+    void* peer[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int32_t world = 0, rank = 0;
+    size_t slot_bytes = 0, flag_offset = 0;
+    void* x = nullptr; // fp16, n16 * 8 elements, 16-byte aligned (sum: in place; gather: this rank's contribution)
+    void* gather_out = nullptr; // non-null: all-gather instead of sum, out = [world][n16 * 16 bytes]
+    int32_t n16 = 0;
+    uint32_t* epoch = nullptr; // device counter, advanced by the kernel
+    uint32_t* error = nullptr; // device flag: non-zero after a spin timed out
+    int32_t max_spins = 4000000;
+};
+int launch_p2p_allreduce(const P2PParams& p, hipStream_t stream);
+
 // Greedy sampler: argmax over fp32 logits [B, V] -> ids; ties -> lowest index.
 int launch_argmax(int32_t* out_ids, const float* logits, int32_t batch, int32_t vocab, hipStream_t stream);
 

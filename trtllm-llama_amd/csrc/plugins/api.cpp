@@ -316,6 +316,34 @@ int32_t tllm_comm_destroy_all(void)
     return comm::destroy_all();
 }
 
+int32_t tllm_comm_p2p_create(int32_t world, int32_t rank, int64_t max_bytes, void* handle64)
+{
+    return comm::p2p::create(world, rank, (size_t) max_bytes, handle64) ? 1 : 0;
+}
+
+int32_t tllm_comm_p2p_attach(const void* handles)
+{
+    return comm::p2p::attach(handles) ? 1 : 0;
+}
+
+void tllm_comm_p2p_enable(int32_t on)
+{
+    comm::p2p::enable(on != 0);
+}
+
+int32_t tllm_comm_p2p_all_reduce(void* buf, int64_t count, tllm_stream_t stream)
+{
+    return comm::p2p::all_reduce_f16(buf, count, reinterpret_cast<hipStream_t>(stream)) ? 1 : 0;
+}
+
+int32_t tllm_comm_p2p_error(void)
+{
+    uint32_t e = 0;
+    if (comm::p2p::error_flag(&e))
+        return -1;
+    return (int32_t) e;
+}
+
 // ------------------------------------------------------------------------------------------------
 // weight-only quantiser + layout (host).  Arithmetic of
 // K/cutlass_kernels/cutlass_preprocessors.cpp:615-721 (symmetric_quantize): per column n of W[k,n]:

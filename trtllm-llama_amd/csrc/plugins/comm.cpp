@@ -139,8 +139,11 @@ bool has_comm(const std::vector<int32_t>& group)
 int all_reduce_sum(const std::vector<int32_t>& group, const void* in, void* out, int64_t count, int32_t dtype,
     hipStream_t stream)
 {
-    if (group.size() <= 1)
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (group.size() <= 1 && !g_comms.count(group))
     {
+        // a group of one without a communicator: the identity (a registered 1-rank communicator goes through RCCL, so
+        // that tests on one GPU exercise the real call sequence)
         if (in != out)
         {
             const int es = dtype == 1 ? 2 : (dtype == 2 ? 1 : 4);
@@ -149,7 +152,6 @@ int all_reduce_sum(const std::vector<int32_t>& group, const void* in, void* out,
         }
         return 0;
     }
-    std::lock_guard<std::mutex> lk(g_mu);
     ncclComm_t c = find(group);
     ncclDataType_t t;
     if (!c || !to_nccl_type(dtype, &t))
@@ -166,8 +168,11 @@ int all_reduce_sum(const std::vector<int32_t>& group, const void* in, void* out,
 int all_gather(const std::vector<int32_t>& group, const void* in, void* out, int64_t count, int32_t dtype,
     hipStream_t stream)
 {
-    if (group.size() <= 1)
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (group.size() <= 1 && !g_comms.count(group))
     {
+        // a group of one without a communicator: the identity (a registered 1-rank communicator goes through RCCL, so
+        // that tests on one GPU exercise the real call sequence)
         if (in != out)
         {
             const int es = dtype == 1 ? 2 : (dtype == 2 ? 1 : 4);
@@ -176,7 +181,6 @@ int all_gather(const std::vector<int32_t>& group, const void* in, void* out, int
         }
         return 0;
     }
-    std::lock_guard<std::mutex> lk(g_mu);
     ncclComm_t c = find(group);
     ncclDataType_t t;
     if (!c || !to_nccl_type(dtype, &t))
@@ -197,6 +201,7 @@ int destroy_all()
         if (g_api.CommDestroy)
             g_api.CommDestroy(kv.second);
     g_comms.clear();
+    (void) p2p::destroy();
     return 0;
 }
 

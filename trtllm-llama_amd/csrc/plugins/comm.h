@@ -18,5 +18,19 @@ int all_gather(const std::vector<int32_t>& group, const void* in, void* out, int
     hipStream_t stream);
 int destroy_all();
 bool has_comm(const std::vector<int32_t>& group);
+
+// One-shot peer-to-peer all-reduce for small fp16 vectors (kernels/p2p_allreduce.hip, plugins/p2p.cpp)
+namespace p2p
+{
+int create(int world, int rank, size_t max_bytes, void* handle64);
+int attach(const void* handles);
+void enable(bool on);
+bool attached();
+bool usable(int world, int64_t bytes);
+int all_reduce_f16(void* buf, int64_t count, hipStream_t stream);
+int all_gather(const void* in, void* out, int64_t bytes_per_rank, hipStream_t stream);
+int error_flag(uint32_t* out);
+int destroy();
+} // namespace p2p
 } // namespace comm
 } // namespace tllm

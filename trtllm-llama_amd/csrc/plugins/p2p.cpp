@@ -1,0 +1,189 @@
+// Host side of the one-shot peer-to-peer all-reduce (kernels/p2p_allreduce.hip): one uncached inbox region per rank,
+// exported with hipIpc, mapped by every peer.  The exchange of the 64-byte handles is the caller's business (bench.py
+// and tensorrt_llm/parallel.py use torch.distributed), like the RCCL unique id.
+#include "comm.h"
+#include "../kernels/kernels.h"
+#include <cstring>
+#include <mutex>
+
+namespace tllm
+{
+namespace comm
+{
+namespace p2p
+{
+namespace
+{
+struct State
+{
+    int world = 0, rank = -1;
+    size_t slot_bytes = 0, flag_offset = 0, region_bytes = 0;
+    void* local = nullptr;          // my region
+    void* peer[8] = {};             // every rank's region as mapped here (peer[rank] == local)
+    uint32_t* counters = nullptr;   // [0] epoch, [1] error  (ordinary device memory)
+    bool attached = false, enabled = false;
+};
+std::mutex g_mu;
+State g;
+
+void release_locked()
+{
+    for (int r = 0; r < g.world; ++r)
+        if (g.peer[r] && r != g.rank)
+            (void) hipIpcCloseMemHandle(g.peer[r]);
+    if (g.local)
+        (void) hipFree(g.local);
+    if (g.counters)
+        (void) hipFree(g.counters);
+    g = State();
+}
+} // namespace
+
+int create(int world, int rank, size_t max_bytes, void* handle64)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t must be 64 bytes");
+    if (world < 2 || world > 8 || rank < 0 || rank >= world || max_bytes == 0 || !handle64)
+    {
+        set_error("p2p: bad arguments (world %d in [2, 8], rank %d)", world, rank);
+        return -1;
+    }
+    release_locked();
+    g.world = world;
+    g.rank = rank;
+    g.slot_bytes = (max_bytes + 255) / 256 * 256;
+    g.flag_offset = 2 * (size_t) world * g.slot_bytes;
+    g.region_bytes = g.flag_offset + 4096;
+    // uncached: peers write it over xGMI and the owner must see those writes without an L2 line in the way
+    hipError_t e = hipExtMallocWithFlags(&g.local, g.region_bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess)
+    {
+        set_error("p2p: hipExtMallocWithFlags(uncached, %zu): %s", g.region_bytes, hipGetErrorString(e));
+        release_locked();
+        return -1;
+    }
+    if (hipMemset(g.local, 0, g.region_bytes) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&g.counters), 256) != hipSuccess
+        || hipMemset(g.counters, 0, 256) != hipSuccess)
+    {
+        set_error("p2p: allocation of the counters failed");
+        release_locked();
+        return -1;
+    }
+    hipIpcMemHandle_t h;
+    e = hipIpcGetMemHandle(&h, g.local);
+    if (e != hipSuccess)
+    {
+        set_error("p2p: hipIpcGetMemHandle: %s", hipGetErrorString(e));
+        release_locked();
+        return -1;
+    }
+    memcpy(handle64, &h, 64);
+    g.peer[rank] = g.local;
+    return 0;
+}
+
+int attach(const void* handles)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.local || !handles)
+    {
+        set_error("p2p: attach before create");
+        return -1;
+    }
+    for (int r = 0; r < g.world; ++r)
+    {
+        if (r == g.rank)
+            continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, static_cast<const char*>(handles) + 64 * r, 64);
+        hipError_t e = hipIpcOpenMemHandle(&g.peer[r], h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess)
+        {
+            set_error("p2p: hipIpcOpenMemHandle(rank %d): %s", r, hipGetErrorString(e));
+            g.peer[r] = nullptr;
+            return -1;
+        }
+    }
+    g.attached = true;
+    return 0;
+}
+
+void enable(bool on)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g.enabled = on && g.attached;
+}
+
+bool usable(int world, int64_t bytes)
+{
+    return g.enabled && g.world == world && bytes > 0 && (size_t) bytes <= g.slot_bytes && bytes % 16 == 0;
+}
+
+bool attached()
+{
+    return g.attached;
+}
+
+int all_reduce_f16(void* buf, int64_t count, hipStream_t stream)
+{
+    if (!g.attached || (count % 8))
+    {
+        set_error("p2p: all-reduce needs attached peers and a multiple of 8 halfs");
+        return -1;
+    }
+    kernels::P2PParams p;
+    for (int r = 0; r < g.world; ++r)
+        p.peer[r] = g.peer[r];
+    p.world = g.world;
+    p.rank = g.rank;
+    p.slot_bytes = g.slot_bytes;
+    p.flag_offset = g.flag_offset;
+    p.x = buf;
+    p.n16 = (int32_t) (count / 8);
+    p.epoch = g.counters;
+    p.error = g.counters + 1;
+    return kernels::launch_p2p_allreduce(p, stream);
+}
+
+int all_gather(const void* in, void* out, int64_t bytes, hipStream_t stream)
+{
+    if (!g.attached || (bytes % 16) || (reinterpret_cast<uintptr_t>(out) & 15))
+    {
+        set_error("p2p: all-gather needs attached peers, a multiple of 16 bytes per rank and a 16-byte aligned output");
+        return -1;
+    }
+    kernels::P2PParams p;
+    for (int r = 0; r < g.world; ++r)
+        p.peer[r] = g.peer[r];
+    p.world = g.world;
+    p.rank = g.rank;
+    p.slot_bytes = g.slot_bytes;
+    p.flag_offset = g.flag_offset;
+    p.x = const_cast<void*>(in);
+    p.gather_out = out;
+    p.n16 = (int32_t) (bytes / 16);
+    p.epoch = g.counters;
+    p.error = g.counters + 1;
+    return kernels::launch_p2p_allreduce(p, stream);
+}
+
+int error_flag(uint32_t* out)
+{
+    if (!g.counters)
+    {
+        *out = 0;
+        return 0;
+    }
+    return hipMemcpy(out, g.counters + 1, 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+
+int destroy()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    release_locked();
+    return 0;
+}
+
+} // namespace p2p
+} // namespace comm
+} // namespace tllm

@@ -913,6 +913,8 @@ public:
         const int64_t n = volume(inDesc[0].dims);
         if (gather)
             return comm::all_gather(group, in[0], out[0], n, type_id, stream) ? 1 : 0;
+        if (type_id == TLLM_HALF && in[0] == out[0] && comm::p2p::usable((int) group.size(), n * 2))
+            return comm::p2p::all_reduce_f16(out[0], n, stream) ? 1 : 0; // one-shot peer-to-peer path (opt-in, validated by the caller)
         return comm::all_reduce_sum(group, in[0], out[0], n, type_id, stream) ? 1 : 0;
     }
     void serialize(Writer& w) const override

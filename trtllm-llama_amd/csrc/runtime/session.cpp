@@ -431,6 +431,8 @@ struct tllm_session
     {
         if (tp == 1 && !force_comm)
             return 0;
+        if (comm::p2p::usable(tp, n * 2))
+            return timed(PC_COMM, st, [&] { return comm::p2p::all_reduce_f16(buf, n, st) ? 1 : 0; });
         return timed(PC_COMM, st, [&] { return comm::all_reduce_sum(group, buf, buf, n, TLLM_HALF, st) ? 1 : 0; });
     }
 
@@ -568,7 +570,13 @@ struct tllm_session
         RUN(head_rc);
         if (tp > 1 || force_comm)
         {
-            if (comm::all_gather(group, logits_local, logits, (int64_t) B * Vr, TLLM_FLOAT, st))
+            const int64_t bytes = (int64_t) B * Vr * 4;
+            if (comm::p2p::usable(tp, bytes))
+            {
+                if (comm::p2p::all_gather(logits_local, logits, bytes, st))
+                    return 1;
+            }
+            else if (comm::all_gather(group, logits_local, logits, (int64_t) B * Vr, TLLM_FLOAT, st))
                 return 1;
         }
         return 0;
@@ -824,9 +832,9 @@ int32_t tllm_session_finalize(tllm_session_t s)
             RUN(s->scalar_f32(p + "attention.kv_quant_orig_scale", &L.kv_qo));
         }
     }
-    if (s->tp > 1 && !comm::has_comm(s->group))
+    if (s->tp > 1 && !comm::has_comm(s->group) && !comm::p2p::attached())
     {
-        set_error("session: tp_size=%d but no communicator registered (tllm_comm_init_rank)", s->tp);
+        set_error("session: tp_size=%d but no communicator registered (tllm_comm_init_rank / tllm_comm_p2p_attach)", s->tp);
         return 1;
     }
     s->finalized = true;

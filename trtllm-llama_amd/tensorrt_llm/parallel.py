@@ -33,3 +33,65 @@ def ensure_tp_communicator(mapping) -> None:
     if lib.tllm_comm_init_rank(group, mapping.tp_size, mapping.rank, raw):
         raise RuntimeError(capi.last_error())
     _done.add(key)
+
+
+def enable_p2p_allreduce(mapping, max_bytes: int = 64 * 1024, iters: int = 8, verbose: bool = True) -> bool:
+    """Switch the decode step's small fp16 all-reduces to the one-shot peer-to-peer kernel (include/tllm_plugin_api.h,
+    tllm_comm_p2p_*) - but only after it has reproduced RCCL's result on THIS machine: every rank runs `iters` random
+    all-reduces both ways, the verdicts are AND-ed over the ranks, and any mismatch, time-out or missing capability
+    (hipIpc, peer access) leaves RCCL in charge.  TLLM_ALLREDUCE=rccl skips the attempt."""
+    if mapping.tp_size <= 1 or os.environ.get('TLLM_ALLREDUCE', '').lower() == 'rccl':
+        return False
+    import torch
+    import torch.distributed as dist
+    ensure_tp_communicator(mapping)
+    lib = capi.load_library()
+    lib.tllm_comm_p2p_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]
+    lib.tllm_comm_p2p_attach.argtypes = [ctypes.c_void_p]
+    lib.tllm_comm_p2p_all_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    lib.tllm_comm_p2p_enable.argtypes = [ctypes.c_int32]
+    lib.tllm_comm_p2p_enable.restype = None
+    dev = torch.device('cuda', torch.cuda.current_device())
+    world, rank = mapping.tp_size, mapping.tp_group.index(mapping.rank)
+    ok = True
+    why = ''
+    h = (ctypes.c_char * 64)()
+    if lib.tllm_comm_p2p_create(world, rank, max_bytes, h):
+        ok, why = False, capi.last_error()
+    mine = torch.frombuffer(bytearray(h.raw), dtype=torch.uint8).to(dev)
+    allh = [torch.zeros(64, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(allh, mine)  # every rank takes part even if its own create failed
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        blob = b''.join(bytes(t.cpu().numpy().tobytes()) for t in allh)
+        if lib.tllm_comm_p2p_attach(ctypes.create_string_buffer(blob, len(blob))):
+            ok, why = False, capi.last_error()
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        stream = torch.cuda.current_stream().cuda_stream
+        g = torch.Generator(device='cpu').manual_seed(1234 + rank)
+        for it in range(iters):  # no early exit: every rank issues the same collectives whatever it observes
+            n = (4096, 8192, 32768, 520 * 8)[it % 4]
+            x = (torch.randn(n, generator=g) * 3).to(torch.float16).to(dev)
+            ref = x.clone()
+            dist.all_reduce(ref)  # RCCL through torch
+            got = x.clone()
+            if lib.tllm_comm_p2p_all_reduce(got.data_ptr(), n, stream):
+                ok, why = False, capi.last_error()
+            torch.cuda.synchronize()
+            # RCCL adds in fp16 along its ring, the one-shot kernel in fp32 in rank order: a few fp16 ulps apart at most
+            if ok and not torch.allclose(got.float(), ref.float(), rtol=4e-3, atol=4e-3 * world):
+                ok, why = False, f'mismatch vs RCCL at iteration {it}: max |diff| {(got.float() - ref.float()).abs().max().item():.4g}'
+        if ok and lib.tllm_comm_p2p_error() != 0:
+            ok, why = False, 'a flag wait timed out'
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    use = int(flag.item()) == 1
+    lib.tllm_comm_p2p_enable(1 if use else 0)
+    if verbose and mapping.rank == mapping.tp_group[0]:
+        import sys
+        print(f'[tensorrt_llm.parallel] decode all-reduce: {"one-shot peer-to-peer (validated against RCCL)" if use else "RCCL"}'
+              + (f' ({why})' if why else ''), file=sys.stderr)
+    return use
