@@ -86,3 +86,43 @@ def test_p2p_allreduce_between_processes_on_one_gpu(world):
     for rank, ok, err in res:
         assert err == 0, f'rank {rank}: a spin timed out (epoch {err})'
         assert ok, f'rank {rank}: wrong sums'
+
+
+def _enable_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'trtllm-llama_amd'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        import tensorrt_llm.parallel as P
+        from tensorrt_llm import Mapping
+        P.ensure_tp_communicator = lambda mapping: None  # two ranks cannot share a GPU under RCCL; gloo plays its part
+        used = P.enable_p2p_allreduce(Mapping(world, rank), verbose=False)
+        q.put((rank, bool(used), ''))
+        dist.barrier()
+        from tensorrt_llm.plugin import capi
+        capi.load_library().tllm_comm_destroy_all()
+    except BaseException as e:
+        q.put((rank, False, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_validated_enable_path_of_the_bootstrap():
+    """tensorrt_llm.parallel.enable_p2p_allreduce - handle exchange, validation against the library all-reduce of
+    torch.distributed, AND-ed verdict, enable - run by two processes on one GPU (gloo standing in for RCCL)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_enable_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
