@@ -292,11 +292,11 @@ def run_attention(p, qkv, cache, seq_len, past_len, is_context, masked, in_len, 
 
 @pytest.mark.parametrize('int8_kv', [0, 1])
 @pytest.mark.parametrize('H,Dh', [(4, 128), (4, 64), (2, 32), (32, 128)])
-@pytest.mark.parametrize('L', [1, 17, 128, 1023])
+@pytest.mark.parametrize('L', [1, 17, 128, 1023, 2047])
 def test_mmha_decode_vs_oracle(int8_kv, H, Dh, L):
     """Generation step: new token at slot L; half of batch element 1's prompt is padding (test_gpt_attention.py:437-449)."""
     r = rng(100 + L)
-    B, smax = 2, 1152
+    B, smax = 2, (1152 if L < 1152 else 2048)  # L = 2047: the last slot of a full n_positions = 2048 cache
     max_in = max(L - 3, 1) if L > 4 else L
     in_len = [max_in, max(max_in // 2, 1)]
     masked = np.zeros((B, smax), dtype=np.int32)

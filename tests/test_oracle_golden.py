@@ -180,3 +180,25 @@ def test_host_weight_quantiser_matches_oracle():
                 for pos in range(8):
                     dec[:, word * 8 + elem_of_nibble[pos]] = nib[:, word * 8 + pos].astype(np.int32) - 8
             np.testing.assert_array_equal(dec, q.T)
+
+
+@pytest.mark.parametrize('pos', [0, 1, 127, 1023, 2047])
+def test_rope_vs_hf_rotary_at_far_positions(pos):
+    """NeoX (rotate-half) RoPE of the oracle against HF's LlamaRotaryEmbedding + apply_rotary_pos_emb in fp32, at the
+    positions SURVEY.md section 8c lists - position 2047 needs the angle computed in fp32 from the fp32 inverse
+    frequencies exactly as HF does, or the fp16 result drifts."""
+    import torch
+    from transformers import LlamaConfig
+    from transformers.models.llama.modeling_llama import LlamaRotaryEmbedding, apply_rotary_pos_emb
+    Dh = 128
+    cfg = LlamaConfig(hidden_size=Dh * 2, num_attention_heads=2, max_position_embeddings=2048)
+    rot = LlamaRotaryEmbedding(config=cfg)
+    g = torch.Generator().manual_seed(pos)
+    q = torch.randn(1, 2, 1, Dh, generator=g).half().float()
+    cos, sin = rot(q, torch.tensor([[pos]]))
+    qh, _ = apply_rotary_pos_emb(q, q, cos, sin)
+    want = qh[0, :, 0].numpy()
+    got = np.stack([O.apply_rope(q[0, h, 0].numpy(), pos, Dh, True) for h in range(2)])
+    # oracle output is rounded to fp16 (the plugin's contract): half an fp16 ulp of |x| <= ~4
+    np.testing.assert_allclose(got, want, atol=2e-3, rtol=1e-3)
+    assert np.abs(got - want).max() < 2.5e-3
