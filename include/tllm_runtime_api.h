@@ -29,7 +29,8 @@ typedef struct tllm_session* tllm_session_t;
  *   rms_norm_eps (1e-6), tp_size (1), tp_rank (0), quant_mode (0: QuantMode bits,
  *   T/tensorrt_llm/quantization/mode.py:6-21), weight_only_precision (int8|int4),
  *   use_gpt_attention_plugin/use_gemm_plugin (informational), neox_rotary_style (1),
- *   force_comm (0; tests: issue the tensor-parallel collectives on a 1-rank communicator as well).
+ *   force_comm (0; tests: issue the tensor-parallel collectives on a 1-rank communicator as well),
+ *   remove_input_padding (0; 1: the context phase runs on the packed real tokens only).
  * Returns NULL on error (tllm_last_error()). */
 tllm_session_t tllm_session_create(const char* config_text);
 

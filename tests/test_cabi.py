@@ -72,9 +72,11 @@ def test_creation_contract_missing_unknown_and_unbuilt_fields():
     assert capi.Plugin.create('GPTAttention', attention_fields() + [capi.PluginField('bogus', i32(1))]) is None
     # options of the contract that are not built are rejected, not ignored
     for k, v in (('multi_query_mode', i8(1)), ('fp8_kv_cache', i32(1)), ('paged_kv_cache', i32(1)),
-                 ('in_flight_batching', i32(1)), ('remove_input_padding', i8(1))):
+                 ('in_flight_batching', i32(1))):
         assert capi.Plugin.create('GPTAttention', attention_fields(**{k: v})) is None, k
         assert capi.last_error()
+    # packed inputs ARE built
+    assert capi.Plugin.create('GPTAttention', attention_fields(remove_input_padding=i8(1))) is not None
     # head sizes the reference asserts (functional.py:2831)
     assert capi.Plugin.create('GPTAttention', attention_fields(head_size=i32(100))) is None
 

@@ -169,10 +169,14 @@ def test_generation_session_matches_hf_golden(mode):
 
 
 @pytest.mark.gpu
-def test_build_then_run_cli(tmp_path):
+@pytest.mark.parametrize('extra', [[], ['--remove_input_padding']])
+def test_build_then_run_cli(tmp_path, extra):
     out = tmp_path / 'eng'
-    subprocess.run([sys.executable, os.path.join(EX, 'build.py'), '--output_dir', str(out), '--log_level', 'error'] + TINY,
-                   check=True, cwd=EX, timeout=300)
+    subprocess.run([sys.executable, os.path.join(EX, 'build.py'), '--output_dir', str(out), '--log_level', 'error'] + TINY
+                   + extra, check=True, cwd=EX, timeout=300)
+    if extra:
+        blob = open(out / 'llama_float16_tp1_rank0.engine', 'rb').read()
+        assert b'remove_input_padding=1' in blob[:4096] and b'"input_ids"' in blob
     np.save(tmp_path / 'in.npy', np.array([5, 17, 99, 3, 64], np.int32))
     r = subprocess.run([sys.executable, os.path.join(EX, 'run.py'), '--max_output_len', '8', '--engine_dir', str(out),
                         '--input_tokens', str(tmp_path / 'in.npy'), '--output_npy', str(tmp_path / 'out.npy'),

@@ -260,12 +260,12 @@ def test_prefill_gemm_every_tile_shape(cfg):
 
 
 # ---------------------------------------------------------------------------------------------- attention
-def attention_plugin(H, Dh, int8_kv, rot=None, neox=1):
+def attention_plugin(H, Dh, int8_kv, rot=None, neox=1, packed=0):
     return make_plugin('GPTAttention', [
         ('num_heads', i32(H)), ('head_size', i32(Dh)), ('unidirectional', i32(1)), ('q_scaling', f32(1.0)),
         ('rotary_embedding_dim', i32(Dh if rot is None else rot)), ('neox_rotary_style', i8(neox)),
         ('context_fmha_type', i8(0)), ('multi_block_mode', i8(0)), ('multi_query_mode', i8(0)),
-        ('int8_kv_cache', i32(int8_kv)), ('fp8_kv_cache', i32(0)), ('remove_input_padding', i8(0)),
+        ('int8_kv_cache', i32(int8_kv)), ('fp8_kv_cache', i32(0)), ('remove_input_padding', i8(packed)),
         ('mask_type', i32([1])), ('paged_kv_cache', i32(0)), ('type_id', i32([capi.HALF])), ('in_flight_batching', i32(0)),
     ])
 
@@ -389,6 +389,42 @@ def test_context_attention_vs_oracle(int8_kv, H, Dh, S):
         np.testing.assert_array_equal(got[:, 1], ref_cache[:, 1])
         np.testing.assert_allclose(got[:, 0].astype(np.float32), ref_cache[:, 0].astype(np.float32), atol=2e-4,
                                    rtol=2e-3)
+
+
+@pytest.mark.parametrize('int8_kv', [0, 1])
+@pytest.mark.parametrize('H,Dh,S', [(4, 128, 200), (2, 64, 70), (2, 32, 40)])
+def test_packed_context_attention_equals_padded(int8_kv, H, Dh, S):
+    """remove_input_padding (gptAttentionPlugin.cpp:344-356): the tokens of all sequences back to back in [1, T, 3 D];
+    the plugin must produce, for every real token, what the padded run produces, and the same KV cache."""
+    r = rng(300 + S)
+    B, smax = 3, S + 8
+    in_len = [S, S // 3, max(S // 2, 1)]
+    qkv = h(r.standard_normal((B, S, 3 * H * Dh)))
+    dt = torch.int8 if int8_kv else torch.float16
+    scales = (20.0, 0.05) if int8_kv else None
+    masked = np.zeros((B, smax), np.int32)
+    cache_pad = torch.zeros((B, 2, H, smax, Dh), dtype=dt, device='cuda')
+    out_pad = run_attention(attention_plugin(H, Dh, int8_kv), qkv.clone(), cache_pad, [S] * B, 0, True, masked, in_len, S, smax,
+                            scales)
+    packed = torch.cat([qkv[b, :in_len[b]] for b in range(B)], dim=0)[None].contiguous()  # [1, T, 3 D]
+    cache_pk = torch.zeros((B, 2, H, smax, Dh), dtype=dt, device='cuda')
+    p = attention_plugin(H, Dh, int8_kv, packed=1)
+    T = packed.shape[1]
+    out_pk = torch.empty((1, T, H * Dh), dtype=torch.float16, device='cuda')
+    ins = [packed, cache_pk, torch.tensor([S] * B, dtype=torch.int32, device='cuda'), HostTensor([0, 1]),
+           torch.tensor(masked, dtype=torch.int32, device='cuda'), torch.tensor(in_len, dtype=torch.int32, device='cuda')]
+    dummy = torch.zeros(max(S, B * smax), dtype=torch.int32, device='cuda')
+    ins += [dummy[:S], dummy[:B * smax].view(B, 1, smax)]
+    if scales:
+        ins += [torch.tensor([scales[0]], dtype=torch.float32, device='cuda'),
+                torch.tensor([scales[1]], dtype=torch.float32, device='cuda')]
+    run_plugin(p, ins, [out_pk, cache_pk])
+    off = 0
+    for b in range(B):
+        # same kernels, same per-row arithmetic: bit-identical rows
+        assert torch.equal(out_pk[0, off:off + in_len[b]], out_pad[b, :in_len[b]]), b
+        off += in_len[b]
+    assert torch.equal(cache_pk, cache_pad)
 
 
 def test_plugin_rejects_unbuilt_features():

@@ -289,3 +289,32 @@ def test_batch_invariance_and_session_reuse(mode, int8_kv):
     single = np.stack(single)
     np.testing.assert_array_equal(got[:, 0], single[:, 0])  # the context phase agrees exactly on the first token
     assert np.mean(got == single) > 0.9, (got, single)
+
+
+@pytest.mark.parametrize('mode,int8_kv', [('fp16', 0), ('sq_static_pc', 1)])
+def test_packed_context_equals_padded(mode, int8_kv):
+    """remove_input_padding=1: the context phase runs on the sum(len) real tokens only; logits of the last prompt token,
+    the KV cache it leaves behind and the generation that follows must be those of the padded run."""
+    cfg, w = synth_model(51)
+    r = np.random.default_rng(19)
+    B, S, NEW = 4, 40, 8
+    lens = np.array([40, 7, 23, 33], np.int32)
+    ids = np.full((B, S), 2, np.int32)
+    for b in range(B):
+        ids[b, :lens[b]] = r.integers(3, cfg['vocab_size'], lens[b])
+    qmodel = QO.quantise_model(cfg, w, mode, int8_kv, calib_ids=ids, calib_lens=lens)
+    outs, logits = [], []
+    for packed in (0, 1):
+        s = NativeSession(dict(cfg, quant_mode=qmodel['quant_mode'], remove_input_padding=packed))
+        for k, v in qmodel['engine_tensors'].items():
+            s.set_tensor(k, v)
+        s.finalize()
+        s.setup(B, S, NEW)
+        s.context(ids, lens)
+        logits.append(s.logits())
+        s.step(NEW - 1, use_graph=True)
+        outs.append(s.output_ids())
+        s.close()
+    # GEMM rows are computed independently of how many rows there are -> the same bits
+    np.testing.assert_array_equal(logits[0], logits[1])
+    np.testing.assert_array_equal(outs[0], outs[1])

@@ -51,6 +51,12 @@ __device__ __forceinline__ uint2 quant8(const uint4& v, float s)
     return make_uint2(o[0], o[1]);
 }
 
+// first row of sequence b in the (padded or packed) token-major buffers
+__device__ __forceinline__ int64_t seq_row0(const ContextAttnParams& p, int b)
+{
+    return p.cu_seqlens ? (int64_t) p.cu_seqlens[b] : (int64_t) b * p.seq;
+}
+
 // grid (S, H, B); DH/8 active lanes, each owning 8 consecutive elements of the head.
 template <int DH>
 __global__ void rope_kv_write_kernel(const ContextAttnParams p)
@@ -61,11 +67,12 @@ __global__ void rope_kv_write_kernel(const ContextAttnParams p)
     if (li >= LPR)
         return;
     const int H = p.num_heads, S = p.seq;
-    uint16_t* row = reinterpret_cast<uint16_t*>(p.qkv) + ((int64_t) b * S + s) * 3 * H * DH;
+    const bool valid = s < p.input_lengths[b];
+    const bool has_row = valid || !p.cu_seqlens; // packed buffers hold no padding rows
+    uint16_t* row = reinterpret_cast<uint16_t*>(p.qkv) + (seq_row0(p, b) + (has_row ? s : 0)) * 3 * H * DH;
     uint16_t* qp = row + (int64_t) h * DH + li * 8;
     uint16_t* kp = row + (int64_t) (H + h) * DH + li * 8;
     uint16_t* vp = row + (int64_t) (2 * H + h) * DH + li * 8;
-    const bool valid = s < p.input_lengths[b];
     uint4 q4 = *reinterpret_cast<const uint4*>(qp);
     uint4 k4 = *reinterpret_cast<const uint4*>(kp);
     uint4 v4 = *reinterpret_cast<const uint4*>(vp);
@@ -122,10 +129,13 @@ __global__ void rope_kv_write_kernel(const ContextAttnParams p)
         q4 = f_to_h8(qf);
         k4 = f_to_h8(kf);
     }
-    *reinterpret_cast<uint4*>(qp) = q4;
-    *reinterpret_cast<uint4*>(kp) = k4;
-    if (!valid)
-        *reinterpret_cast<uint4*>(vp) = v4;
+    if (has_row)
+    {
+        *reinterpret_cast<uint4*>(qp) = q4;
+        *reinterpret_cast<uint4*>(kp) = k4;
+        if (!valid)
+            *reinterpret_cast<uint4*>(vp) = v4;
+    }
     if (s < p.max_seq_len)
     {
         const int esz = p.int8_kv ? 1 : 2;
@@ -159,14 +169,14 @@ __global__ __launch_bounds__(256) void context_attn_kernel(const ContextAttnPara
     if (qi >= S)
         return;
     const int len = p.input_lengths[b];
-    uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) + (((int64_t) b * S + qi) * H + h) * DH + li * 8;
+    uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) + ((seq_row0(p, b) + qi) * H + h) * DH + li * 8;
     if (qi >= len)
     {
-        if (grp == 0)
+        if (grp == 0 && !p.cu_seqlens) // packed outputs have no padding rows
             *reinterpret_cast<uint4*>(outp) = make_uint4(0, 0, 0, 0);
         return;
     }
-    const uint16_t* base = reinterpret_cast<const uint16_t*>(p.qkv) + (int64_t) b * S * 3 * H * DH;
+    const uint16_t* base = reinterpret_cast<const uint16_t*>(p.qkv) + seq_row0(p, b) * 3 * H * DH;
     const int64_t rs = (int64_t) 3 * H * DH; // row stride
     const uint4 q16 = *reinterpret_cast<const uint4*>(base + (int64_t) qi * rs + (int64_t) h * DH + li * 8);
     const uint16_t* kb = base + (int64_t) (H + h) * DH + li * 8;
@@ -289,13 +299,14 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const ContextAttnParam
     __shared__ uint16_t tile[64 * PITCH];
     const int kv0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
     const int H = p.num_heads, S = p.seq;
-    const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.qkv) + (int64_t) b * S * 3 * H * DH + (int64_t) (2 * H + h) * DH;
+    const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.qkv) + seq_row0(p, b) * 3 * H * DH + (int64_t) (2 * H + h) * DH;
+    const int nrows = p.cu_seqlens ? p.input_lengths[b] : S; // rows that exist (padded: rows >= len were zeroed in place)
     constexpr int CPR = DH / 8; // 16-byte pieces per key row
     for (int i = threadIdx.x; i < 64 * CPR; i += 256)
     {
         const int key = i / CPR, c = i % CPR;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (kv0 + key < S)
+        if (kv0 + key < nrows)
             v = *reinterpret_cast<const uint4*>(vb + (int64_t) (kv0 + key) * 3 * H * DH + c * 8);
         uint32_t* d = reinterpret_cast<uint32_t*>(tile + key * PITCH + c * 8);
         d[0] = v.x;
@@ -335,20 +346,23 @@ __global__ __launch_bounds__(256) void context_attn_mfma_kernel(const ContextAtt
     const int ql = lane & 31, hf = lane >> 5;
     const int q = q0 + ql;
     const int len = p.input_lengths[b];
-    const int64_t rs = (int64_t) 3 * H * DH * 2; // bytes per token row of the packed QKV buffer
-    const char* qkv = reinterpret_cast<const char*>(p.qkv) + (int64_t) b * S * rs;
+    const int64_t rs = (int64_t) 3 * H * DH * 2; // bytes per token row of the fused QKV buffer
+    const char* qkv = reinterpret_cast<const char*>(p.qkv) + seq_row0(p, b) * rs;
+    const int nrows = p.cu_seqlens ? len : S; // token rows of this sequence that exist in the buffers
     const char* vt = reinterpret_cast<const char*>(p.workspace) + ((int64_t) (b * H + h) * DH) * spad * 2;
 
     // Q fragments (B operand): lane (q, half) holds d = 16 s + 8 half .. + 8 for every k-step s
     uint4 qf[KST];
     {
-        const char* qrow = qkv + (int64_t) (q < S ? q : S - 1) * rs + (int64_t) h * DH * 2;
+        const char* qrow = qkv + (int64_t) (q < nrows ? q : nrows - 1) * rs + (int64_t) h * DH * 2;
 #pragma unroll
         for (int s = 0; s < KST; ++s)
             qf[s] = *reinterpret_cast<const uint4*>(qrow + (16 * s + 8 * hf) * 2);
     }
 
-    const int kv_end = (qb * 128 + 128 < S ? qb * 128 + 128 : S); // causal: keys <= the block's last query
+    if (qb * 128 >= nrows) // packed inputs: this query block lies entirely beyond the sequence (block-uniform)
+        return;
+    const int kv_end = (qb * 128 + 128 < nrows ? qb * 128 + 128 : nrows); // causal: keys <= the block's last query
     const int nkb = (kv_end + 63) / 64;
     const uint32_t lds_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void*) lds;
     auto issue = [&](int t) {
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(256) void context_attn_mfma_kernel(const ContextAtt
             {
                 const int sub = c / 8, row = (c % 8) * 8 + r8;
                 const int col = (lane & 7) ^ ((row >> 1) & 7);
-                const int key = kv0 + row < S ? kv0 + row : S - 1;
+                const int key = kv0 + row < nrows ? kv0 + row : nrows - 1;
                 src = qkv + (int64_t) key * rs + (int64_t) (H + h) * DH * 2 + sub * 128 + col * 16;
             }
             else
@@ -480,13 +494,13 @@ __global__ __launch_bounds__(256) void context_attn_mfma_kernel(const ContextAtt
             *reinterpret_cast<uint2*>(scr + ql * PITCH + (32 * i + 8 * g + 4 * hf) * 2) = make_uint2(w0, w1);
         }
     constexpr int PPR = DH / 8; // 16-byte pieces per output row
-    uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) + (int64_t) b * S * H * DH + (int64_t) h * DH;
+    uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) + seq_row0(p, b) * H * DH + (int64_t) h * DH;
 #pragma unroll
     for (int i = lane; i < 32 * PPR; i += 64)
     {
         const int row = i / PPR, pc = i % PPR;
         const uint4 v = *reinterpret_cast<const uint4*>(scr + row * PITCH + pc * 16);
-        if (q0 + row < S)
+        if (q0 + row < nrows)
             *reinterpret_cast<uint4*>(outp + (int64_t) (q0 + row) * H * DH + pc * 8) = v;
     }
 }

@@ -195,8 +195,15 @@ struct ContextAttnParams
     int32_t rope_table_len = 0;
     void* out = nullptr; // fp16 [B, S, H*Dh]; rows >= input_len[b] are zero
     void* workspace = nullptr; // context_attention_workspace_size() bytes; NULL -> the (slow) wave-per-query kernel
+    // packed inputs (remove_input_padding, P/gptAttentionPlugin/gptAttentionPlugin.cpp:344-356): qkv / out hold only the real
+    // tokens, [sum(len), ...]; token s of sequence b is row cu_seqlens[b] + s.  `seq` stays the longest sequence (grid bound).
+    const int32_t* cu_seqlens = nullptr; // device int32 [B + 1], exclusive prefix sum of input_lengths
 };
 size_t context_attention_workspace_size(int batch, int num_heads, int head_size, int seq);
+// cu[0] = 0, cu[b + 1] = cu[b] + lens[b]  (device, one tiny launch; packed-input bookkeeping)
+int launch_exclusive_scan_i32(int32_t* cu, const int32_t* lens, int32_t n, hipStream_t stream);
+// out[b, :] = hidden[rows[b], :]  (fp16 rows; the packed-input flavour of gather_last_token)
+int launch_gather_rows(void* out, const void* hidden, const int32_t* rows, int32_t batch, int32_t hidden_size, hipStream_t stream);
 int launch_context_attention(const ContextAttnParams& p, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------

@@ -679,6 +679,43 @@ int launch_gather_last_token(void* out, const void* hidden, const int32_t* last_
     return check_launch("gather_last_token");
 }
 
+__global__ __launch_bounds__(256) void gather_rows_kernel(uint16_t* out, const uint16_t* hidden, const int32_t* rows, int32_t hs)
+{
+    const uint16_t* src = hidden + (int64_t) rows[blockIdx.x] * hs;
+    uint16_t* dst = out + (int64_t) blockIdx.x * hs;
+    for (int k = threadIdx.x; k < hs; k += blockDim.x)
+        dst[k] = src[k];
+}
+
+int launch_gather_rows(void* out, const void* hidden, const int32_t* rows, int32_t batch, int32_t hidden_size, hipStream_t stream)
+{
+    if (batch <= 0)
+        return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(batch), dim3(256), 0, stream, reinterpret_cast<uint16_t*>(out),
+        reinterpret_cast<const uint16_t*>(hidden), rows, hidden_size);
+    return check_launch("gather_rows");
+}
+
+__global__ void exclusive_scan_i32_kernel(int32_t* cu, const int32_t* lens, int32_t n)
+{
+    if (threadIdx.x == 0)
+    {
+        int32_t acc = 0;
+        cu[0] = 0;
+        for (int i = 0; i < n; ++i)
+        {
+            acc += lens[i];
+            cu[i + 1] = acc;
+        }
+    }
+}
+
+int launch_exclusive_scan_i32(int32_t* cu, const int32_t* lens, int32_t n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(exclusive_scan_i32_kernel, dim3(1), dim3(64), 0, stream, cu, lens, n);
+    return check_launch("exclusive_scan");
+}
+
 int launch_greedy_step(const GreedyParams& p, hipStream_t stream)
 {
     if (p.batch <= 0)

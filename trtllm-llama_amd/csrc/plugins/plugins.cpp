@@ -80,6 +80,7 @@ const float* rope_table(int rotary_dim, int min_len, int* len_out)
 class GPTAttentionPlugin : public Plugin
 {
 public:
+    static constexpr size_t kCuBytes = 4096; // packed inputs: cu_seqlens at the head of the workspace (batch <= 1023)
     struct Cfg
     {
         int32_t num_heads, head_size, unidirectional;
@@ -141,8 +142,6 @@ public:
             throw std::runtime_error("GPTAttention: paged_kv_cache not built");
         if (c.in_flight_batching)
             throw std::runtime_error("GPTAttention: in_flight_batching not built");
-        if (c.remove_input_padding)
-            throw std::runtime_error("GPTAttention: remove_input_padding not built");
         if (!c.unidirectional)
             throw std::runtime_error("GPTAttention: only causal (unidirectional) attention");
     }
@@ -194,11 +193,13 @@ public:
 
     size_t workspaceSize(const Desc* in, int nin, const Desc* out, int nout) const override
     {
-        const int B = in[0].dims.d[0];
+        // packed inputs: qkv is [1, tokens, 3 D]; the batch is input_lengths' extent, the longest sequence input 6's
+        const int B = c.remove_input_padding ? in[5].dims.d[0] : in[0].dims.d[0];
+        const int S = c.remove_input_padding ? in[6].dims.d[0] : in[0].dims.d[1];
         const int Smax = in[1].dims.d[3];
         // max(context, generation), like the reference (gptAttentionPlugin.cpp:132-144)
         const size_t gen = mmha_workspace_size(B, c.num_heads, c.head_size, Smax) + 256;
-        const size_t ctx = context_attention_workspace_size(B, c.num_heads, c.head_size, in[0].dims.d[1]) + 256;
+        const size_t ctx = context_attention_workspace_size(B, c.num_heads, c.head_size, S) + 256 + kCuBytes;
         return gen > ctx ? gen : ctx;
     }
 
@@ -207,8 +208,9 @@ public:
     {
         const int nin_expected = 8 + (c.int8_kv_cache ? 2 : 0);
         (void) nin_expected;
-        const int B = inDesc[0].dims.d[0];
-        const int S = inDesc[0].dims.d[1];
+        const bool packed = c.remove_input_padding != 0; // tokens of all sequences back to back (gptAttentionPlugin.cpp:344-356)
+        const int B = packed ? inDesc[5].dims.d[0] : inDesc[0].dims.d[0];
+        int S = packed ? 1 : inDesc[0].dims.d[1];
         const int Smax = inDesc[7].dims.d[2]; // max_seq_len from cache_indirection.shape[2] (gptAttentionPlugin.cpp:335)
         if (inDesc[1].dims.nbDims != 5 || inDesc[1].dims.d[3] != Smax || inDesc[1].dims.d[2] != c.num_heads
             || inDesc[1].dims.d[4] != c.head_size || inDesc[1].dims.d[1] != 2)
@@ -243,6 +245,20 @@ public:
         if (is_context)
         {
             ContextAttnParams p;
+            if (packed)
+            {
+                // row of (b, s) = cu[b] + s: prefix sum of the device-resident input_lengths at the head of the workspace
+                if (!ws || B + 1 > (int) (kCuBytes / 4))
+                {
+                    set_error("GPTAttention: packed inputs need the workspace (batch <= %d)", (int) (kCuBytes / 4) - 1);
+                    return 1;
+                }
+                S = max_input_len;
+                if (launch_exclusive_scan_i32(static_cast<int32_t*>(ws), static_cast<const int32_t*>(in[5]), B, stream))
+                    return 1;
+                p.cu_seqlens = static_cast<const int32_t*>(ws);
+                ws = static_cast<char*>(ws) + kCuBytes;
+            }
             p.batch = B;
             p.seq = S;
             p.num_heads = c.num_heads;

@@ -148,6 +148,10 @@ struct tllm_session
     Linear head;
     bool finalized = false;
     std::vector<int32_t> group;
+    bool packed = false;       // remove_input_padding: the context phase runs on the real tokens only
+    int ctx_tokens = 0;        // ... their number in the current prompt batch
+    int32_t* cu_dev = nullptr;    // [B + 1] exclusive prefix sum of the input lengths
+    int32_t* last_rows = nullptr; // [B] packed row of every sequence's last prompt token
     bool force_comm = false; // tests: run the TP collectives on a 1-rank communicator too (RCCL inside the captured graph)
 
     // ---- runtime state (setup)
@@ -439,7 +443,7 @@ struct tllm_session
     // ------------------------------------------------------------------------------------------ context step
     int run_context(hipStream_t st)
     {
-        const int S = max_in, M = B * S, D = hidden;
+        const int S = max_in, M = packed ? ctx_tokens : B * S, D = hidden;
         RUN(launch_embedding(x, ids_in, emb, M, D, vocab, st));
         for (int li = 0; li < num_layers; ++li)
         {
@@ -483,6 +487,7 @@ struct tllm_session
             c.rope_table_len = rope_len;
             c.out = ctx;
             c.workspace = ctx_ws;
+            c.cu_seqlens = packed ? cu_dev : nullptr;
             RUN(launch_context_attention(c, st));
             const void* d_in = ctx;
             if (sq)
@@ -556,7 +561,10 @@ struct tllm_session
             }
         }
         // head: last real token of every sequence -> ln_f -> lm_head -> fp32 logits  (Q/llama_model.py:272-279)
-        RUN(launch_gather_last_token(last_hidden, x, last_tok, B, S, D, st));
+        if (packed)
+            RUN(launch_gather_rows(last_hidden, x, last_rows, B, D, st));
+        else
+            RUN(launch_gather_last_token(last_hidden, x, last_tok, B, S, D, st));
         RUN(run_head(last_hidden, st));
         return 0;
     }
@@ -724,6 +732,7 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->quant_mode = geti("quant_mode", 0);
     s->neox = geti("neox_rotary_style", 1);
     s->force_comm = geti("force_comm", 0) != 0;
+    s->packed = geti("remove_input_padding", 0) != 0;
     if (kv.count("rms_norm_eps"))
         s->eps = (float) atof(kv["rms_norm_eps"].c_str());
     if (kv.count("weight_only_precision"))
@@ -958,6 +967,8 @@ int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_inp
     RUN(s->dalloc(&s->logits, (size_t) B * s->Vr * s->tp * 4));
     RUN(s->dalloc(&s->last_hidden, (size_t) B * D * 2));
     RUN(s->dalloc(&s->ctx_ws, context_attention_workspace_size(B, s->Hr, s->Dh, S) + 256));
+    RUN(s->dalloc(&s->cu_dev, (size_t) (B + 1) * 4));
+    RUN(s->dalloc(&s->last_rows, (size_t) B * 4));
     RUN(s->dalloc(&s->mmha_ws, mmha_workspace_size(B, s->Hr, s->Dh, Smax) + 256));
     HIP_OK(hipMemset(s->mmha_ws, 0, mmha_workspace_size(B, s->Hr, s->Dh, Smax) + 256));
     RUN(s->dalloc(&s->ids_in, M * 4));
@@ -1016,7 +1027,24 @@ static int upload_prompt(tllm_session_t s, const int32_t* input_ids, const int32
         for (int t = 0; t < S; ++t)
             out[(size_t) b * Smax + t] = input_ids[(size_t) b * S + t];
     }
-    HIP_OK(hipMemcpyAsync(s->ids_in, input_ids, (size_t) B * S * 4, hipMemcpyHostToDevice, st));
+    std::vector<int32_t> packed_ids, cu(B + 1, 0), last(B, 0);
+    if (s->packed)
+    {
+        // the real tokens back to back; generation keeps the padded cache layout (slots [len, max_in) masked), so only
+        // the context phase changes shape (generation.py:556-568 with remove_input_padding)
+        for (int b = 0; b < B; ++b)
+        {
+            cu[b + 1] = cu[b] + lens[b];
+            last[b] = cu[b + 1] - 1;
+            packed_ids.insert(packed_ids.end(), input_ids + (size_t) b * S, input_ids + (size_t) b * S + lens[b]);
+        }
+        s->ctx_tokens = cu[B];
+        HIP_OK(hipMemcpyAsync(s->ids_in, packed_ids.data(), packed_ids.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(s->cu_dev, cu.data(), cu.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(s->last_rows, last.data(), last.size() * 4, hipMemcpyHostToDevice, st));
+    }
+    else
+        HIP_OK(hipMemcpyAsync(s->ids_in, input_ids, (size_t) B * S * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(s->in_len, lens.data(), B * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(s->last_tok, lens.data(), B * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(s->seq_len, seq.data(), B * 4, hipMemcpyHostToDevice, st));

@@ -90,6 +90,7 @@ class Builder():
             'rms_norm_eps': cfg.get('rms_norm_eps', 1e-6), 'tp_size': cfg.get('tensor_parallel', 1),
             'tp_rank': cfg.get('tp_rank', 0), 'quant_mode': int(cfg.get('quant_mode', 0)),
             'neox_rotary_style': 1, 'precision': cfg['precision'],
+            'remove_input_padding': 1 if network.plugin_config.remove_input_padding else 0,
             'network_ops': ','.join(ops[:0]),  # the node list itself goes below as one JSON line
         }
         text = '\n'.join(f'{k}={v}' for k, v in header.items())

@@ -251,10 +251,11 @@ def rms_norm(input: Tensor, normalized_shape, weight: Optional[Tensor] = None, e
 
 def gather_last_token_logits(hidden_states: Tensor, last_token_ids: Tensor, remove_input_padding: bool) -> Tensor:
     """hidden[b, last_token_ids[b] - 1, :] (functional.py:3316-3380)."""
-    if remove_input_padding:
-        raise NotImplementedError('remove_input_padding is not built for the MI355X path')
-    out = _new(hidden_states.dtype, (hidden_states.shape[0], hidden_states.shape[-1]), 'last_token')
-    default_net().add_node('gather_last_token_logits', [hidden_states, last_token_ids], [out])
+    # packed inputs: hidden is [1, num_tokens, H] and last_token_ids holds inclusive prefix sums of the lengths
+    batch = last_token_ids.shape[0] if remove_input_padding else hidden_states.shape[0]
+    out = _new(hidden_states.dtype, (batch, hidden_states.shape[-1]), 'last_token')
+    default_net().add_node('gather_last_token_logits', [hidden_states, last_token_ids], [out],
+                           remove_input_padding=bool(remove_input_padding))
     return out
 
 

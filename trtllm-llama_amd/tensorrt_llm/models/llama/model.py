@@ -151,8 +151,7 @@ class LLaMAForCausalLM(LLaMAModel):
         beams = [1, (max_beam_width + 1) // 2, max_beam_width]
         inlen = [1, 1, max_input_len]
         lens = [0, (max_len + 1) // 2, max_len]
-        if default_net().plugin_config.remove_input_padding:
-            raise NotImplementedError('remove_input_padding is not built for the MI355X path')
+        remove_input_padding = default_net().plugin_config.remove_input_padding
         if not default_net().plugin_config.gpt_attention_plugin:
             raise ValueError('the LLaMA path needs plugin_config.set_gpt_attention_plugin() (RoPE lives in the plugin)')
         i32 = DataType.INT32
@@ -160,8 +159,14 @@ class LLaMAForCausalLM(LLaMAModel):
         def named(name, shape, ranges):
             return Tensor(name=name, dtype=i32, shape=shape, dim_range=OrderedDict(ranges))
 
-        input_ids = named('input_ids', [-1, -1], [('batch_size', [bb]), ('input_len', [inlen])])
-        position_ids = named('position_ids', [-1, -1], [('batch_size', [bb]), ('input_len', [inlen])])
+        if remove_input_padding:
+            # the real tokens of the whole batch back to back (llama_model.py:312-331)
+            ntok = [1, (max_input_len * max_batch_size + 1) // 2, max_input_len * max_batch_size]
+            input_ids = named('input_ids', [1, -1], [('batch_size_fake', [1]), ('num_tokens', [ntok])])
+            position_ids = named('position_ids', [1, -1], [('batch_size_fake', [1]), ('num_tokens', [ntok])])
+        else:
+            input_ids = named('input_ids', [-1, -1], [('batch_size', [bb]), ('input_len', [inlen])])
+            position_ids = named('position_ids', [-1, -1], [('batch_size', [bb]), ('input_len', [inlen])])
         past_key_value = []
         for i in range(self.num_layers):
             kv = Tensor(name=f'past_key_value_{i}', dtype=self.kv_dtype, shape=[-1, 2, num_heads, -1, head_size],
