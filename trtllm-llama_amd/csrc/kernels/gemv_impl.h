@@ -146,9 +146,12 @@ __device__ __forceinline__ float silu_mul_fp16(float g, float u)
 // registers (sum of squares -> ONE barrier -> normalise / quantise) -> LDS -> ONE barrier -> dots -> DPP reduction ->
 // epilogue.  Further tiles are double-buffered, with the next group's epilogue operands requested ahead of the next
 // tile so that waiting for them never drains the weight stream.
-template <int WT, int PK, int EK, int MB, int kNXV>
+template <int WT, int PK, int EK, int MB, int kNXV, int UU = tllm::kernels::gemv_detail::U>
 __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 {
+    // chunks per tile: 4, or 2 for rows of at most 2 KiB (int4 K = 4096): a 4-chunk tile would be half neutral elements -
+    // half the load slots, LDS reads and dequantisation arithmetic wasted
+    constexpr int U = UU;
     using TR = WTraits<WT>;
     constexpr int VEC = TR::VEC;
     constexpr bool SQ = TR::IS_SQ;
@@ -677,10 +680,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     }
 }
 
-template <int WT, int PK, int EK, int MB, int NXV>
+template <int WT, int PK, int EK, int MB, int NXV, int UU = U>
 int launch_inst(const GemvArgs& a, hipStream_t stream)
 {
-    auto kfn = gemv_kernel<WT, PK, EK, MB, NXV>;
+    auto kfn = gemv_kernel<WT, PK, EK, MB, NXV, UU>;
     const size_t smem = kRedBytes + (size_t) MB * a.Kp * (WT == W_INT8_SQ ? 1 : 2);
     if (smem > 160 * 1024)
     {
@@ -733,7 +736,12 @@ template <int WT, int PK, int EK, int NXV>
 int launch_mb(const GemvArgs& a, hipStream_t stream)
 {
     if (a.p.M <= 1)
+    {
+        if constexpr (WT == W_INT4_WOQ)
+            if (a.nchunks <= 2)
+                return launch_inst<WT, PK, EK, 1, NXV, 2>(a, stream);
         return launch_inst<WT, PK, EK, 1, NXV>(a, stream);
+    }
     if (a.p.M <= 2)
         return launch_inst<WT, PK, EK, 2, NXV>(a, stream);
     if (a.p.M <= 4)
