@@ -361,7 +361,9 @@ def test_kv_cache_append_bit_exact(int8_kv):
 
 
 @pytest.mark.parametrize('int8_kv', [0, 1])
-@pytest.mark.parametrize('H,Dh,S', [(4, 128, 90), (2, 32, 128), (4, 64, 33), (4, 128, 300), (2, 64, 257), (2, 128, 1024)])
+@pytest.mark.parametrize('H,Dh,S', [(4, 128, 90), (2, 32, 128), (4, 64, 33), (4, 128, 300), (2, 64, 257), (2, 128, 1024),
+                                    # block boundaries of the MFMA kernel (64-key blocks, 128-query workgroups) and n_positions
+                                    (2, 128, 64), (2, 128, 65), (2, 64, 127), (2, 128, 129), (1, 128, 2048)])
 def test_context_attention_vs_oracle(int8_kv, H, Dh, S):
     r = rng(200 + S)
     B, smax = 2, S + 8
