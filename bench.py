@@ -332,13 +332,20 @@ def main():
             raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    if os.environ.get('TLLM_TEST_SHARED_GPU') == '1':
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if os.environ.get('TLLM_TEST_SHARED_GPU') == '1':
+            # test rig (tests/test_bench_multirank.py): N ranks share GPU 0, gloo carries torch.distributed, the library's
+            # peer-to-peer transport carries the model's collectives - exercises this file's N > 1 flow on a 1-GPU box
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         # TP communicator for the plugin library: rank 0's RCCL unique id -> everyone (replaces the MPI bootstrap), then
         # the one-shot peer-to-peer all-reduce if - and only if - it reproduces RCCL's sums on this node
         from tensorrt_llm import Mapping

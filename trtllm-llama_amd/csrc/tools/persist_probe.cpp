@@ -303,6 +303,23 @@ int main(int argc, char** argv)
         printf("A' phase %d alone (%6.1f MB)              : %7.2f us/launch %6.0f GB/s\n", p, sz[p] / 1e6, us, sz[p] / us / 1e3);
     }
 
+    // (A' eager) the same launches issued one by one from the host (what the microbench and tllm_session_time_kernel time)
+    for (int p = 0; p < 5; ++p)
+    {
+        for (int rep = 0; rep < 2; ++rep)
+        {
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i)
+                for (int l = 0; l < L; ++l)
+                    hipLaunchKernelGGL(phase_kernel, dim3(1024), dim3(256), 0, st, hl[l].ph[p], xb + (l & 1) * 256, xb + ((l & 1) ^ 1) * 256);
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+        }
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / iters / L;
+        printf("A' phase %d alone, eager launches         : %7.2f us/launch %6.0f GB/s\n", p, us, sz[p] / us / 1e3);
+    }
+
     // (A'') structural pieces of the real kernel added to the pure stream, phase sizes 0 (50.8 MB) and 4 (45.4 MB)
     for (int mode : {0, 1, 4, 5})
         for (int p : {0, 4})
