@@ -318,3 +318,35 @@ def test_packed_context_equals_padded(mode, int8_kv):
     # GEMM rows are computed independently of how many rows there are -> the same bits
     np.testing.assert_array_equal(logits[0], logits[1])
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_end_id_stops_a_sequence_and_leaves_the_others_alone():
+    """Stop criteria on the device (K/stopCriteriaKernels.cu, generation.py:943-983): once a sequence emits end_id it keeps
+    emitting end_id, the other sequences of the batch continue exactly as without a stop token, and generate() returns as
+    soon as every sequence has finished."""
+    cfg, w = synth_model(61)
+    r = np.random.default_rng(23)
+    B, S, NEW = 3, 10, 40
+    lens = np.array([10, 6, 8], np.int32)
+    ids = np.full((B, S), 2, np.int32)
+    for b in range(B):
+        ids[b, :lens[b]] = r.integers(3, cfg['vocab_size'], lens[b])
+    s = NativeSession(dict(cfg, quant_mode=0))
+    for k, v in w.items():
+        s.set_tensor(k, v)
+    s.finalize()
+    s.setup(B, S, NEW)
+    free = s.generate(ids, lens, NEW, end_id=-1)[:, S:]
+    # a token sequence 0 emits at step 5 and that did not occur earlier in that sequence
+    k = next(i for i in range(3, NEW) if free[0, i] not in free[0, :i])
+    end_id = int(free[0, k])
+    s.setup(B, S, NEW)
+    stopped = s.generate(ids, lens, NEW, end_id=end_id)[:, S:]
+    s.close()
+    np.testing.assert_array_equal(stopped[0, :k + 1], free[0, :k + 1])
+    assert (stopped[0, k:] == end_id).all()
+    for b in (1, 2):
+        hit = np.where(free[b] == end_id)[0]
+        upto = NEW if len(hit) == 0 else hit[0] + 1
+        np.testing.assert_array_equal(stopped[b, :upto], free[b, :upto])
+        assert (stopped[b, upto:] == end_id).all()
