@@ -181,7 +181,9 @@ def test_smooth_quant_gemm_fp32_view_weight():
 
 # ---------------------------------------------------------------------------------------------- weight-only
 @pytest.mark.parametrize('bits', [8, 4])
-@pytest.mark.parametrize('m,n,k', [(1, 1024, 4096), (3, 4096, 4096), (1, 4096, 11008), (24, 512, 1024)])
+@pytest.mark.parametrize('m,n,k', [(1, 1024, 4096), (3, 4096, 4096), (1, 4096, 11008), (24, 512, 1024),
+                                    # prefill sizes: the fp16-expansion + LDS-DMA MFMA path (M >= 32), ragged M / N
+                                    (300, 456, 1152), (64, 1024, 4096)])
 def test_weight_only_quant_matmul(bits, m, n, k):
     torch.manual_seed(0)
     w = (torch.rand(k, n) * 2 - 1).half()  # [in, out], as the loaders pass it

@@ -257,6 +257,11 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
     {
         const int col = wave_n0 + j * 32 + (lane & 31);
         sc[j] = 1.f;
+        if constexpr (!SQ)
+        {
+            if (p.scale_col) // weight-only: integers expanded to fp16, fp16 scale per output channel
+                sc[j] = h2f(reinterpret_cast<const uint16_t*>(p.scale_col)[col < N ? col : N - 1]);
+        }
         if constexpr (SQ)
             sc[j] = p.per_channel ? reinterpret_cast<const float*>(p.scale_col)[col < N ? col : N - 1]
                                   : reinterpret_cast<const float*>(p.scale_col)[0];
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
                         v = (float) acc[i][j][r] * (sc[j] * sr);
                     }
                     else
-                        v = acc[i][j][r];
+                        v = acc[i][j][r] * sc[j];
                     *reinterpret_cast<uint16_t*>(scr + rr * PITCH + (j * 32 + (lane & 31)) * 2) = f2h(v);
                 }
             // 32 rows x (NT * 4) 16-byte pieces
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
                 }
                 else
                 {
-                    const float v = acc[i][j][r];
+                    const float v = acc[i][j][r] * sc[j];
                     if (p.out_dtype == DT_HALF)
                         reinterpret_cast<uint16_t*>(p.c)[o] = f2h(v);
                     else

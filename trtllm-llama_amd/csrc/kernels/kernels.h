@@ -224,8 +224,12 @@ struct GemmParams
     void* c = nullptr;
     int64_t ldc = 0;
     const void* residual = nullptr; // optional fp16 [M, ldc]: C = fp16(fp16(gemm) + residual) (may alias c); fp16 output only
+    // weight-only types at M >= 32: scratch of gemm_woq_scratch_bytes(N, K) bytes lets the GEMM expand the integers to
+    // fp16 once (exact) and run the LDS-DMA staged fp16 kernel with the per-channel scale in its epilogue
+    void* scratch = nullptr;
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);
+size_t gemm_woq_scratch_bytes(int32_t N, int32_t K);
 
 // One-shot peer-to-peer sum all-reduce of an fp16 vector, in place (kernels/p2p_allreduce.hip; plugins/p2p.cpp owns the
 // inboxes).  peer[r]: base of rank r's region as mapped in THIS process: [2 gens][world][slot_bytes] data, then flags.

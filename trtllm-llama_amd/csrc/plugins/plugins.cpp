@@ -557,6 +557,13 @@ public:
             return io[pos].type == TLLM_FLOAT || io[pos].type == TLLM_INT8;
         return io[pos].type == type_id;
     }
+    size_t workspaceSize(const Desc* in, int nin, const Desc* out, int nout) const override
+    {
+        // prefill-sized calls expand the integers to fp16 once (kernels/gemm.hip): room for [N, K] halfs
+        const int64_t M = rows_of(in[0].dims);
+        const int K = in[0].dims.d[in[0].dims.nbDims - 1];
+        return M >= 32 ? gemm_woq_scratch_bytes(n_of(in[1].dims, in[1].type), K) : 0;
+    }
     int enqueue(const Desc* inDesc, const Desc* outDesc, const void* const* in, void* const* out, void* ws,
         hipStream_t stream) override
     {
@@ -588,6 +595,7 @@ public:
         g.scale_col = in[2];
         g.c = out[0];
         g.ldc = N;
+        g.scratch = M >= 32 ? ws : nullptr;
         return launch_gemm(g, stream) ? 1 : 0;
     }
     void serialize(Writer& w) const override

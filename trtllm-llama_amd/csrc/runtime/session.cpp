@@ -163,6 +163,7 @@ struct tllm_session
     float* logits = nullptr; // [B, V] (or gathered [tp, B, Vr])
     float* logits_local = nullptr;
     void* last_hidden = nullptr;
+    void* woq_scratch = nullptr;
     void* mmha_ws = nullptr;
     void* ctx_ws = nullptr; // V^T scratch of the MFMA context attention
     int32_t *ids_in = nullptr, *cur_ids = nullptr, *out_ids = nullptr, *seq_len = nullptr, *in_len = nullptr,
@@ -413,6 +414,7 @@ struct tllm_session
     {
         GemmParams g;
         g.residual = residual;
+        g.scratch = woq_scratch; // weight-only prefill: room for the fp16 expansion of the largest weight matrix
         g.wtype = L.wtype;
         g.out_dtype = out_dtype;
         g.M = M;
@@ -967,6 +969,14 @@ int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_inp
     RUN(s->dalloc(&s->logits, (size_t) B * s->Vr * s->tp * 4));
     RUN(s->dalloc(&s->last_hidden, (size_t) B * D * 2));
     RUN(s->dalloc(&s->ctx_ws, context_attention_workspace_size(B, s->Hr, s->Dh, S) + 256));
+    if (s->woq && B * S >= 32)
+    {
+        size_t mx = 0;
+        for (auto& L : s->layers)
+            for (const Linear* l : {&L.qkv, &L.dense, &L.fc, &L.gate, &L.proj})
+                mx = std::max(mx, gemm_woq_scratch_bytes(l->N, l->K));
+        RUN(s->dalloc(&s->woq_scratch, mx));
+    }
     RUN(s->dalloc(&s->cu_dev, (size_t) (B + 1) * 4));
     RUN(s->dalloc(&s->last_rows, (size_t) B * 4));
     RUN(s->dalloc(&s->mmha_ws, mmha_workspace_size(B, s->Hr, s->Dh, Smax) + 256));
