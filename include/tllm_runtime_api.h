@@ -52,6 +52,32 @@ tllm_session_t tllm_session_load_engine(const void* engine, size_t nbytes);
  * [B, 2, H/tp, max_input_len + max_new_tokens, Dh] (fp16 or int8), activations and the RoPE table. */
 int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_input_len, int32_t max_new_tokens);
 
+/* The same with beam search (SamplingConfig.num_beams > 1, generation.py:365-411, 823-866): batch_size prompts, beam_width
+ * hypotheses each (1 <= beam_width <= 8, batch_size * beam_width <= 8 for the generation kernels).  The KV cache holds
+ * batch_size * beam_width sequences; the prompt's K/V is stored once per batch entry (in hypothesis 0's rows) and reached by
+ * the others through the cache indirection [batch_size * beam_width, max_seq_len] (value = sibling hypothesis whose rows
+ * hold that time step), which the device-side beam step re-parents every step - the reference's src/tgt
+ * cache_indirection pair (gptAttention plugin input, decoderMaskedMultiheadAttentionTemplate.h:1137-1146) in one buffer.
+ * Selection rule of the reference's dynamic decoder without beam_hyps (onlineSoftmaxBeamsearchKernels.cu): the
+ * beam_width best cum_log_prob + log_softmax(logits) over (hypothesis, token); a finished hypothesis continues with
+ * end_id at unchanged score.  tllm_session_generate then returns [batch_size, beam_width, max_seq_len]. */
+int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t beam_width, int32_t max_input_len,
+    int32_t max_new_tokens);
+
+/* gather_tree (decodingKernels.cu:30-171; generation.py:990-994): ids HOST int32 [batch_size, beam_width, max_seq_len], the
+ * back-tracked hypotheses, best first; cum_log_probs HOST float [batch_size, beam_width] or NULL.  After the first end_id
+ * and beyond the current length the row is filled with end_id.  With beam_width 1 it is tllm_session_get_output_ids. */
+int32_t tllm_session_get_beam_output(tllm_session_t s, int32_t* ids, float* cum_log_probs, tllm_stream_t stream);
+
+/* The device-side beam bookkeeping, for tests and debugging (any pointer may be NULL): parent_ids and cache_indirection
+ * HOST int32 [batch_size * beam_width, max_seq_len] (generation.py:387-391, 823-837), finished and sequence_lengths
+ * HOST int32 [batch_size * beam_width]. */
+int32_t tllm_session_get_beam_state(tllm_session_t s, int32_t* parent_ids, int32_t* cache_indirection, int32_t* finished,
+    int32_t* sequence_lengths, tllm_stream_t stream);
+
+/* Rows the last logits hold (tllm_session_get_logits): batch_size after the prompt, batch_size * beam_width after a step. */
+int32_t tllm_session_logit_rows(tllm_session_t s);
+
 /* GenerationSession.decode (generation.py:782-997), greedy (top-k = 1): context step on the padded prompts,
  * then up to max_new_tokens generation steps with the sampler on device and no per-step host sync
  * (the reference syncs every step, generation.py:963).

@@ -272,7 +272,8 @@ def attention_plugin(H, Dh, int8_kv, rot=None, neox=1, packed=0):
     ])
 
 
-def run_attention(p, qkv, cache, seq_len, past_len, is_context, masked, in_len, max_in, smax, scales=None):
+def run_attention(p, qkv, cache, seq_len, past_len, is_context, masked, in_len, max_in, smax, scales=None,
+                  cache_indirection=None):
     B = qkv.shape[0]
     out = torch.empty(qkv.shape[:-1] + (qkv.shape[-1] // 3, ), dtype=torch.float16, device='cuda')
     ins = [qkv, cache, torch.tensor(seq_len, dtype=torch.int32, device='cuda'),
@@ -285,6 +286,8 @@ def run_attention(p, qkv, cache, seq_len, past_len, is_context, masked, in_len, 
     dummy = torch.zeros(max(max_in, B * smax), dtype=torch.int32, device='cuda')
     ins[6] = dummy[:max_in]
     ins[7] = dummy[:B * smax].view(B, 1, smax)
+    if cache_indirection is not None:  # int32 [batch, beam_width, smax]
+        ins[7] = torch.from_numpy(np.ascontiguousarray(cache_indirection, dtype=np.int32)).cuda()
     if scales is not None:
         ins += [torch.tensor([scales[0]], dtype=torch.float32, device='cuda'),
                 torch.tensor([scales[1]], dtype=torch.float32, device='cuda')]
@@ -332,6 +335,51 @@ def test_mmha_decode_vs_oracle(int8_kv, H, Dh, L):
     else:
         np.testing.assert_allclose(got[:, :, :, L].astype(np.float32), ref_cache[:, :, :, L].astype(np.float32),
                                    atol=2e-4, rtol=2e-3)  # KV tolerance of test_gpt_attention.py:561-578 (+1 ulp)
+
+
+@pytest.mark.parametrize('int8_kv', [0, 1])
+@pytest.mark.parametrize('H,Dh,L,W', [(4, 128, 200, 3), (2, 64, 37, 2), (4, 128, 1023, 4)])
+def test_mmha_decode_beam_cache_indirection(int8_kv, H, Dh, L, W):
+    """Beam search generation step (P/gptAttentionPlugin/gptAttentionPlugin.cpp:330-336, MM/...Template.h:1137-1146,
+    1624-1631): sequence b * W + k reads time step t from the cache rows of sequence b * W + cache_indirection[b, k, t];
+    the new token's K/V go to the sequence's own rows."""
+    r = rng(300 + L)
+    batch, smax = 2, 1152
+    B = batch * W
+    max_in = L - 3
+    in_len = np.repeat([max_in, max_in // 2], W).tolist()
+    masked = np.zeros((B, smax), dtype=np.int32)
+    masked[W:, in_len[W]:max_in] = 1
+    kv_scale = 0.05
+    scales = (1.0 / kv_scale, kv_scale) if int8_kv else None
+    past = r.standard_normal((B, 2, H, smax, Dh)).astype(np.float32)
+    past[:, :, :, L:] = 0
+    cache_np = O.rni_sat_i8(past * np.float32(scales[0])) if int8_kv else past.astype(np.float16)
+    cache = torch.from_numpy(cache_np.copy()).cuda()
+    ci = r.integers(0, W, (batch, W, smax)).astype(np.int32)
+    qkv = h(r.standard_normal((B, 1, 3 * H * Dh)))
+    p = attention_plugin(H, Dh, int8_kv)
+    out = run_attention(p, qkv, cache, [L] * B, L, False, masked, in_len, max_in, smax, scales, cache_indirection=ci)
+    # the oracle sees, per sequence, the cache its indirection row selects
+    eff = np.empty_like(cache_np)
+    for bb in range(B):
+        b, k = divmod(bb, W)
+        src = b * W + ci[b, k]  # [smax]
+        eff[bb] = cache_np[src, :, :, np.arange(smax)].transpose(1, 2, 0, 3)
+    ref_cache = eff.copy()
+    ref = O.mmha_decode(as_f32(qkv)[:, 0], ref_cache, [L] * B, in_len, max_in, L, H, Dh, Dh, True, 1.0, masked,
+                        scales[0] if scales else None, scales[1] if scales else None)
+    np.testing.assert_allclose(as_f32(out)[:, 0], ref, atol=2e-3, rtol=0)
+    got = cache.cpu().numpy()
+    keep = np.ones(smax, dtype=bool)
+    keep[L] = False
+    np.testing.assert_array_equal(got[:, :, :, keep], cache_np[:, :, :, keep])  # siblings' rows untouched
+    if int8_kv:
+        d = np.abs(got[:, :, :, L].astype(np.int32) - ref_cache[:, :, :, L].astype(np.int32))
+        assert d.max() <= 1 and np.mean(d == 0) > 0.98
+    else:
+        np.testing.assert_allclose(got[:, :, :, L].astype(np.float32), ref_cache[:, :, :, L].astype(np.float32),
+                                   atol=2e-4, rtol=2e-3)
 
 
 @pytest.mark.parametrize('int8_kv', [0, 1])

@@ -140,9 +140,9 @@ __global__ void rope_kv_write_kernel(const ContextAttnParams p)
     {
         const int esz = p.int8_kv ? 1 : 2;
         char* kc = reinterpret_cast<char*>(p.kv_cache)
-            + (((int64_t) (b * 2 + 0) * H + h) * p.max_seq_len + s) * DH * esz + li * 8 * esz;
+            + (((int64_t) (b * p.cache_seq_stride * 2 + 0) * H + h) * p.max_seq_len + s) * DH * esz + li * 8 * esz;
         char* vc = reinterpret_cast<char*>(p.kv_cache)
-            + (((int64_t) (b * 2 + 1) * H + h) * p.max_seq_len + s) * DH * esz + li * 8 * esz;
+            + (((int64_t) (b * p.cache_seq_stride * 2 + 1) * H + h) * p.max_seq_len + s) * DH * esz + li * 8 * esz;
         if (p.int8_kv)
         {
             const float sc = p.kv_scale_orig_quant[0];

@@ -159,6 +159,10 @@ struct MmhaParams
     const float* rope_row = nullptr; // optional f32 [B, rotary_dim/2, 2]: this step's cos/sin row, prepared on the
                                      // device by the sampler (removes the length -> position -> table dependency)
     int32_t rows_per_group = 0;      // cache rows per lane group and split: 4 (default, finest split) or 16
+    // beam search (MM/...Template.h:1137-1146, :1624-1631): `batch` counts batch x beam sequences; sequence bb = b * beam_width
+    // + k reads the K/V of timestep t from the cache rows of sequence b * beam_width + cache_indirection[bb, t]
+    const int32_t* cache_indirection = nullptr; // int32 [batch, max_seq_len]
+    int32_t beam_width = 1;
     int32_t skip_combine = 0;        // 1: leave the split partials in the workspace (the consumer merges them:
                                      // GemvParams::attn_*), no combine launch
     void* out = nullptr;       // fp16 [B, H*Dh]
@@ -198,6 +202,9 @@ struct ContextAttnParams
     // packed inputs (remove_input_padding, P/gptAttentionPlugin/gptAttentionPlugin.cpp:344-356): qkv / out hold only the real
     // tokens, [sum(len), ...]; token s of sequence b is row cu_seqlens[b] + s.  `seq` stays the longest sequence (grid bound).
     const int32_t* cu_seqlens = nullptr; // device int32 [B + 1], exclusive prefix sum of input_lengths
+    // beam search: prompt b fills the cache rows of sequence b * cache_seq_stride (hypothesis 0 of its beam group; the
+    // siblings reach those rows through the cache indirection, so the prompt's K/V is stored once)
+    int32_t cache_seq_stride = 1;
 };
 size_t context_attention_workspace_size(int batch, int num_heads, int head_size, int seq);
 // cu[0] = 0, cu[b + 1] = cu[b] + lens[b]  (device, one tiny launch; packed-input bookkeeping)
@@ -275,6 +282,35 @@ struct GreedyParams
     int32_t max_input_len = 0;
 };
 int launch_greedy_step(const GreedyParams& p, hipStream_t stream);
+
+// One beam-search step on the device (K/onlineSoftmaxBeamsearchKernels.cu, layers/onlineBeamSearchLayer.cu; called at
+// PY/runtime/generation.py:949-961 with beam_width > 1).  Per batch entry, over its `beam` hypotheses:
+//   score(k, v) = cum_log_probs[k] + log_softmax(logits[k])[v]      (a finished hypothesis only continues with end_id, score kept)
+//   the `beam` best (k, v) in score order (ties: lowest k * vocab + v) become the new hypotheses j: token v, parent k;
+//   cache_indirection[j, s] <- cache_indirection[parent, s] for every used slot s, and the slot the consumed token's K/V
+//   went to <- parent;  out_ids / parent_ids[j, slot] record the step for the final back-track (gather_tree).
+// Bookkeeping (sequence length, current ids, next RoPE row) as launch_greedy_step.
+struct BeamParams
+{
+    const float* logits = nullptr; // [nparts, batch * beam, vocab_part]  ([nparts, batch, vocab_part] if logits_per_batch)
+    int32_t logits_per_batch = 0;  // first step after the prompt: one logits row per batch entry, shared by its hypotheses
+    int32_t batch = 0, beam = 1, vocab_part = 0, nparts = 1, vocab = 0;
+    float* cum_log_probs = nullptr; // [batch * beam]
+    int32_t* cur_ids = nullptr;
+    int32_t* out_ids = nullptr;    // [batch * beam, out_stride]
+    int32_t* parent_ids = nullptr; // [batch * beam, out_stride]
+    int32_t out_stride = 0;
+    int32_t* seq_len = nullptr;
+    int32_t* finished = nullptr;
+    int32_t end_id = -1, advance = 0;
+    int32_t* cache_indirection = nullptr; // [batch * beam, out_stride]
+    float* rope_row_out = nullptr;
+    const float* rope_table = nullptr;
+    int32_t rope_half = 0, rope_table_len = 0;
+    const int32_t* input_lengths = nullptr;
+    int32_t max_input_len = 0;
+};
+int launch_beam_step(const BeamParams& p, hipStream_t stream);
 
 // deterministic pseudo-random fill (fp16 ~U(-scale, scale) or int8 ~U[-127,127]) for synthetic KV caches
 int launch_fill_random(void* dst, int32_t dtype, int64_t n, uint32_t seed, float scale, hipStream_t stream);

@@ -95,7 +95,7 @@ __device__ __forceinline__ uint2 quant8(const uint4& v, float s)
 }
 
 // ---- kernel 1: one workgroup per (split, head, batch) -> partial {max, sum, out[DH]} in the workspace
-template <int DH, int NIT, bool INT8KV>
+template <int DH, int NIT, bool INT8KV, bool BEAM>
 __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, float2* ws_ml, float* ws_o, int nsplit_max)
 {
     using G = MmhaGeom<DH, NIT>;
@@ -114,13 +114,27 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
     // ---- 1. request the cache rows: nothing below is needed to form their addresses (rows at or beyond the
     //         current length are loaded too - the buffer has Smax rows - and dropped by the validity mask)
     uint4 kreg[NIT], vreg[NIT];
+    // beam search: timestep t of this hypothesis lives in the cache rows of a sibling (cache_indirection); the row
+    // strides between siblings are whole (batch, 2, H, Smax, DH) sequences
+    int64_t sib[NIT];
+    if constexpr (BEAM)
+    {
+        const int32_t* ci = p.cache_indirection + (int64_t) b * Smax;
+        const int64_t seq_bytes = (int64_t) 2 * H * Smax * DH * ESZ;
+        const int k_own = b % p.beam_width;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+            sib[i] = (int64_t) (ci[min(t0 + i * NGRP + gid, Smax - 1)] - k_own) * seq_bytes;
+    }
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
     {
         // no branches around the loads (a divergent `if` makes the compiler drain the queue at every one):
         // out-of-range rows read the last row of the buffer and are masked out by `valid` below
         const int t = min(t0 + i * NGRP + gid, Smax - 1);
-        const int64_t off = ((int64_t) t * DH + li * 8) * ESZ;
+        int64_t off = ((int64_t) t * DH + li * 8) * ESZ;
+        if constexpr (BEAM)
+            off += sib[i];
         if constexpr (INT8KV)
         {
             const uint2 k8 = *reinterpret_cast<const uint2*>(kbase + off);
@@ -443,10 +457,15 @@ int launch_nit(const MmhaParams& p, hipStream_t stream)
     const size_t ml_bytes = ((size_t) p.batch * p.num_heads * ns * sizeof(float2) + 255) / 256 * 256;
     float* ws_o = reinterpret_cast<float*>(ws + ml_bytes);
     dim3 grid(ns, p.num_heads, p.batch);
-    if (p.int8_kv)
-        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, true>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
+    const bool beam = p.beam_width > 1 && p.cache_indirection;
+    if (p.int8_kv && beam)
+        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, true, true>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
+    else if (p.int8_kv)
+        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, true, false>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
+    else if (beam)
+        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, false, true>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
     else
-        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, false>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
+        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, false, false>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
     if (!p.skip_combine)
         hipLaunchKernelGGL((mmha_combine_kernel<DH, NIT>), dim3(p.num_heads, p.batch), dim3(256), 0, stream, p, ws_ml, ws_o, ns);
     hipError_t e = hipGetLastError();

@@ -493,6 +493,164 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const GreedyParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Beam search step (see BeamParams in kernels.h).  One workgroup of 1024 threads per batch entry.
+// Dynamic LDS: the cache-indirection rows being re-parented, [beam][used slots] int32.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void beam_step_kernel(const BeamParams p)
+{
+    constexpr int MAXW = 8;
+    extern __shared__ int32_t ci_stage[];
+    __shared__ float red[32];
+    __shared__ int redi[32];
+    __shared__ float s_lse[MAXW], s_cum[MAXW], s_score[MAXW];
+    __shared__ int s_fin[MAXW], s_idx[MAXW];
+    const int b = blockIdx.x, W = p.beam, V = p.vocab, tid = threadIdx.x, bb0 = b * W;
+    const int nrows = p.logits_per_batch ? p.batch : p.batch * W;
+    auto logit = [&](int k, int v) -> float {
+        const int part = v / p.vocab_part, vi = v % p.vocab_part;
+        return p.logits[((int64_t) part * nrows + (p.logits_per_batch ? b : bb0 + k)) * p.vocab_part + vi];
+    };
+    if (tid < W)
+    {
+        s_cum[tid] = p.cum_log_probs[bb0 + tid];
+        s_fin[tid] = p.finished ? p.finished[bb0 + tid] : 0;
+    }
+    __syncthreads();
+    // ---- 1. log-sum-exp of every live hypothesis
+    for (int k = 0; k < W; ++k)
+    {
+        if (s_fin[k]) // uniform
+            continue;
+        float mx = -INFINITY;
+        for (int v = tid; v < V; v += blockDim.x)
+            mx = fmaxf(mx, logit(k, v));
+        mx = block_max(mx, red);
+        float sm = 0.f;
+        for (int v = tid; v < V; v += blockDim.x)
+            sm += __expf(logit(k, v) - mx);
+        sm = block_sum(sm, red);
+        if (tid == 0)
+            s_lse[k] = mx + __logf(sm);
+        __syncthreads();
+    }
+    // ---- 2. the W best (hypothesis, token) pairs, best first; ties -> lowest k * V + v
+    for (int j = 0; j < W; ++j)
+    {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        auto consider = [&](float sc, int idx) {
+            if (sc > best || (sc == best && idx < bi))
+            {
+                bool taken = false;
+                for (int q = 0; q < j; ++q)
+                    taken = taken || s_idx[q] == idx;
+                if (!taken)
+                {
+                    best = sc;
+                    bi = idx;
+                }
+            }
+        };
+        for (int k = 0; k < W; ++k)
+        {
+            if (s_fin[k])
+            {
+                // a finished hypothesis stays as it is: one candidate, end_id, at its score
+                if (tid == 0 && p.end_id >= 0)
+                    consider(s_cum[k], k * V + p.end_id);
+                continue;
+            }
+            const float base = s_cum[k] - s_lse[k];
+            for (int v = tid; v < V; v += blockDim.x)
+                consider(logit(k, v) + base, k * V + v);
+        }
+        // block arg-max
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+        {
+            const float ov = __shfl_xor(best, m, 64);
+            const int oi = __shfl_xor(bi, m, 64);
+            if (ov > best || (ov == best && oi < bi))
+            {
+                best = ov;
+                bi = oi;
+            }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0)
+        {
+            red[tid >> 6] = best;
+            redi[tid >> 6] = bi;
+        }
+        __syncthreads();
+        if (tid == 0)
+        {
+            for (int w = 1; w < (int) (blockDim.x >> 6); ++w)
+                if (red[w] > best || (red[w] == best && redi[w] < bi))
+                {
+                    best = red[w];
+                    bi = redi[w];
+                }
+            if (bi == 0x7fffffff) // every remaining candidate is -inf (fewer live candidates than beams): repeat the best
+            {
+                bi = j > 0 ? s_idx[0] : 0;
+                best = j > 0 ? s_score[0] : -INFINITY;
+            }
+            s_idx[j] = bi;
+            s_score[j] = best;
+        }
+        __syncthreads();
+    }
+    // ---- 3. re-parent the cache indirection: stage the parents' rows, then write them to the children
+    const int sl_old = p.seq_len[bb0];
+    const int sl_new = sl_old + (p.advance ? 1 : 0);
+    const int used = p.advance ? sl_old : sl_new; // slots whose K/V exist before this step's token: [0, used)
+    int32_t* ci = p.cache_indirection;
+    if (ci)
+    {
+        for (int i = tid; i < W * used; i += blockDim.x)
+        {
+            const int j = i / used, sidx = i % used;
+            ci_stage[i] = ci[(int64_t) (bb0 + s_idx[j] / V) * p.out_stride + sidx];
+        }
+        __syncthreads();
+        for (int i = tid; i < W * used; i += blockDim.x)
+        {
+            const int j = i / used, sidx = i % used;
+            ci[(int64_t) (bb0 + j) * p.out_stride + sidx] = ci_stage[i];
+        }
+        // the token consumed by this step put its K/V into the parent's rows at slot sl_old
+        if (p.advance && tid < W && sl_old < p.out_stride)
+            ci[(int64_t) (bb0 + tid) * p.out_stride + sl_old] = s_idx[tid] / V;
+    }
+    // ---- 4. bookkeeping of the new hypotheses
+    if (tid < W)
+    {
+        const int j = tid, parent = s_idx[j] / V, tok = s_idx[j] % V;
+        const int fin = s_fin[parent] || (p.end_id >= 0 && tok == p.end_id);
+        p.cum_log_probs[bb0 + j] = s_score[j];
+        if (p.finished)
+            p.finished[bb0 + j] = fin;
+        p.seq_len[bb0 + j] = sl_new;
+        p.cur_ids[bb0 + j] = tok;
+        if (sl_new < p.out_stride)
+        {
+            p.out_ids[(int64_t) (bb0 + j) * p.out_stride + sl_new] = tok;
+            p.parent_ids[(int64_t) (bb0 + j) * p.out_stride + sl_new] = parent;
+        }
+    }
+    if (p.rope_row_out)
+    {
+        // next step's RoPE row, the same position for every hypothesis of this batch entry
+        int pos = sl_new - (p.max_input_len - p.input_lengths[bb0]);
+        pos = pos < 0 ? 0 : (pos >= p.rope_table_len ? p.rope_table_len - 1 : pos);
+        for (int i = tid; i < W * p.rope_half; i += blockDim.x)
+            reinterpret_cast<float2*>(p.rope_row_out)[(int64_t) bb0 * p.rope_half + i]
+                = reinterpret_cast<const float2*>(p.rope_table)[(int64_t) pos * p.rope_half + i % p.rope_half];
+    }
+}
+
 __device__ __forceinline__ uint32_t hash32(uint32_t x)
 {
     x ^= x >> 16;
@@ -722,6 +880,31 @@ int launch_greedy_step(const GreedyParams& p, hipStream_t stream)
         return 0;
     hipLaunchKernelGGL(greedy_step_kernel, dim3(p.batch), dim3(1024), 0, stream, p);
     return check_launch("greedy_step");
+}
+
+int launch_beam_step(const BeamParams& p, hipStream_t stream)
+{
+    if (p.batch <= 0)
+        return 0;
+    if (p.beam < 1 || p.beam > 8 || !p.cum_log_probs || !p.parent_ids || !p.cache_indirection)
+    {
+        set_error("beam step: beam width %d out of [1, 8] or missing state buffers", p.beam);
+        return -1;
+    }
+    const size_t smem = (size_t) p.beam * p.out_stride * sizeof(int32_t);
+    if (smem > 96 * 1024)
+    {
+        set_error("beam step: beam %d x %d slots does not fit the staging buffer", p.beam, p.out_stride);
+        return -1;
+    }
+    static bool attr_done = false;
+    if (!attr_done)
+    {
+        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(beam_step_kernel, dim3(p.batch), dim3(1024), smem, stream, p);
+    return check_launch("beam_step");
 }
 
 int launch_fill_random(void* dst, int32_t dtype, int64_t n, uint32_t seed, float scale, hipStream_t stream)

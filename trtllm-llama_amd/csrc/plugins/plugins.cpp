@@ -218,9 +218,12 @@ public:
             set_error("GPTAttention: past_key_value must be [B,2,H,Smax,Dh] with Smax = cache_indirection.shape[2]");
             return 1;
         }
-        if (inDesc[7].dims.d[1] != 1)
+        // cache_indirection [batch, beam_width, max_seq_len] (gptAttentionPlugin.cpp:330-336): in the generation phase the
+        // B = batch * beam_width sequences read time step t from sibling cache_indirection[b, k, t]'s cache rows
+        const int beam_width = inDesc[7].dims.d[1];
+        if (beam_width < 1 || beam_width > 8)
         {
-            set_error("GPTAttention: beam search (cache_indirection beam width > 1) not built");
+            set_error("GPTAttention: beam width %d (cache_indirection.shape[1]) outside [1, 8]", beam_width);
             return 1;
         }
         if (in[1] != out[1])
@@ -299,6 +302,16 @@ public:
         p.input_lengths = static_cast<const int32_t*>(in[5]);
         p.masked_tokens = static_cast<const int32_t*>(in[4]);
         p.timestep_host = past_len;
+        if (beam_width > 1)
+        {
+            if (inDesc[7].dims.d[0] * beam_width != B)
+            {
+                set_error("GPTAttention: %d sequences but cache_indirection is [%d, %d, ...]", B, inDesc[7].dims.d[0], beam_width);
+                return 1;
+            }
+            p.cache_indirection = static_cast<const int32_t*>(in[7]);
+            p.beam_width = beam_width;
+        }
         if (c.int8_kv_cache)
         {
             p.kv_scale_orig_quant = static_cast<const float*>(in[8]);

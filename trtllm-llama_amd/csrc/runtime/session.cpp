@@ -156,6 +156,11 @@ struct tllm_session
 
     // ---- runtime state (setup)
     int B = 0, max_in = 0, max_new = 0, Smax = 0;
+    // beam search: Bc prompts, `beam` hypotheses each; B = Bc * beam sequences in the generation phase (B == Bc otherwise)
+    int Bc = 0, beam = 1;
+    int logit_rows = 0; // rows of the last head launch (Bc after the prompt, B after a generation step)
+    float* cum_log_probs = nullptr; // [B]
+    int32_t *parent_ids = nullptr, *cache_ind = nullptr, *in_len_ctx = nullptr; // [B, Smax], [B, Smax], [Bc]
     std::vector<void*> allocs;
     void *x = nullptr, *qkv = nullptr, *ctx = nullptr, *g = nullptr, *u = nullptr, *inter_buf = nullptr, *tmp = nullptr;
     int8_t* q8 = nullptr;   // quantised activations (context path) [B*S, max(D, I)]
@@ -445,7 +450,7 @@ struct tllm_session
     // ------------------------------------------------------------------------------------------ context step
     int run_context(hipStream_t st)
     {
-        const int S = max_in, M = packed ? ctx_tokens : B * S, D = hidden;
+        const int S = max_in, M = packed ? ctx_tokens : Bc * S, D = hidden;
         RUN(launch_embedding(x, ids_in, emb, M, D, vocab, st));
         for (int li = 0; li < num_layers; ++li)
         {
@@ -472,7 +477,7 @@ struct tllm_session
             RUN(launch_rmsnorm(r, st));
             RUN(gemm(L.qkv, M, a_in, sq && per_token ? qscale : nullptr, sq && per_token, qkv, DT_HALF, st));
             ContextAttnParams c;
-            c.batch = B;
+            c.batch = Bc;
             c.seq = S;
             c.num_heads = Hr;
             c.head_size = Dh;
@@ -483,7 +488,8 @@ struct tllm_session
             c.max_seq_len = Smax;
             c.qkv = qkv;
             c.kv_cache = L.kv;
-            c.input_lengths = in_len;
+            c.input_lengths = in_len_ctx;
+            c.cache_seq_stride = beam;
             c.kv_scale_orig_quant = L.kv_oq;
             c.rope_table = rope;
             c.rope_table_len = rope_len;
@@ -564,29 +570,30 @@ struct tllm_session
         }
         // head: last real token of every sequence -> ln_f -> lm_head -> fp32 logits  (Q/llama_model.py:272-279)
         if (packed)
-            RUN(launch_gather_rows(last_hidden, x, last_rows, B, D, st));
+            RUN(launch_gather_rows(last_hidden, x, last_rows, Bc, D, st));
         else
-            RUN(launch_gather_last_token(last_hidden, x, last_tok, B, S, D, st));
-        RUN(run_head(last_hidden, st));
+            RUN(launch_gather_last_token(last_hidden, x, last_tok, Bc, S, D, st));
+        RUN(run_head(last_hidden, Bc, st));
         return 0;
     }
 
-    int run_head(const void* h, hipStream_t st)
+    int run_head(const void* h, int rows, hipStream_t st)
     {
+        logit_rows = rows;
         gemv_cls = PC_GEMV_HEAD;
-        const int head_rc = gemv(head, B, PRO_RMSNORM, EPI_NONE, h, hidden, lnf, nullptr, nullptr, nullptr, logits_local, Vr, DT_FLOAT,
+        const int head_rc = gemv(head, rows, PRO_RMSNORM, EPI_NONE, h, hidden, lnf, nullptr, nullptr, nullptr, logits_local, Vr, DT_FLOAT,
             nullptr, st);
         gemv_cls = PC_GEMV_LAYER;
         RUN(head_rc);
         if (tp > 1 || force_comm)
         {
-            const int64_t bytes = (int64_t) B * Vr * 4;
+            const int64_t bytes = (int64_t) rows * Vr * 4;
             if (comm::p2p::usable(tp, bytes))
             {
                 if (comm::p2p::all_gather(logits_local, logits, bytes, st))
                     return 1;
             }
-            else if (comm::all_gather(group, logits_local, logits, (int64_t) B * Vr, TLLM_FLOAT, st))
+            else if (comm::all_gather(group, logits_local, logits, (int64_t) rows * Vr, TLLM_FLOAT, st))
                 return 1;
         }
         return 0;
@@ -594,6 +601,34 @@ struct tllm_session
 
     int run_sampler(int advance, hipStream_t st)
     {
+        if (beam > 1)
+        {
+            BeamParams bp;
+            bp.logits = (tp > 1 || force_comm) ? logits : logits_local;
+            bp.logits_per_batch = advance ? 0 : 1;
+            bp.batch = Bc;
+            bp.beam = beam;
+            bp.vocab_part = Vr;
+            bp.nparts = tp;
+            bp.vocab = vocab;
+            bp.cum_log_probs = cum_log_probs;
+            bp.cur_ids = cur_ids;
+            bp.out_ids = out_ids;
+            bp.parent_ids = parent_ids;
+            bp.out_stride = Smax;
+            bp.seq_len = seq_len;
+            bp.finished = finished;
+            bp.end_id = end_id;
+            bp.advance = advance;
+            bp.cache_indirection = cache_ind;
+            bp.rope_row_out = rope_row;
+            bp.rope_table = rope;
+            bp.rope_half = Dh / 2;
+            bp.rope_table_len = rope_len;
+            bp.input_lengths = in_len;
+            bp.max_input_len = max_in;
+            return timed(PC_OTHER, st, [&] { return launch_beam_step(bp, st) ? 1 : 0; });
+        }
         GreedyParams gp;
         gp.logits = (tp > 1 || force_comm) ? logits : logits_local;
         gp.batch = B;
@@ -660,6 +695,8 @@ struct tllm_session
             m.rope_table = rope;
             m.rope_table_len = rope_len;
             m.rope_row = rope_row;
+            m.cache_indirection = beam > 1 ? cache_ind : nullptr;
+            m.beam_width = beam;
             m.rows_per_group = attn_nit;
             m.skip_combine = attn_fused ? 1 : 0;
             m.out = ctx;
@@ -688,7 +725,7 @@ struct tllm_session
         }
         if (ok >= 0)
             return 0;
-        RUN(run_head(x, st));
+        RUN(run_head(x, B, st));
         RUN(run_sampler(1, st));
         return 0;
     }
@@ -933,23 +970,33 @@ tllm_session_t tllm_session_load_engine(const void* engine, size_t nbytes)
 
 int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_input_len, int32_t max_new_tokens)
 {
+    return tllm_session_setup_beam(s, batch_size, 1, max_input_len, max_new_tokens);
+}
+
+int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t beam_width, int32_t max_input_len,
+    int32_t max_new_tokens)
+{
     if (!s || !s->finalized)
     {
         set_error("tllm_session_setup: session not finalized");
         return 1;
     }
-    if (batch_size < 1 || max_input_len < 1 || max_new_tokens < 0)
+    if (batch_size < 1 || max_input_len < 1 || max_new_tokens < 0 || beam_width < 1 || beam_width > 8)
     {
-        set_error("tllm_session_setup: bad sizes");
+        set_error("tllm_session_setup: bad sizes (batch %d, beam width %d in [1, 8], input %d, new %d)", batch_size, beam_width,
+            max_input_len, max_new_tokens);
         return 1;
     }
     s->free_runtime();
-    s->B = batch_size;
+    s->Bc = batch_size;
+    s->beam = beam_width;
+    s->B = batch_size * beam_width;
     s->max_in = max_input_len;
     s->max_new = max_new_tokens;
     s->Smax = max_input_len + max_new_tokens; // generation.py:450-461
     const int B = s->B, S = s->max_in, D = s->hidden, Smax = s->Smax;
-    const size_t M = (size_t) B * S;
+    const int Bc = s->Bc;
+    const size_t M = std::max((size_t) Bc * S, (size_t) B); // prompt rows; the generation phase needs B
     const size_t kv_bytes = (size_t) B * 2 * s->Hr * Smax * s->Dh * (s->int8_kv ? 1 : 2);
     for (auto& L : s->layers)
     {
@@ -968,8 +1015,8 @@ int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_inp
     RUN(s->dalloc(&s->logits_local, (size_t) B * s->Vr * 4));
     RUN(s->dalloc(&s->logits, (size_t) B * s->Vr * s->tp * 4));
     RUN(s->dalloc(&s->last_hidden, (size_t) B * D * 2));
-    RUN(s->dalloc(&s->ctx_ws, context_attention_workspace_size(B, s->Hr, s->Dh, S) + 256));
-    if (s->woq && B * S >= 32)
+    RUN(s->dalloc(&s->ctx_ws, context_attention_workspace_size(Bc, s->Hr, s->Dh, S) + 256));
+    if (s->woq && Bc * S >= 32)
     {
         size_t mx = 0;
         for (auto& L : s->layers)
@@ -977,8 +1024,8 @@ int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_inp
                 mx = std::max(mx, gemm_woq_scratch_bytes(l->N, l->K));
         RUN(s->dalloc(&s->woq_scratch, mx));
     }
-    RUN(s->dalloc(&s->cu_dev, (size_t) (B + 1) * 4));
-    RUN(s->dalloc(&s->last_rows, (size_t) B * 4));
+    RUN(s->dalloc(&s->cu_dev, (size_t) (Bc + 1) * 4));
+    RUN(s->dalloc(&s->last_rows, (size_t) Bc * 4));
     RUN(s->dalloc(&s->mmha_ws, mmha_workspace_size(B, s->Hr, s->Dh, Smax) + 256));
     HIP_OK(hipMemset(s->mmha_ws, 0, mmha_workspace_size(B, s->Hr, s->Dh, Smax) + 256));
     RUN(s->dalloc(&s->ids_in, M * 4));
@@ -986,7 +1033,16 @@ int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_inp
     RUN(s->dalloc(&s->out_ids, (size_t) B * Smax * 4));
     RUN(s->dalloc(&s->seq_len, (size_t) B * 4));
     RUN(s->dalloc(&s->in_len, (size_t) B * 4));
-    RUN(s->dalloc(&s->last_tok, (size_t) B * 4));
+    RUN(s->dalloc(&s->last_tok, (size_t) Bc * 4));
+    RUN(s->dalloc(&s->in_len_ctx, (size_t) Bc * 4));
+    s->cum_log_probs = nullptr;
+    s->parent_ids = s->cache_ind = nullptr;
+    if (s->beam > 1)
+    {
+        RUN(s->dalloc(&s->cum_log_probs, (size_t) B * 4));
+        RUN(s->dalloc(&s->parent_ids, (size_t) B * Smax * 4));
+        RUN(s->dalloc(&s->cache_ind, (size_t) B * Smax * 4));
+    }
     RUN(s->dalloc(&s->finished, (size_t) B * 4));
     RUN(s->dalloc(&s->masked, (size_t) B * Smax * 4));
     s->rope = plugins::rope_table(s->Dh, Smax > s->max_pos ? Smax : s->max_pos, &s->rope_len);
@@ -1021,42 +1077,58 @@ int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_inp
 
 static int upload_prompt(tllm_session_t s, const int32_t* input_ids, const int32_t* input_lengths, hipStream_t st)
 {
-    const int B = s->B, S = s->max_in, Smax = s->Smax;
-    std::vector<int32_t> lens(input_lengths, input_lengths + B), seq(B, S), zeros(B, 0);
+    // input_ids / input_lengths describe the Bc prompts; the per-sequence generation state is tiled over the beam
+    // (generation.py:898-915 _tile_beam_width) - the prompt itself runs once per batch entry
+    const int B = s->B, Bc = s->Bc, W = s->beam, S = s->max_in, Smax = s->Smax;
+    std::vector<int32_t> lens_c(input_lengths, input_lengths + Bc), lens(B), seq(B, S), zeros(B, 0);
     std::vector<int32_t> mask((size_t) B * Smax, 0), out((size_t) B * Smax, 0);
-    for (int b = 0; b < B; ++b)
+    for (int bb = 0; bb < B; ++bb)
     {
-        if (lens[b] < 1 || lens[b] > S)
+        const int b = bb / W;
+        lens[bb] = lens_c[b];
+        if (lens[bb] < 1 || lens[bb] > S)
         {
-            set_error("session: input_lengths[%d]=%d out of range [1, %d]", b, lens[b], S);
+            set_error("session: input_lengths[%d]=%d out of range [1, %d]", b, lens[bb], S);
             return 1;
         }
         // masked_tokens[b, len_b:max_in] = 1 (generation.py:812-821)
-        for (int t = lens[b]; t < S; ++t)
-            mask[(size_t) b * Smax + t] = 1;
+        for (int t = lens[bb]; t < S; ++t)
+            mask[(size_t) bb * Smax + t] = 1;
         for (int t = 0; t < S; ++t)
-            out[(size_t) b * Smax + t] = input_ids[(size_t) b * S + t];
+            out[(size_t) bb * Smax + t] = input_ids[(size_t) b * S + t];
     }
-    std::vector<int32_t> packed_ids, cu(B + 1, 0), last(B, 0);
+    std::vector<int32_t> packed_ids, cu(Bc + 1, 0), last(Bc, 0);
     if (s->packed)
     {
         // the real tokens back to back; generation keeps the padded cache layout (slots [len, max_in) masked), so only
         // the context phase changes shape (generation.py:556-568 with remove_input_padding)
-        for (int b = 0; b < B; ++b)
+        for (int b = 0; b < Bc; ++b)
         {
-            cu[b + 1] = cu[b] + lens[b];
+            cu[b + 1] = cu[b] + lens_c[b];
             last[b] = cu[b + 1] - 1;
-            packed_ids.insert(packed_ids.end(), input_ids + (size_t) b * S, input_ids + (size_t) b * S + lens[b]);
+            packed_ids.insert(packed_ids.end(), input_ids + (size_t) b * S, input_ids + (size_t) b * S + lens_c[b]);
         }
-        s->ctx_tokens = cu[B];
+        s->ctx_tokens = cu[Bc];
         HIP_OK(hipMemcpyAsync(s->ids_in, packed_ids.data(), packed_ids.size() * 4, hipMemcpyHostToDevice, st));
         HIP_OK(hipMemcpyAsync(s->cu_dev, cu.data(), cu.size() * 4, hipMemcpyHostToDevice, st));
         HIP_OK(hipMemcpyAsync(s->last_rows, last.data(), last.size() * 4, hipMemcpyHostToDevice, st));
     }
     else
-        HIP_OK(hipMemcpyAsync(s->ids_in, input_ids, (size_t) B * S * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemcpyAsync(s->ids_in, input_ids, (size_t) Bc * S * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(s->in_len, lens.data(), B * 4, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemcpyAsync(s->last_tok, lens.data(), B * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(s->in_len_ctx, lens_c.data(), Bc * 4, hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(s->last_tok, lens_c.data(), Bc * 4, hipMemcpyHostToDevice, st));
+    std::vector<float> cum;
+    if (W > 1)
+    {
+        // only hypothesis 0 of every beam group is live before the first step (generation.py:392-397)
+        cum.assign(B, -1e20f);
+        for (int b = 0; b < Bc; ++b)
+            cum[(size_t) b * W] = 0.f;
+        HIP_OK(hipMemcpyAsync(s->cum_log_probs, cum.data(), B * 4, hipMemcpyHostToDevice, st));
+        HIP_OK(hipMemsetAsync(s->parent_ids, 0, (size_t) B * Smax * 4, st));
+        HIP_OK(hipMemsetAsync(s->cache_ind, 0, (size_t) B * Smax * 4, st)); // every slot -> hypothesis 0's rows
+    }
     HIP_OK(hipMemcpyAsync(s->seq_len, seq.data(), B * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(s->finished, zeros.data(), B * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(s->masked, mask.data(), mask.size() * 4, hipMemcpyHostToDevice, st));
@@ -1134,7 +1206,7 @@ int32_t tllm_session_fake_context(tllm_session_t s, int32_t length, uint32_t see
     }
     hipStream_t st = s->pick(stream);
     const int B = s->B, S = s->max_in;
-    std::vector<int32_t> ids((size_t) B * S, 3), lens(B, length);
+    std::vector<int32_t> ids((size_t) s->Bc * S, 3), lens(s->Bc, length);
     // a padded prompt of `length` real tokens: slots [length, max_in) are masked
     RUN(upload_prompt(s, ids.data(), lens.data(), st));
     const size_t kv_elems = (size_t) B * 2 * s->Hr * s->Smax * s->Dh;
@@ -1195,6 +1267,8 @@ int32_t tllm_session_generate(tllm_session_t s, const int32_t* input_ids, const 
             }
         }
     }
+    if (s->beam > 1)
+        return tllm_session_get_beam_output(s, output_ids, nullptr, stream);
     return tllm_session_get_output_ids(s, output_ids, stream);
 }
 
@@ -1203,18 +1277,19 @@ int32_t tllm_session_get_logits(tllm_session_t s, float* logits, tllm_stream_t s
     if (!s || !s->B || !logits)
         return 1;
     hipStream_t st = s->pick(stream);
+    const int rows = s->logit_rows;
     if (s->tp == 1)
     {
-        HIP_OK(hipMemcpyAsync(logits, s->logits_local, (size_t) s->B * s->vocab * 4, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipMemcpyAsync(logits, s->logits_local, (size_t) rows * s->vocab * 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         return 0;
     }
-    std::vector<float> g((size_t) s->tp * s->B * s->Vr);
+    std::vector<float> g((size_t) s->tp * rows * s->Vr);
     HIP_OK(hipMemcpyAsync(g.data(), s->logits, g.size() * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    for (int b = 0; b < s->B; ++b)
+    for (int b = 0; b < rows; ++b)
         for (int v = 0; v < s->vocab; ++v)
-            logits[(size_t) b * s->vocab + v] = g[((size_t) (v / s->Vr) * s->B + b) * s->Vr + v % s->Vr];
+            logits[(size_t) b * s->vocab + v] = g[((size_t) (v / s->Vr) * rows + b) * s->Vr + v % s->Vr];
     return 0;
 }
 
@@ -1224,6 +1299,89 @@ int32_t tllm_session_get_output_ids(tllm_session_t s, int32_t* ids, tllm_stream_
         return 1;
     hipStream_t st = s->pick(stream);
     HIP_OK(hipMemcpyAsync(ids, s->out_ids, (size_t) s->B * s->Smax * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int32_t tllm_session_logit_rows(tllm_session_t s)
+{
+    return s ? s->logit_rows : 0;
+}
+
+// Back-track the beams (K/decodingKernels.cu:30-171 gatherTree, called at PY/runtime/generation.py:990-994): hypothesis j of
+// batch entry b ends with the token recorded for it at the last slot; its earlier tokens are those of its ancestors.
+int32_t tllm_session_get_beam_output(tllm_session_t s, int32_t* ids, float* cum_log_probs, tllm_stream_t stream)
+{
+    if (!s || !s->B || !ids)
+    {
+        set_error("tllm_session_get_beam_output: bad arguments / setup not called");
+        return 1;
+    }
+    hipStream_t st = s->pick(stream);
+    const int B = s->B, W = s->beam, Smax = s->Smax, S = s->max_in;
+    if (W == 1)
+    {
+        if (cum_log_probs)
+        {
+            set_error("tllm_session_get_beam_output: cum_log_probs are only kept with beam_width > 1");
+            return 1;
+        }
+        return tllm_session_get_output_ids(s, ids, stream);
+    }
+    std::vector<int32_t> step_ids((size_t) B * Smax), parents((size_t) B * Smax), len(B);
+    HIP_OK(hipMemcpyAsync(step_ids.data(), s->out_ids, step_ids.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(parents.data(), s->parent_ids, parents.size() * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(len.data(), s->seq_len, B * 4, hipMemcpyDeviceToHost, st));
+    if (cum_log_probs)
+        HIP_OK(hipMemcpyAsync(cum_log_probs, s->cum_log_probs, B * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    const int32_t fill = s->end_id >= 0 ? s->end_id : 0;
+    for (int bb = 0; bb < B; ++bb)
+    {
+        const int b0 = bb / W * W;
+        int32_t* o = ids + (size_t) bb * Smax;
+        const int last = std::min(len[bb], Smax - 1); // slot of the newest token
+        for (int t = 0; t < S; ++t)
+            o[t] = step_ids[(size_t) bb * Smax + t]; // the (padded) prompt, shared by the beam group
+        int j = bb - b0;
+        for (int t = last; t >= S; --t)
+        {
+            o[t] = step_ids[(size_t) (b0 + j) * Smax + t];
+            j = parents[(size_t) (b0 + j) * Smax + t];
+            if (j < 0 || j >= W)
+                j = 0;
+        }
+        // everything after the first end token, and the unused tail, is the end token (:130-156)
+        bool done = false;
+        for (int t = S; t < Smax; ++t)
+        {
+            if (t > last || done)
+                o[t] = fill;
+            else if (s->end_id >= 0 && o[t] == s->end_id)
+                done = true;
+        }
+    }
+    return 0;
+}
+
+int32_t tllm_session_get_beam_state(tllm_session_t s, int32_t* parent_ids, int32_t* cache_indirection, int32_t* finished,
+    int32_t* sequence_lengths, tllm_stream_t stream)
+{
+    if (!s || !s->B || s->beam < 2)
+    {
+        set_error("tllm_session_get_beam_state: no beam search set up");
+        return 1;
+    }
+    hipStream_t st = s->pick(stream);
+    const size_t n = (size_t) s->B * s->Smax * 4;
+    if (parent_ids)
+        HIP_OK(hipMemcpyAsync(parent_ids, s->parent_ids, n, hipMemcpyDeviceToHost, st));
+    if (cache_indirection)
+        HIP_OK(hipMemcpyAsync(cache_indirection, s->cache_ind, n, hipMemcpyDeviceToHost, st));
+    if (finished)
+        HIP_OK(hipMemcpyAsync(finished, s->finished, (size_t) s->B * 4, hipMemcpyDeviceToHost, st));
+    if (sequence_lengths)
+        HIP_OK(hipMemcpyAsync(sequence_lengths, s->seq_len, (size_t) s->B * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     return 0;
 }

@@ -82,24 +82,29 @@ class GenerationSession(object):
         return self._model_config.hidden_size
 
     def setup(self, batch_size: int, max_input_length: int, max_new_tokens: int, beam_width: int = 1):
-        if beam_width != 1:
-            raise NotImplementedError('beam search is not built (greedy top-k=1 only)')
+        if not 1 <= beam_width <= 8 or batch_size * beam_width > 8:
+            raise ValueError(f'beam_width {beam_width} x batch {batch_size}: the generation kernels take at most 8 sequences')
         self.batch_size, self.max_input_length, self.max_new_tokens = batch_size, max_input_length, max_new_tokens
-        self.runtime.setup(batch_size, max_input_length, max_new_tokens)
+        self.beam_width = beam_width
+        self.runtime.setup(batch_size, max_input_length, max_new_tokens, beam_width)
 
     def decode(self, input_ids, input_lengths, sampling_config: SamplingConfig, prompt_embedding_table=None,
                tasks=None, prompt_vocab_size=None):
         """input_ids: int32 [batch, max_input_length] (torch tensor or ndarray), padded with pad_id.
-        Returns int32 [batch, beams=1, max_input_length + max_new_tokens] like the reference (generation.py:991-997)."""
-        if sampling_config.num_beams != 1 or sampling_config.top_k != 1:
-            raise NotImplementedError('only greedy decoding (num_beams=1, top_k=1) is built')
+        Returns int32 [batch, num_beams, max_input_length + max_new_tokens] like the reference (generation.py:991-997):
+        greedy for num_beams == 1, beam search (hypotheses best first, back-tracked by gather_tree) otherwise."""
+        if sampling_config.top_k != 1 and sampling_config.num_beams == 1:
+            raise NotImplementedError('sampling (top_k > 1 / top_p) is not built: greedy or beam search only')
+        if sampling_config.num_beams != getattr(self, 'beam_width', 1):
+            # the reference sizes its beam buffers inside decode() from scfg.num_beams (generation.py:365-411)
+            self.setup(self.batch_size, self.max_input_length, self.max_new_tokens, sampling_config.num_beams)
         is_torch = hasattr(input_ids, 'cpu')
         ids = input_ids.cpu().numpy() if is_torch else np.asarray(input_ids)
         lens = input_lengths.cpu().numpy() if hasattr(input_lengths, 'cpu') else np.asarray(input_lengths)
         assert ids.shape == (self.batch_size, self.max_input_length), 'call setup() with matching sizes first'
         out = self.runtime.generate(ids.astype(np.int32), lens.astype(np.int32), self.max_new_tokens,
                                     end_id=sampling_config.end_id, pad_id=sampling_config.pad_id)
-        out = out.reshape(self.batch_size, 1, -1)
+        out = out.reshape(self.batch_size, sampling_config.num_beams, -1)
         if is_torch:
             import torch
             return torch.from_numpy(out).to(input_ids.device)

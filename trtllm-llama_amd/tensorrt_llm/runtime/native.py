@@ -33,6 +33,14 @@ def _lib():
     lib.tllm_session_load_engine.restype = c.c_void_p
     lib.tllm_session_setup.argtypes = [c.c_void_p, c.c_int32, c.c_int32, c.c_int32]
     lib.tllm_session_setup.restype = c.c_int32
+    lib.tllm_session_setup_beam.argtypes = [c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_int32]
+    lib.tllm_session_setup_beam.restype = c.c_int32
+    lib.tllm_session_get_beam_output.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.tllm_session_get_beam_output.restype = c.c_int32
+    lib.tllm_session_get_beam_state.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.tllm_session_get_beam_state.restype = c.c_int32
+    lib.tllm_session_logit_rows.argtypes = [c.c_void_p]
+    lib.tllm_session_logit_rows.restype = c.c_int32
     lib.tllm_session_generate.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32,
                                           c.c_void_p, c.c_void_p]
     lib.tllm_session_generate.restype = c.c_int32
@@ -103,9 +111,10 @@ class NativeSession:
     def finalize(self):
         _check(_lib().tllm_session_finalize(self._h), 'finalize')
 
-    def setup(self, batch: int, max_input_len: int, max_new_tokens: int):
-        _check(_lib().tllm_session_setup(self._h, batch, max_input_len, max_new_tokens), 'setup')
-        self.batch, self.max_in, self.max_new = batch, max_input_len, max_new_tokens
+    def setup(self, batch: int, max_input_len: int, max_new_tokens: int, beam_width: int = 1):
+        """batch prompts x beam_width hypotheses (beam search when > 1; batch * beam_width <= 8 in the generation phase)."""
+        _check(_lib().tllm_session_setup_beam(self._h, batch, beam_width, max_input_len, max_new_tokens), 'setup')
+        self.batch, self.max_in, self.max_new, self.beam = batch, max_input_len, max_new_tokens, beam_width
 
     @staticmethod
     def _i32(a) -> np.ndarray:
@@ -124,19 +133,40 @@ class NativeSession:
 
     def logits(self, vocab: Optional[int] = None, stream: int = 0) -> np.ndarray:
         v = vocab or self.vocab
-        out = np.empty((self.batch, v), np.float32)
+        rows = _lib().tllm_session_logit_rows(self._h)  # batch after the prompt, batch * beam after a step
+        out = np.empty((rows, v), np.float32)
         _check(_lib().tllm_session_get_logits(self._h, out.ctypes.data, stream), 'get_logits')
         return out
 
     def output_ids(self, stream: int = 0) -> np.ndarray:
-        out = np.empty((self.batch, self.max_in + self.max_new), np.int32)
+        """Per-sequence token record [batch * beam, max_seq_len] (with beam search: the un-back-tracked step ids)."""
+        out = np.empty((self.batch * self.beam, self.max_in + self.max_new), np.int32)
         _check(_lib().tllm_session_get_output_ids(self._h, out.ctypes.data, stream), 'get_output_ids')
         return out
+
+    def beam_output(self, stream: int = 0):
+        """(ids [batch, beam, max_seq_len] back-tracked and best first, cum_log_probs [batch, beam])."""
+        out = np.empty((self.batch, self.beam, self.max_in + self.max_new), np.int32)
+        cum = np.empty((self.batch, self.beam), np.float32)
+        _check(_lib().tllm_session_get_beam_output(self._h, out.ctypes.data, cum.ctypes.data if self.beam > 1 else None, stream),
+               'get_beam_output')
+        return out, (cum if self.beam > 1 else None)
+
+    def beam_state(self, stream: int = 0):
+        """dict(parent_ids, cache_indirection [batch * beam, max_seq_len], finished, sequence_lengths [batch * beam])."""
+        n, smax = self.batch * self.beam, self.max_in + self.max_new
+        d = dict(parent_ids=np.empty((n, smax), np.int32), cache_indirection=np.empty((n, smax), np.int32),
+                 finished=np.empty(n, np.int32), sequence_lengths=np.empty(n, np.int32))
+        _check(_lib().tllm_session_get_beam_state(self._h, d['parent_ids'].ctypes.data, d['cache_indirection'].ctypes.data,
+                                                  d['finished'].ctypes.data, d['sequence_lengths'].ctypes.data, stream),
+               'get_beam_state')
+        return d
 
     def generate(self, input_ids, input_lengths, max_new_tokens: int, end_id: int = -1, pad_id: int = 0,
                  stream: int = 0) -> np.ndarray:
         ids, lens = self._i32(input_ids), self._i32(input_lengths)
-        out = np.empty((self.batch, self.max_in + self.max_new), np.int32)
+        shape = (self.batch, self.max_in + self.max_new) if self.beam == 1 else (self.batch, self.beam, self.max_in + self.max_new)
+        out = np.empty(shape, np.int32)
         _check(_lib().tllm_session_generate(self._h, ids.ctypes.data, lens.ctypes.data, max_new_tokens, end_id, pad_id,
                                             out.ctypes.data, stream), 'generate')
         return out
