@@ -30,7 +30,10 @@ typedef struct tllm_session* tllm_session_t;
  *   T/tensorrt_llm/quantization/mode.py:6-21), weight_only_precision (int8|int4),
  *   use_gpt_attention_plugin/use_gemm_plugin (informational), neox_rotary_style (1),
  *   force_comm (0; tests: issue the tensor-parallel collectives on a 1-rank communicator as well),
- *   remove_input_padding (0; 1: the context phase runs on the packed real tokens only).
+ *   remove_input_padding (0; 1: the context phase runs on the packed real tokens only),
+ *   paged_kv_cache (0; 1: every layer's cache is a pool of [Hr, tokens_per_block, Dh] blocks reached through a per-sequence
+ *   table of block pointers - K/kvCacheUtils.h:34-112, PY/runtime/kv_cache_manager.py; the table is filled at setup),
+ *   tokens_per_block (64; a power of two).
  * Returns NULL on error (tllm_last_error()). */
 tllm_session_t tllm_session_create(const char* config_text);
 

@@ -139,6 +139,17 @@ def test_build_cli_writes_engine_and_config(tmp_path):
     assert eng[:8] == b'TLLMENG1'
 
 
+def test_paged_kv_cache_trace_adds_pool_and_block_pointer_inputs(tmp_path):
+    """--paged_kv_cache: the GPTAttention node carries paged_kv_cache = 1 and one more input (the block pointers), the
+    cache input becomes the block pool [blocks, 2, heads, tokens_per_block, head_size] (gptAttentionPlugin.cpp:206-253)."""
+    out = tmp_path / 'eng'
+    subprocess.run([sys.executable, os.path.join(EX, 'build.py'), '--output_dir', str(out), '--paged_kv_cache', '--int8_kv_cache',
+                    '--log_level', 'error'] + TINY, check=True, cwd=EX, timeout=300)
+    blob = open(out / 'llama_float16_tp1_rank0.engine', 'rb').read()
+    assert b'paged_kv_cache=1' in blob[:4096] and b'tokens_per_block=64' in blob[:4096]
+    assert b'kv_cache_block_pointers_0' in blob and b'kv_cache_block_pointers_1' in blob
+
+
 def test_smooth_quant_and_weight_only_are_exclusive():
     from build import parse_arguments
     with pytest.raises(AssertionError):
@@ -169,14 +180,14 @@ def test_generation_session_matches_hf_golden(mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('extra', [[], ['--remove_input_padding']])
+@pytest.mark.parametrize('extra', [[], ['--remove_input_padding'], ['--paged_kv_cache']])
 def test_build_then_run_cli(tmp_path, extra):
     out = tmp_path / 'eng'
     subprocess.run([sys.executable, os.path.join(EX, 'build.py'), '--output_dir', str(out), '--log_level', 'error'] + TINY
                    + extra, check=True, cwd=EX, timeout=300)
     if extra:
         blob = open(out / 'llama_float16_tp1_rank0.engine', 'rb').read()
-        assert b'remove_input_padding=1' in blob[:4096] and b'"input_ids"' in blob
+        assert extra[0][2:].encode() + b'=1' in blob[:4096] and b'"input_ids"' in blob
     np.save(tmp_path / 'in.npy', np.array([5, 17, 99, 3, 64], np.int32))
     r = subprocess.run([sys.executable, os.path.join(EX, 'run.py'), '--max_output_len', '8', '--engine_dir', str(out),
                         '--input_tokens', str(tmp_path / 'in.npy'), '--output_npy', str(tmp_path / 'out.npy'),

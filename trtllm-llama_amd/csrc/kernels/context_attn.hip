@@ -143,6 +143,14 @@ __global__ void rope_kv_write_kernel(const ContextAttnParams p)
             + (((int64_t) (b * p.cache_seq_stride * 2 + 0) * H + h) * p.max_seq_len + s) * DH * esz + li * 8 * esz;
         char* vc = reinterpret_cast<char*>(p.kv_cache)
             + (((int64_t) (b * p.cache_seq_stride * 2 + 1) * H + h) * p.max_seq_len + s) * DH * esz + li * 8 * esz;
+        if (p.block_pointers) // uniform: paged cache, block s / tokens_per_block of the sequence, row s % tokens_per_block
+        {
+            const int lg = 31 - __builtin_clz(p.tokens_per_block);
+            const int64_t* row = p.block_pointers + (int64_t) b * p.cache_seq_stride * 2 * p.max_blocks_per_seq + (s >> lg);
+            const int64_t off = (((int64_t) h * p.tokens_per_block + (s & (p.tokens_per_block - 1))) * DH + li * 8) * esz;
+            kc = reinterpret_cast<char*>(row[0]) + off;
+            vc = reinterpret_cast<char*>(row[p.max_blocks_per_seq]) + off;
+        }
         if (p.int8_kv)
         {
             const float sc = p.kv_scale_orig_quant[0];
@@ -559,6 +567,16 @@ int launch_context_attention(const ContextAttnParams& p, hipStream_t stream)
     {
         set_error("context attention: int8 KV cache needs kv_scale_orig_quant");
         return -1;
+    }
+    if (p.block_pointers)
+    {
+        const int t = p.tokens_per_block;
+        if (t < 1 || (t & (t - 1)) || (int64_t) p.max_blocks_per_seq * t < p.max_seq_len)
+        {
+            set_error("context attention: paged KV cache needs tokens_per_block a power of two and max_blocks_per_seq * "
+                      "tokens_per_block >= max_seq_len (got %d x %d for %d)", p.max_blocks_per_seq, t, p.max_seq_len);
+            return -1;
+        }
     }
     if (p.seq > p.max_seq_len)
     {

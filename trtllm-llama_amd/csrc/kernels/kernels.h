@@ -163,6 +163,11 @@ struct MmhaParams
     // + k reads the K/V of timestep t from the cache rows of sequence b * beam_width + cache_indirection[bb, t]
     const int32_t* cache_indirection = nullptr; // int32 [batch, max_seq_len]
     int32_t beam_width = 1;
+    // paged KV cache (K/kvCacheUtils.h:34-112 KVBlockArray): instead of kv_cache, a table int64 [batch, 2, max_blocks_per_seq]
+    // of device pointers to blocks laid out [H, tokens_per_block, Dh]; time step t is row t % tokens_per_block of block
+    // t / tokens_per_block (tokens_per_block a power of two)
+    const int64_t* block_pointers = nullptr;
+    int32_t tokens_per_block = 0, max_blocks_per_seq = 0;
     int32_t skip_combine = 0;        // 1: leave the split partials in the workspace (the consumer merges them:
                                      // GemvParams::attn_*), no combine launch
     void* out = nullptr;       // fp16 [B, H*Dh]
@@ -205,6 +210,9 @@ struct ContextAttnParams
     // beam search: prompt b fills the cache rows of sequence b * cache_seq_stride (hypothesis 0 of its beam group; the
     // siblings reach those rows through the cache indirection, so the prompt's K/V is stored once)
     int32_t cache_seq_stride = 1;
+    // paged KV cache: see MmhaParams (kv_cache unused when set)
+    const int64_t* block_pointers = nullptr;
+    int32_t tokens_per_block = 0, max_blocks_per_seq = 0;
 };
 size_t context_attention_workspace_size(int batch, int num_heads, int head_size, int seq);
 // cu[0] = 0, cu[b + 1] = cu[b] + lens[b]  (device, one tiny launch; packed-input bookkeeping)

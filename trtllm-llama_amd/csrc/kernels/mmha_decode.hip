@@ -95,7 +95,19 @@ __device__ __forceinline__ uint2 quant8(const uint4& v, float s)
 }
 
 // ---- kernel 1: one workgroup per (split, head, batch) -> partial {max, sum, out[DH]} in the workspace
-template <int DH, int NIT, bool INT8KV, bool BEAM>
+// CACHE: how a (sequence, time step) finds its K/V row -
+//   CACHE_LINEAR  [B, 2, H, Smax, DH], the sequence's own rows
+//   CACHE_BEAM    the same buffer, rows of the sibling hypothesis cache_indirection names
+//   CACHE_PAGED   block table [B, 2, max_blocks] of pointers to [H, tokens_per_block, DH] blocks (K/kvCacheUtils.h:34-112),
+//                 through the cache indirection too when beam_width > 1
+enum
+{
+    CACHE_LINEAR = 0,
+    CACHE_BEAM = 1,
+    CACHE_PAGED = 2
+};
+
+template <int DH, int NIT, bool INT8KV, int CACHE>
 __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, float2* ws_ml, float* ws_o, int nsplit_max)
 {
     using G = MmhaGeom<DH, NIT>;
@@ -114,9 +126,31 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
     // ---- 1. request the cache rows: nothing below is needed to form their addresses (rows at or beyond the
     //         current length are loaded too - the buffer has Smax rows - and dropped by the validity mask)
     uint4 kreg[NIT], vreg[NIT];
+    constexpr bool BEAM = CACHE == CACHE_BEAM, PAGED = CACHE == CACHE_PAGED;
     // beam search: timestep t of this hypothesis lives in the cache rows of a sibling (cache_indirection); the row
     // strides between siblings are whole (batch, 2, H, Smax, DH) sequences
     int64_t sib[NIT];
+    // paged: the block holding time step t, from the sequence's (or the sibling's) row of the block table
+    const char* kblk[NIT];
+    const char* vblk[NIT];
+    const int tpb_mask = p.tokens_per_block - 1;
+    if constexpr (PAGED)
+    {
+        const int lg = 31 - __builtin_clz(p.tokens_per_block);
+        const int k_own = p.beam_width > 1 ? b % p.beam_width : 0;
+        const int32_t* ci = p.cache_indirection + (int64_t) b * Smax;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+        {
+            const int t = min(t0 + i * NGRP + gid, Smax - 1);
+            int seq = b;
+            if (p.beam_width > 1) // uniform
+                seq = b - k_own + ci[t];
+            const int64_t* row = p.block_pointers + (int64_t) seq * 2 * p.max_blocks_per_seq + (t >> lg);
+            kblk[i] = reinterpret_cast<const char*>(row[0]);
+            vblk[i] = reinterpret_cast<const char*>(row[p.max_blocks_per_seq]);
+        }
+    }
     if constexpr (BEAM)
     {
         const int32_t* ci = p.cache_indirection + (int64_t) b * Smax;
@@ -135,17 +169,24 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
         int64_t off = ((int64_t) t * DH + li * 8) * ESZ;
         if constexpr (BEAM)
             off += sib[i];
+        const char *kp = kbase + off, *vp = vbase + off;
+        if constexpr (PAGED)
+        {
+            off = (((int64_t) h * p.tokens_per_block + (t & tpb_mask)) * DH + li * 8) * ESZ;
+            kp = kblk[i] + off;
+            vp = vblk[i] + off;
+        }
         if constexpr (INT8KV)
         {
-            const uint2 k8 = *reinterpret_cast<const uint2*>(kbase + off);
-            const uint2 v8 = *reinterpret_cast<const uint2*>(vbase + off);
+            const uint2 k8 = *reinterpret_cast<const uint2*>(kp);
+            const uint2 v8 = *reinterpret_cast<const uint2*>(vp);
             kreg[i] = make_uint4(k8.x, k8.y, 0, 0);
             vreg[i] = make_uint4(v8.x, v8.y, 0, 0);
         }
         else
         {
-            kreg[i] = *reinterpret_cast<const uint4*>(kbase + off);
-            vreg[i] = *reinterpret_cast<const uint4*>(vbase + off);
+            kreg[i] = *reinterpret_cast<const uint4*>(kp);
+            vreg[i] = *reinterpret_cast<const uint4*>(vp);
         }
     }
     // ---- 2. the new token's q, k, v, the step scalars, the padding-mask words and the RoPE row: all requested
@@ -250,16 +291,26 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
     // ---- 3. the workgroup that owns slot tl appends the new token to the cache
     if (tl / G::TCHUNK == c && gid == 0 && tl < Smax)
     {
-        const int64_t off = ((int64_t) tl * DH + li * 8) * ESZ;
+        int64_t off = ((int64_t) tl * DH + li * 8) * ESZ;
+        char *kw = kbase + off, *vw = vbase + off;
+        if constexpr (PAGED)
+        {
+            // the sequence's OWN block (never a sibling's: a new token belongs to the hypothesis that consumed it)
+            const int lg = 31 - __builtin_clz(p.tokens_per_block);
+            const int64_t* row = p.block_pointers + (int64_t) b * 2 * p.max_blocks_per_seq + (tl >> lg);
+            off = (((int64_t) h * p.tokens_per_block + (tl & tpb_mask)) * DH + li * 8) * ESZ;
+            kw = reinterpret_cast<char*>(row[0]) + off;
+            vw = reinterpret_cast<char*>(row[p.max_blocks_per_seq]) + off;
+        }
         if constexpr (INT8KV)
         {
-            *reinterpret_cast<uint2*>(kbase + off) = quant8(k_new, s_oq);
-            *reinterpret_cast<uint2*>(vbase + off) = quant8(v_new, s_oq);
+            *reinterpret_cast<uint2*>(kw) = quant8(k_new, s_oq);
+            *reinterpret_cast<uint2*>(vw) = quant8(v_new, s_oq);
         }
         else
         {
-            *reinterpret_cast<uint4*>(kbase + off) = k_new;
-            *reinterpret_cast<uint4*>(vbase + off) = v_new;
+            *reinterpret_cast<uint4*>(kw) = k_new;
+            *reinterpret_cast<uint4*>(vw) = v_new;
         }
     }
 
@@ -458,14 +509,28 @@ int launch_nit(const MmhaParams& p, hipStream_t stream)
     float* ws_o = reinterpret_cast<float*>(ws + ml_bytes);
     dim3 grid(ns, p.num_heads, p.batch);
     const bool beam = p.beam_width > 1 && p.cache_indirection;
-    if (p.int8_kv && beam)
-        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, true, true>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
-    else if (p.int8_kv)
-        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, true, false>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
-    else if (beam)
-        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, false, true>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
+    const int mode = p.block_pointers ? CACHE_PAGED : (beam ? CACHE_BEAM : CACHE_LINEAR);
+#define TLLM_MMHA_LAUNCH(I8, MODE)                                                                                     \
+    hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, I8, MODE>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns)
+    if (p.int8_kv)
+    {
+        if (mode == CACHE_PAGED)
+            TLLM_MMHA_LAUNCH(true, CACHE_PAGED);
+        else if (mode == CACHE_BEAM)
+            TLLM_MMHA_LAUNCH(true, CACHE_BEAM);
+        else
+            TLLM_MMHA_LAUNCH(true, CACHE_LINEAR);
+    }
     else
-        hipLaunchKernelGGL((mmha_partial_kernel<DH, NIT, false, false>), grid, dim3(256), 0, stream, p, ws_ml, ws_o, ns);
+    {
+        if (mode == CACHE_PAGED)
+            TLLM_MMHA_LAUNCH(false, CACHE_PAGED);
+        else if (mode == CACHE_BEAM)
+            TLLM_MMHA_LAUNCH(false, CACHE_BEAM);
+        else
+            TLLM_MMHA_LAUNCH(false, CACHE_LINEAR);
+    }
+#undef TLLM_MMHA_LAUNCH
     if (!p.skip_combine)
         hipLaunchKernelGGL((mmha_combine_kernel<DH, NIT>), dim3(p.num_heads, p.batch), dim3(256), 0, stream, p, ws_ml, ws_o, ns);
     hipError_t e = hipGetLastError();
@@ -565,6 +630,21 @@ int launch_mmha(const MmhaParams& p, hipStream_t stream)
         set_error("mmha: timestep %d exceeds cache capacity %d (circular cache not supported)", p.timestep_host,
             p.max_seq_len);
         return -1;
+    }
+    if (p.block_pointers)
+    {
+        const int t = p.tokens_per_block;
+        if (t < 1 || (t & (t - 1)) || (int64_t) p.max_blocks_per_seq * t < p.max_seq_len)
+        {
+            set_error("mmha: paged KV cache needs tokens_per_block a power of two and max_blocks_per_seq * tokens_per_block >= "
+                      "max_seq_len (got %d x %d for %d)", p.max_blocks_per_seq, t, p.max_seq_len);
+            return -1;
+        }
+        if (p.beam_width > 1 && !p.cache_indirection)
+        {
+            set_error("mmha: beam width %d without a cache indirection", p.beam_width);
+            return -1;
+        }
     }
     switch (p.head_size)
     {

@@ -138,8 +138,6 @@ public:
             throw std::runtime_error("GPTAttention: multi_query_mode not built (LLaMA-7B is MHA)");
         if (c.fp8_kv_cache)
             throw std::runtime_error("GPTAttention: fp8_kv_cache not built");
-        if (c.paged_kv_cache)
-            throw std::runtime_error("GPTAttention: paged_kv_cache not built");
         if (c.in_flight_batching)
             throw std::runtime_error("GPTAttention: in_flight_batching not built");
         if (!c.unidirectional)
@@ -179,7 +177,7 @@ public:
         const Desc& d = io[pos];
         if (!linear_fmt(d))
             return false;
-        const int nin_expected = 8 + (c.int8_kv_cache ? 2 : 0);
+        const int nin_expected = 8 + (c.int8_kv_cache ? 2 : 0) + (c.paged_kv_cache ? 1 : 0);
         if (nin != nin_expected)
             return false;
         if (pos == 0 || pos == nin)
@@ -188,15 +186,19 @@ public:
             return d.type == (c.int8_kv_cache ? TLLM_INT8 : c.type_id);
         if (pos >= 2 && pos <= 7)
             return d.type == TLLM_INT32;
+        if (c.paged_kv_cache && pos == block_pointers_idx())
+            return d.type == TLLM_INT32; // int64 pointers carried as int32 pairs (gptAttentionPlugin.cpp:106-110)
         return d.type == TLLM_FLOAT; // kv scales
     }
+
+    int block_pointers_idx() const { return c.int8_kv_cache ? 10 : 8; } // gptAttentionPlugin.h:156-159
 
     size_t workspaceSize(const Desc* in, int nin, const Desc* out, int nout) const override
     {
         // packed inputs: qkv is [1, tokens, 3 D]; the batch is input_lengths' extent, the longest sequence input 6's
         const int B = c.remove_input_padding ? in[5].dims.d[0] : in[0].dims.d[0];
         const int S = c.remove_input_padding ? in[6].dims.d[0] : in[0].dims.d[1];
-        const int Smax = in[1].dims.d[3];
+        const int Smax = c.paged_kv_cache ? in[7].dims.d[2] : in[1].dims.d[3];
         // max(context, generation), like the reference (gptAttentionPlugin.cpp:132-144)
         const size_t gen = mmha_workspace_size(B, c.num_heads, c.head_size, Smax) + 256;
         const size_t ctx = context_attention_workspace_size(B, c.num_heads, c.head_size, S) + 256 + kCuBytes;
@@ -212,7 +214,26 @@ public:
         const int B = packed ? inDesc[5].dims.d[0] : inDesc[0].dims.d[0];
         int S = packed ? 1 : inDesc[0].dims.d[1];
         const int Smax = inDesc[7].dims.d[2]; // max_seq_len from cache_indirection.shape[2] (gptAttentionPlugin.cpp:335)
-        if (inDesc[1].dims.nbDims != 5 || inDesc[1].dims.d[3] != Smax || inDesc[1].dims.d[2] != c.num_heads
+        // paged KV cache (gptAttentionPlugin.cpp:313-325): input 1 is the block pool [blocks, 2, H, tokens_per_block, Dh],
+        // reached only through the pointer table int64 [B, beam, 2, max_blocks] that travels as int32 [.., 2 * max_blocks]
+        const bool paged = c.paged_kv_cache != 0;
+        const int64_t* block_pointers = nullptr;
+        int tokens_per_block = 0, max_blocks = 0;
+        if (paged)
+        {
+            const Desc& bp = inDesc[block_pointers_idx()];
+            if (inDesc[1].dims.nbDims != 5 || inDesc[1].dims.d[1] != 2 || inDesc[1].dims.d[2] != c.num_heads
+                || inDesc[1].dims.d[4] != c.head_size || bp.dims.nbDims != 4 || bp.dims.d[2] != 2 || bp.dims.d[3] % 2)
+            {
+                set_error("GPTAttention: paged KV cache needs the pool [blocks,2,H,tokens_per_block,Dh] and block pointers "
+                          "int32 [B,beam,2,2*max_blocks]");
+                return 1;
+            }
+            tokens_per_block = inDesc[1].dims.d[3];
+            max_blocks = bp.dims.d[3] / 2;
+            block_pointers = static_cast<const int64_t*>(in[block_pointers_idx()]);
+        }
+        else if (inDesc[1].dims.nbDims != 5 || inDesc[1].dims.d[3] != Smax || inDesc[1].dims.d[2] != c.num_heads
             || inDesc[1].dims.d[4] != c.head_size || inDesc[1].dims.d[1] != 2)
         {
             set_error("GPTAttention: past_key_value must be [B,2,H,Smax,Dh] with Smax = cache_indirection.shape[2]");
@@ -273,6 +294,16 @@ public:
             p.max_seq_len = Smax;
             p.qkv = const_cast<void*>(in[0]);
             p.kv_cache = out[1];
+            if (paged)
+            {
+                // the prompt of batch entry b fills the blocks of table row (b, hypothesis 0): with beam search the table has
+                // beam_width rows per entry while the context phase runs one sequence per entry
+                p.block_pointers = block_pointers;
+                p.tokens_per_block = tokens_per_block;
+                p.max_blocks_per_seq = max_blocks;
+                const int rows = inDesc[block_pointers_idx()].dims.d[0] * inDesc[block_pointers_idx()].dims.d[1];
+                p.cache_seq_stride = rows == B ? 1 : beam_width;
+            }
             p.input_lengths = static_cast<const int32_t*>(in[5]);
             p.kv_scale_orig_quant = c.int8_kv_cache ? static_cast<const float*>(in[8]) : nullptr;
             p.rope_table = table;
@@ -311,6 +342,12 @@ public:
             }
             p.cache_indirection = static_cast<const int32_t*>(in[7]);
             p.beam_width = beam_width;
+        }
+        if (paged)
+        {
+            p.block_pointers = block_pointers;
+            p.tokens_per_block = tokens_per_block;
+            p.max_blocks_per_seq = max_blocks;
         }
         if (c.int8_kv_cache)
         {

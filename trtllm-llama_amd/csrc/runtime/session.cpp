@@ -93,7 +93,8 @@ struct Layer
     const float* kv_oq = nullptr;
     const float* kv_qo = nullptr;
     Linear qkv, dense, fc, gate, proj;
-    void* kv = nullptr;
+    void* kv = nullptr;                // linear cache [B, 2, Hr, Smax, Dh], or the block pool [2, blocks, Hr, tokens_per_block, Dh]
+    const int64_t* kv_table = nullptr; // paged: device table int64 [B, 2, max_blocks] of block pointers into `kv`
 };
 
 size_t dtype_bytes(int32_t t)
@@ -152,6 +153,12 @@ struct tllm_session
     int ctx_tokens = 0;        // ... their number in the current prompt batch
     int32_t* cu_dev = nullptr;    // [B + 1] exclusive prefix sum of the input lengths
     int32_t* last_rows = nullptr; // [B] packed row of every sequence's last prompt token
+    // paged KV cache (plugin field paged_kv_cache; K/kvCacheUtils.h KVBlockArray, PY/runtime/kv_cache_manager.py): the session
+    // owns the pool and hands every sequence its blocks at setup - the whole table is known then, so the generation graph
+    // needs no host-side block allocation between steps
+    bool paged_kv = false;
+    int tokens_per_block = 64, max_blocks = 0;
+    size_t kv_elems = 0; // elements of one layer's cache / pool
     bool force_comm = false; // tests: run the TP collectives on a 1-rank communicator too (RCCL inside the captured graph)
 
     // ---- runtime state (setup)
@@ -490,6 +497,9 @@ struct tllm_session
             c.kv_cache = L.kv;
             c.input_lengths = in_len_ctx;
             c.cache_seq_stride = beam;
+            c.block_pointers = L.kv_table;
+            c.tokens_per_block = tokens_per_block;
+            c.max_blocks_per_seq = max_blocks;
             c.kv_scale_orig_quant = L.kv_oq;
             c.rope_table = rope;
             c.rope_table_len = rope_len;
@@ -697,6 +707,9 @@ struct tllm_session
             m.rope_row = rope_row;
             m.cache_indirection = beam > 1 ? cache_ind : nullptr;
             m.beam_width = beam;
+            m.block_pointers = L.kv_table;
+            m.tokens_per_block = tokens_per_block;
+            m.max_blocks_per_seq = max_blocks;
             m.rows_per_group = attn_nit;
             m.skip_combine = attn_fused ? 1 : 0;
             m.out = ctx;
@@ -772,6 +785,13 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->neox = geti("neox_rotary_style", 1);
     s->force_comm = geti("force_comm", 0) != 0;
     s->packed = geti("remove_input_padding", 0) != 0;
+    s->paged_kv = geti("paged_kv_cache", 0) != 0;
+    s->tokens_per_block = geti("tokens_per_block", 64);
+    if (s->paged_kv && (s->tokens_per_block < 1 || (s->tokens_per_block & (s->tokens_per_block - 1))))
+    {
+        set_error("tllm_session_create: tokens_per_block must be a power of two (got %d)", s->tokens_per_block);
+        return nullptr;
+    }
     if (kv.count("rms_norm_eps"))
         s->eps = (float) atof(kv["rms_norm_eps"].c_str());
     if (kv.count("weight_only_precision"))
@@ -997,11 +1017,38 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
     const int B = s->B, S = s->max_in, D = s->hidden, Smax = s->Smax;
     const int Bc = s->Bc;
     const size_t M = std::max((size_t) Bc * S, (size_t) B); // prompt rows; the generation phase needs B
-    const size_t kv_bytes = (size_t) B * 2 * s->Hr * Smax * s->Dh * (s->int8_kv ? 1 : 2);
+    const size_t kv_esz = s->int8_kv ? 1 : 2;
+    size_t kv_bytes = (size_t) B * 2 * s->Hr * Smax * s->Dh * kv_esz;
+    const int T = s->tokens_per_block;
+    s->max_blocks = s->paged_kv ? (Smax + T - 1) / T : 0;
+    const size_t nblocks = (size_t) B * s->max_blocks, blk_bytes = (size_t) s->Hr * T * s->Dh * kv_esz;
+    if (s->paged_kv)
+        kv_bytes = 2 * nblocks * blk_bytes;
+    s->kv_elems = kv_bytes / kv_esz;
     for (auto& L : s->layers)
     {
         RUN(s->dalloc(&L.kv, kv_bytes));
         HIP_OK(hipMemset(L.kv, 0, kv_bytes));
+        L.kv_table = nullptr;
+        if (s->paged_kv)
+        {
+            // pool [2, blocks, Hr, T, Dh] (K half then V half, like the reference's BlocksManager:
+            // kv_cache_manager.py:84-96); logical block j of sequence bb is pool block j * B + bb, so consecutive time
+            // blocks of one sequence are NOT contiguous
+            std::vector<int64_t> table((size_t) B * 2 * s->max_blocks);
+            const int64_t base = reinterpret_cast<int64_t>(L.kv);
+            for (int bb = 0; bb < B; ++bb)
+                for (int j = 0; j < s->max_blocks; ++j)
+                {
+                    const int64_t blk = (int64_t) j * B + bb;
+                    table[((size_t) bb * 2 + 0) * s->max_blocks + j] = base + blk * (int64_t) blk_bytes;
+                    table[((size_t) bb * 2 + 1) * s->max_blocks + j] = base + ((int64_t) nblocks + blk) * (int64_t) blk_bytes;
+                }
+            int64_t* dev = nullptr;
+            RUN(s->dalloc(&dev, table.size() * 8));
+            HIP_OK(hipMemcpy(dev, table.data(), table.size() * 8, hipMemcpyHostToDevice));
+            L.kv_table = dev;
+        }
     }
     RUN(s->dalloc(&s->x, M * D * 2));
     RUN(s->dalloc(&s->tmp, M * D * 2));
@@ -1209,9 +1256,8 @@ int32_t tllm_session_fake_context(tllm_session_t s, int32_t length, uint32_t see
     std::vector<int32_t> ids((size_t) s->Bc * S, 3), lens(s->Bc, length);
     // a padded prompt of `length` real tokens: slots [length, max_in) are masked
     RUN(upload_prompt(s, ids.data(), lens.data(), st));
-    const size_t kv_elems = (size_t) B * 2 * s->Hr * s->Smax * s->Dh;
     for (int i = 0; i < s->num_layers; ++i)
-        RUN(launch_fill_random(s->layers[i].kv, s->int8_kv ? DT_INT8 : DT_HALF, kv_elems, seed + 7919u * i, 1.0f, st));
+        RUN(launch_fill_random(s->layers[i].kv, s->int8_kv ? DT_INT8 : DT_HALF, s->kv_elems, seed + 7919u * i, 1.0f, st));
     RUN(s->run_sampler(0, st)); // prepares the RoPE row of the first generation step (the ids are overwritten next)
     RUN(launch_fill_i32(s->cur_ids, 3, B, st));
     return 0;

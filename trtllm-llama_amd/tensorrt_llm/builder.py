@@ -91,6 +91,8 @@ class Builder():
             'tp_rank': cfg.get('tp_rank', 0), 'quant_mode': int(cfg.get('quant_mode', 0)),
             'neox_rotary_style': 1, 'precision': cfg['precision'],
             'remove_input_padding': 1 if network.plugin_config.remove_input_padding else 0,
+            'paged_kv_cache': 1 if network.plugin_config.paged_kv_cache else 0,
+            'tokens_per_block': int(getattr(network.plugin_config, 'tokens_per_block', 64)),
             'network_ops': ','.join(ops[:0]),  # the node list itself goes below as one JSON line
         }
         text = '\n'.join(f'{k}={v}' for k, v in header.items())

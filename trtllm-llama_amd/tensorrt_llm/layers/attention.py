@@ -53,7 +53,7 @@ class Attention(Module):
         self.dense = RowLinear(hidden_size, hidden_size, bias=bias, dtype=dtype, tp_group=tp_group, tp_size=tp_size)
 
     def _attend(self, qkv, hidden_states: RaggedTensor, past_key_value, sequence_length, past_key_value_length,
-                masked_tokens, cache_indirection):
+                masked_tokens, cache_indirection, kv_cache_block_pointers=None):
         cfg = default_net().plugin_config
         if not cfg.gpt_attention_plugin:
             raise ValueError('RoPE is only supported with GPTAttention plugin'
@@ -72,7 +72,8 @@ class Attention(Module):
                              hidden_states.row_lengths, hidden_states.max_row_length, cache_indirection,
                              self.num_attention_heads, self.attention_head_size, self.q_scaling,
                              self.rotary_embedding_dim, self.neox_rotary_style, self.multi_block_mode,
-                             self.multi_query_mode, kv_oq, kv_qo, self.use_int8_kv_cache)
+                             self.multi_query_mode, kv_oq, kv_qo, self.use_int8_kv_cache,
+                             kv_cache_block_pointers=kv_cache_block_pointers)
 
     def forward(self, hidden_states: RaggedTensor, attention_mask=None, past_key_value=None, sequence_length=None,
                 past_key_value_length=None, masked_tokens=None, use_cache=False, cache_indirection=None,
@@ -80,7 +81,7 @@ class Attention(Module):
         assert isinstance(hidden_states, RaggedTensor)
         qkv = self.qkv(hidden_states.data)
         context, present = self._attend(qkv, hidden_states, past_key_value, sequence_length, past_key_value_length,
-                                        masked_tokens, cache_indirection)
+                                        masked_tokens, cache_indirection, kv_cache_block_pointers)
         context = self.dense(context)
         context = RaggedTensor.from_row_lengths(context, hidden_states.row_lengths, hidden_states.max_row_length)
         return (context, present) if use_cache else context

@@ -48,13 +48,15 @@ class LLaMADecoderLayer(Module):
         self.post_layernorm = RmsNorm(normalized_shape=hidden_size, dtype=dtype)
 
     def forward(self, hidden_states: RaggedTensor, attention_mask=None, past_key_value=None, sequence_length=None,
-                past_key_value_length=None, masked_tokens=None, use_cache=False, cache_indirection=None):
+                past_key_value_length=None, masked_tokens=None, use_cache=False, cache_indirection=None,
+                kv_cache_block_pointers=None):
         x = hidden_states.data
         lengths, max_len = hidden_states.row_lengths, hidden_states.max_row_length
         normed = RaggedTensor.from_row_lengths(self.input_layernorm(x), lengths, max_len)
         attn = self.attention(normed, attention_mask=attention_mask, past_key_value=past_key_value,
                               sequence_length=sequence_length, past_key_value_length=past_key_value_length,
-                              masked_tokens=masked_tokens, use_cache=use_cache, cache_indirection=cache_indirection)
+                              masked_tokens=masked_tokens, use_cache=use_cache, cache_indirection=cache_indirection,
+                              kv_cache_block_pointers=kv_cache_block_pointers)
         presents = None
         if use_cache:
             attn, presents = attn
@@ -82,18 +84,21 @@ class LLaMAModel(Module):
 
     def forward(self, input_ids: RaggedTensor, position_ids=None, past_key_value=None, sequence_length=None,
                 past_key_value_length=None, masked_tokens=None, use_cache=False, attention_mask=None,
-                cache_indirection=None):
+                cache_indirection=None, kv_cache_block_pointers=None):
         hidden = self.vocab_embedding(input_ids.data)
         if past_key_value is None:
             past_key_value = tuple([None] * len(self.layers))
+        if kv_cache_block_pointers is None:
+            kv_cache_block_pointers = tuple([None] * len(self.layers))
         if attention_mask is not None:
             attention_mask = expand_mask(attention_mask, shape(input_ids.data, -1))
         hidden = RaggedTensor.from_row_lengths(hidden, input_ids.row_lengths, input_ids.max_row_length)
         presents = []
-        for layer, past in zip(self.layers, past_key_value):
+        for layer, past, pointers in zip(self.layers, past_key_value, kv_cache_block_pointers):
             hidden = layer(hidden, past_key_value=past, sequence_length=sequence_length,
                            past_key_value_length=past_key_value_length, masked_tokens=masked_tokens,
-                           use_cache=use_cache, attention_mask=attention_mask, cache_indirection=cache_indirection)
+                           use_cache=use_cache, attention_mask=attention_mask, cache_indirection=cache_indirection,
+                           kv_cache_block_pointers=pointers)
             if use_cache:
                 hidden, present = hidden
                 presents.append(present)
@@ -126,9 +131,9 @@ class LLaMAForCausalLM(LLaMAModel):
 
     def forward(self, input_ids: RaggedTensor, position_ids=None, past_key_value=None, sequence_length=None,
                 past_key_value_length=None, masked_tokens=None, use_cache=False, last_token_ids=None,
-                attention_mask=None, cache_indirection=None):
+                attention_mask=None, cache_indirection=None, kv_cache_block_pointers=None):
         hidden = super().forward(input_ids, position_ids, past_key_value, sequence_length, past_key_value_length,
-                                 masked_tokens, use_cache, attention_mask, cache_indirection)
+                                 masked_tokens, use_cache, attention_mask, cache_indirection, kv_cache_block_pointers)
         presents = None
         if use_cache:
             hidden, presents = hidden
@@ -168,10 +173,25 @@ class LLaMAForCausalLM(LLaMAModel):
             input_ids = named('input_ids', [-1, -1], [('batch_size', [bb]), ('input_len', [inlen])])
             position_ids = named('position_ids', [-1, -1], [('batch_size', [bb]), ('input_len', [inlen])])
         past_key_value = []
+        paged = default_net().plugin_config.paged_kv_cache
+        block_pointers = []
         for i in range(self.num_layers):
-            kv = Tensor(name=f'past_key_value_{i}', dtype=self.kv_dtype, shape=[-1, 2, num_heads, -1, head_size],
-                        dim_range=OrderedDict([('batch_size', [bb]), ('kv', [2]), ('num_heads', [num_heads]),
-                                               ('past_key_len', [lens]), ('head_size', [head_size])]))
+            if paged:
+                # the block pool [blocks, 2, heads, tokens_per_block, head_size] and, per layer, the table of block pointers
+                # int64 [batch, beam, 2, max_blocks] carried as int32 pairs (T/tensorrt_llm/models/gpt/model.py prepare_inputs)
+                tpb = default_net().plugin_config.tokens_per_block
+                nblk = [1, (max_len // tpb + 2) // 2, -(-max_len // tpb)]
+                kv = Tensor(name=f'past_key_value_{i}', dtype=self.kv_dtype, shape=[-1, 2, num_heads, tpb, head_size],
+                            dim_range=OrderedDict([('blocks', [[1, bb[2] * nblk[2] // 2 + 1, bb[2] * nblk[2]]]), ('kv', [2]),
+                                                   ('num_heads', [num_heads]), ('tokens_per_block', [tpb]),
+                                                   ('head_size', [head_size])]))
+                block_pointers.append(named(f'kv_cache_block_pointers_{i}', [-1, -1, 2, -1],
+                                            [('batch_size', [bs]), ('beam_width', [beams]), ('kv', [2]),
+                                             ('max_blocks_x2', [[2 * n for n in nblk]])]))
+            else:
+                kv = Tensor(name=f'past_key_value_{i}', dtype=self.kv_dtype, shape=[-1, 2, num_heads, -1, head_size],
+                            dim_range=OrderedDict([('batch_size', [bb]), ('kv', [2]), ('num_heads', [num_heads]),
+                                                   ('past_key_len', [lens]), ('head_size', [head_size])]))
             past_key_value.append(kv)
             assertion(shape(input_ids, 0), 'batch size')
         sequence_length = named('sequence_length', [-1], [('batch_size', [bb])])
@@ -183,5 +203,6 @@ class LLaMAForCausalLM(LLaMAModel):
         cache_indirection = named('cache_indirection', [-1, -1, -1],
                                   [('batch_size', [bs]), ('beam_width', [beams]), ('max_seq_len', [lens])])
         input_ids_ragged = RaggedTensor.from_row_lengths(input_ids, input_lengths, max_input_length)
-        return (input_ids_ragged, position_ids, past_key_value, sequence_length, past_key_value_length, masked_tokens,
-                True, last_token_ids, None, cache_indirection)
+        inputs = (input_ids_ragged, position_ids, past_key_value, sequence_length, past_key_value_length, masked_tokens,
+                  True, last_token_ids, None, cache_indirection)
+        return inputs + (block_pointers, ) if paged else inputs

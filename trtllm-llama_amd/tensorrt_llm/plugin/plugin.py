@@ -40,6 +40,7 @@ class PluginConfig(object):
         self.quantize_per_token_plugin = False
         self.quantize_tensor_plugin = False
         self.paged_kv_cache = False
+        self.tokens_per_block = 64
         self.lookup_plugin = False
         self.in_flight_batching = False
         # MI355X addition: the RMSNorm(+int8 quant) plugin that LLaMA's SmoothQuant needs (SURVEY "fact 1")

@@ -53,8 +53,8 @@ class GenerationSession(object):
         assert isinstance(model_config, ModelConfig)
         if not model_config.gpt_attention_plugin:
             raise ValueError('the MI355X LLaMA path needs the gpt_attention plugin (RoPE lives in it)')
-        if model_config.paged_kv_cache or model_config.multi_query_mode:
-            raise NotImplementedError('paged_kv_cache / multi_query_mode are not built')
+        if model_config.multi_query_mode:
+            raise NotImplementedError('multi_query_mode is not built')
         self._model_config = model_config
         self.mapping = mapping
         self.debug_mode = debug_mode
