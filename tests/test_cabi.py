@@ -71,12 +71,19 @@ def test_creation_contract_missing_unknown_and_unbuilt_fields():
     # unknown field
     assert capi.Plugin.create('GPTAttention', attention_fields() + [capi.PluginField('bogus', i32(1))]) is None
     # options of the contract that are not built are rejected, not ignored
-    for k, v in (('multi_query_mode', i8(1)), ('fp8_kv_cache', i32(1)), ('paged_kv_cache', i32(1)),
-                 ('in_flight_batching', i32(1))):
+    for k, v in (('multi_query_mode', i8(1)), ('fp8_kv_cache', i32(1)), ('in_flight_batching', i32(1))):
         assert capi.Plugin.create('GPTAttention', attention_fields(**{k: v})) is None, k
         assert capi.last_error()
-    # packed inputs ARE built
+    # packed inputs and the paged KV cache ARE built
     assert capi.Plugin.create('GPTAttention', attention_fields(remove_input_padding=i8(1))) is not None
+    paged = capi.Plugin.create('GPTAttention', attention_fields(paged_kv_cache=i32(1)))
+    assert paged is not None
+    # ... and it takes one more input (the block pointers, int32 pairs) after the 8 (+2 with int8 KV) of the linear cache
+    B, S, H, Dh, T, M = 2, 16, 32, 128, 64, 3
+    shapes = [[B, S, 3 * H * Dh], [B * M, 2, H, T, Dh], [B], [2], [B, M * T], [B], [S], [B, 1, M * T], [1], [1], [B, 1, 2, 2 * M]]
+    types = [capi.HALF, capi.INT8] + [capi.INT32] * 6 + [capi.FLOAT] * 2 + [capi.INT32]
+    for pos in range(len(shapes) + 2):
+        assert paged.supports_format(pos, shapes + [[B, S, H * Dh], shapes[1]], types + [capi.HALF, capi.INT8], len(shapes), 2), pos
     # head sizes the reference asserts (functional.py:2831)
     assert capi.Plugin.create('GPTAttention', attention_fields(head_size=i32(100))) is None
 
