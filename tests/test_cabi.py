@@ -83,7 +83,7 @@ def test_creation_contract_missing_unknown_and_unbuilt_fields():
     shapes = [[B, S, 3 * H * Dh], [B * M, 2, H, T, Dh], [B], [2], [B, M * T], [B], [S], [B, 1, M * T], [1], [1], [B, 1, 2, 2 * M]]
     types = [capi.HALF, capi.INT8] + [capi.INT32] * 6 + [capi.FLOAT] * 2 + [capi.INT32]
     for pos in range(len(shapes) + 2):
-        assert paged.supports_format(pos, shapes + [[B, S, H * Dh], shapes[1]], types + [capi.HALF, capi.INT8], len(shapes), 2), pos
+        assert paged.supports_format(pos, shapes + [[B, S, H * Dh], shapes[1]], types + [capi.HALF, capi.INT8], len(shapes)), pos
     # head sizes the reference asserts (functional.py:2831)
     assert capi.Plugin.create('GPTAttention', attention_fields(head_size=i32(100))) is None
 
