@@ -118,15 +118,27 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     stream = torch.cuda.current_stream().cuda_stream
     sess.fake_context(args.context, seed=1, stream=stream)
     sess.step(2, use_graph=False, stream=stream)  # eager: lazy init outside the capture
-    sess.step(max(W, 1), use_graph=True, stream=stream)  # captures the graph, W untimed warm-up steps
+    # captures the graph + W untimed warm-up steps.  Insurance for N > 1: if the capture fails (e.g. a collective that cannot
+    # be captured on this software stack) the run continues with eager launches instead of dying - the result line says so.
+    use_graph = True
+    try:
+        sess.step(max(W, 1), use_graph=True, stream=stream)
+    except RuntimeError as e:
+        print(f'[bench rank {rank}] graph capture failed ({e}); falling back to eager steps', file=sys.stderr, flush=True)
+        use_graph = False
+        sess.step(max(W, 1), use_graph=False, stream=stream)  # the same collectives the other ranks' warm-up issues
     torch.cuda.synchronize()
+    if world > 1:
+        flag = torch.tensor([1 if use_graph else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_graph = bool(flag.item())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    sess.step(K, use_graph=True, stream=stream)
+    sess.step(K, use_graph=use_graph, stream=stream)
     e1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -143,7 +155,7 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     # context length seen by the timed steps: context + 2 + W ... + K (mean)
     l_mean = args.context + 2 + max(W, 1) + (K - 1) / 2.0
     step_bytes = sess.step_bytes(int(round(l_mean)))
-    res = dict(mode=mode, wall_s=wall, dev_ms=dev_ms, ms_per_step=wall * 1e3 / K, tokens_per_s=K / wall, finite=finite,
+    res = dict(graph=use_graph, mode=mode, wall_s=wall, dev_ms=dev_ms, ms_per_step=wall * 1e3 / K, tokens_per_s=K / wall, finite=finite,
                step_bytes=step_bytes, mean_context=l_mean)
     # instrumented pass for the roofline of the dominant kernel (layer GEMVs) — rank 0 reports
     prof = sess.profile(8, stream=stream)
@@ -401,7 +413,8 @@ def main():
         'data': 'synthetic',
         'config': {'workload': f'LLaMA-7B ({args.layers} layers) {names[args.config]}, batch 1, context {args.context} '
                                f'(synthetic KV), greedy decode, TP={world}', 'global_batch': 1,
-                   'seq_len': args.context, 'parallelism': f'tp{world}', 'allreduce': allreduce_path},
+                   'seq_len': args.context, 'parallelism': f'tp{world}', 'allreduce': allreduce_path,
+                   'step_launch': 'hipGraph replay' if res.get('graph', True) else 'eager (graph capture failed)'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                      # name as rocprofv3 prints it: gemv_kernel<WT, PK_NORM = 1, EK_SWIGLU = 1, MB = 1, NXV = 2>

@@ -262,9 +262,9 @@ def test_prefill_gemm_every_tile_shape(cfg):
 
 
 # ---------------------------------------------------------------------------------------------- attention
-def attention_plugin(H, Dh, int8_kv, rot=None, neox=1, packed=0):
+def attention_plugin(H, Dh, int8_kv, rot=None, neox=1, packed=0, q_scaling=1.0):
     return make_plugin('GPTAttention', [
-        ('num_heads', i32(H)), ('head_size', i32(Dh)), ('unidirectional', i32(1)), ('q_scaling', f32(1.0)),
+        ('num_heads', i32(H)), ('head_size', i32(Dh)), ('unidirectional', i32(1)), ('q_scaling', f32(q_scaling)),
         ('rotary_embedding_dim', i32(Dh if rot is None else rot)), ('neox_rotary_style', i8(neox)),
         ('context_fmha_type', i8(0)), ('multi_block_mode', i8(0)), ('multi_query_mode', i8(0)),
         ('int8_kv_cache', i32(int8_kv)), ('fp8_kv_cache', i32(0)), ('remove_input_padding', i8(packed)),
@@ -380,6 +380,47 @@ def test_mmha_decode_beam_cache_indirection(int8_kv, H, Dh, L, W):
     else:
         np.testing.assert_allclose(got[:, :, :, L].astype(np.float32), ref_cache[:, :, :, L].astype(np.float32),
                                    atol=2e-4, rtol=2e-3)
+
+
+@pytest.mark.parametrize('int8_kv', [0, 1])
+@pytest.mark.parametrize('Dh,rot,q_scaling', [(128, 128, 1.0), (128, 64, 2.0), (64, 32, 0.5), (32, 32, 1.0)])
+def test_gptj_rotary_partial_dim_and_q_scaling(int8_kv, Dh, rot, q_scaling):
+    """The plugin fields LLaMA leaves at their defaults: GPT-J style RoPE (pairs (2i, 2i+1), neox_rotary_style = 0), a
+    rotary dimension smaller than the head (the tail is not rotated) and q_scaling != 1 (inv_sqrt_dh = 1 / (sqrt(Dh) *
+    q_scaling), gptAttentionCommon.cpp:163) - context phase and one generation step against the oracle."""
+    r = rng(500 + Dh + rot)
+    H, B, S = 4, 2, 70
+    smax = S + 8
+    in_len = [S, S - 9]
+    kv_scale = 0.05
+    scales = (1.0 / kv_scale, kv_scale) if int8_kv else None
+    p = attention_plugin(H, Dh, int8_kv, rot=rot, neox=0, q_scaling=q_scaling)
+    qkv = h(r.standard_normal((B, S, 3 * H * Dh)))
+    qkv_in = qkv.clone()
+    dt = torch.int8 if int8_kv else torch.float16
+    cache = torch.zeros((B, 2, H, smax, Dh), dtype=dt, device='cuda')
+    masked = np.zeros((B, smax), np.int32)
+    masked[1, in_len[1]:S] = 1
+    out = run_attention(p, qkv, cache, [S, S], 0, True, masked, in_len, S, smax, scales)
+    ref_cache = np.zeros((B, 2, H, smax, Dh), dtype=np.int8 if int8_kv else np.float16)
+    ref, _ = O.context_attention(as_f32(qkv_in), ref_cache, in_len, H, Dh, rot, False, q_scaling, scales[0] if scales else None)
+    np.testing.assert_allclose(as_f32(out), ref, atol=5e-3, rtol=0)
+    got = cache.cpu().numpy()
+    np.testing.assert_array_equal(got[:, 1], ref_cache[:, 1])  # V is never rotated
+    if not int8_kv:
+        np.testing.assert_allclose(got[:, 0].astype(np.float32), ref_cache[:, 0].astype(np.float32), atol=2e-4, rtol=2e-3)
+        # the un-rotated tail of K is a pure copy
+        src = as_f32(qkv_in).reshape(B, S, 3, H, Dh)
+        for b in range(B):
+            np.testing.assert_array_equal(got[b, 0, :, :in_len[b], rot:].astype(np.float32),
+                                          src[b, :in_len[b], 1, :, rot:].transpose(1, 0, 2))
+    # one generation step on top of the oracle's cache
+    cache = torch.from_numpy(ref_cache.copy()).cuda()
+    q1 = h(r.standard_normal((B, 1, 3 * H * Dh)))
+    out = run_attention(p, q1, cache, [S, S], S, False, masked, in_len, S, smax, scales)
+    ref = O.mmha_decode(as_f32(q1)[:, 0], ref_cache, [S, S], in_len, S, S, H, Dh, rot, False, q_scaling, masked,
+                        scales[0] if scales else None, scales[1] if scales else None)
+    np.testing.assert_allclose(as_f32(out)[:, 0], ref, atol=2e-3, rtol=0)
 
 
 @pytest.mark.parametrize('int8_kv', [0, 1])
