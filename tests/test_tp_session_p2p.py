@@ -16,6 +16,7 @@ GOLD = os.path.join(ROOT, 'tests', 'golden')
 pytestmark = pytest.mark.gpu
 
 NEW = 40
+NEW_BEAM = 10
 
 
 def model():
@@ -95,7 +96,16 @@ def _rank(rank, world, port, q):
         s.step(NEW - 1, use_graph=True)  # captured graph with the peer-to-peer kernels inside, replayed 39 times
         out = s.output_ids()
         s.close()
-        q.put((rank, logits_ctx, logits_dec, out, lib.tllm_comm_p2p_error()))
+        # beam search over a paged cache, sharded: the beam step reads the vocabulary-split logits [tp, batch * beam, V / tp]
+        s = NativeSession(dict(CFG, quant_mode=0, tp_size=world, tp_rank=rank, paged_kv_cache=1, tokens_per_block=8))
+        for k, v in shard(t, world, rank).items():
+            s.set_tensor(k, v)
+        s.finalize()
+        s.setup(B, S, NEW_BEAM, beam_width=2)
+        s.generate(ids, lens, NEW_BEAM)
+        beams, cum = s.beam_output()
+        s.close()
+        q.put((rank, logits_ctx, logits_dec, out, lib.tllm_comm_p2p_error(), beams, cum))
         dist.barrier()
         lib.tllm_comm_destroy_all()
     except BaseException as e:  # the parent must not wait for a result that will never come
@@ -117,7 +127,7 @@ def test_tp2_sessions_on_one_gpu_match_the_unsharded_session():
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in procs]
-    assert all(len(r) == 5 for r in res), [r for r in res if len(r) != 5]
+    assert all(len(r) == 7 for r in res), [r for r in res if len(r) != 7]
     res = sorted(res, key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
@@ -137,7 +147,21 @@ def test_tp2_sessions_on_one_gpu_match_the_unsharded_session():
     s.step(NEW - 1, use_graph=True)
     ref_out = s.output_ids()
     s.close()
-    for rank, lc, ld, out, err in res:
+    s = NativeSession(dict(CFG, quant_mode=0))
+    for k, v in shard(t, 1, 0).items():
+        s.set_tensor(k, v)
+    s.finalize()
+    s.setup(B, S, NEW_BEAM, beam_width=2)
+    s.generate(ids, lens, NEW_BEAM)
+    ref_beams, ref_cum = s.beam_output()
+    s.close()
+    # beam search: the ranks agree with each other exactly, and with the un-sharded linear-cache run up to near-ties
+    np.testing.assert_array_equal(res[0][5], res[1][5])
+    np.testing.assert_array_equal(res[0][6], res[1][6])
+    assert res[0][5].shape == ref_beams.shape == (B, 2, S + NEW_BEAM)
+    np.testing.assert_allclose(res[0][6], ref_cum, atol=0.1)
+    np.testing.assert_array_equal(res[0][5][:, :, :S + 2], ref_beams[:, :, :S + 2])
+    for rank, lc, ld, out, err, _, _ in res:
         assert err == 0, f'rank {rank}: a peer-to-peer wait timed out'
         scale = max(np.abs(ref_ctx).max(), 1.0)
         np.testing.assert_allclose(lc, ref_ctx, atol=2e-2 * scale)
