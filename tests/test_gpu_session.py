@@ -320,6 +320,42 @@ def test_packed_context_equals_padded(mode, int8_kv):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('S,int8_kv', [(1080, 1), (1080, 0), (1750, 1), (2200, 0)])
+def test_long_contexts_cover_every_generation_attention_geometry(S, int8_kv):
+    """The session picks the split-KV geometry of the generation attention from the cache capacity: 12 rows per lane group
+    (<= 1536 slots) or 16 (<= 2048) with the merge fused into the O-projection, the fine split with its own combine launch
+    beyond.  Context logits and three generation steps (eager + graph) against the oracle at each."""
+    cfg, w = synth_model(41)
+    B, NEW = 2, 5
+    r = np.random.default_rng(S)
+    lens = np.array([S, S - 333], np.int32)
+    ids = np.full((B, S), 2, np.int32)
+    for b in range(B):
+        ids[b, :lens[b]] = r.integers(3, cfg['vocab_size'], lens[b])
+    # weight-only int8 with the int8 cache: the activations stay fp16, so the comparison keeps the tight fp16-path bound (the
+    # SmoothQuant paths amplify 1-LSB quantiser flips over a thousand positions into a bulk error that says nothing here)
+    mode = 'woq8' if int8_kv else 'fp16'
+    qmodel = QO.quantise_model(cfg, w, mode, int8_kv, calib_ids=ids[:, :64], calib_lens=np.array([64, 64], np.int32))
+    s = NativeSession(dict(cfg, quant_mode=qmodel['quant_mode']))
+    for k, v in qmodel['engine_tensors'].items():
+        s.set_tensor(k, v)
+    s.finalize()
+    s.setup(B, S, NEW)
+    s.context(ids, lens)
+    got = [s.logits()]
+    s.step(1, use_graph=False)
+    got.append(s.logits())
+    s.step(2, use_graph=True)
+    got.append(s.logits())
+    out = s.output_ids()
+    s.close()
+    ref, _ = QO.run_model(qmodel, ids, lens, 4, feed_ids=out[:, S:S + 4])
+    scale = max(np.abs(ref[0]).max(), 1.0)
+    for g, rr in ((got[0], ref[0]), (got[1], ref[1]), (got[2], ref[3])):
+        np.testing.assert_allclose(g, rr, atol=3e-2 * scale)
+        assert np.abs(g - rr).mean() < 5e-3 * scale
+
+
 def test_end_id_stops_a_sequence_and_leaves_the_others_alone():
     """Stop criteria on the device (K/stopCriteriaKernels.cu, generation.py:943-983): once a sequence emits end_id it keeps
     emitting end_id, the other sequences of the batch continue exactly as without a stop token, and generate() returns as

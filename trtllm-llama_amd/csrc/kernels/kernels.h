@@ -158,7 +158,7 @@ struct MmhaParams
     int32_t rope_table_len = 0;
     const float* rope_row = nullptr; // optional f32 [B, rotary_dim/2, 2]: this step's cos/sin row, prepared on the
                                      // device by the sampler (removes the length -> position -> table dependency)
-    int32_t rows_per_group = 0;      // cache rows per lane group and split: 4 (default, finest split) or 16
+    int32_t rows_per_group = 0;      // cache rows per lane group and split: 4 (default, finest split), 12 or 16
     // beam search (MM/...Template.h:1137-1146, :1624-1631): `batch` counts batch x beam sequences; sequence bb = b * beam_width
     // + k reads the K/V of timestep t from the cache rows of sequence b * beam_width + cache_indirection[bb, t]
     const int32_t* cache_indirection = nullptr; // int32 [batch, max_seq_len]
