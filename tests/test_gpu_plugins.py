@@ -145,7 +145,10 @@ def test_swiglu():
 # ---------------------------------------------------------------------------------------------- SmoothQuant GEMM
 @pytest.mark.parametrize('out_dtype', ['float16', 'float32', 'int32'])
 @pytest.mark.parametrize('per_token,per_channel', [(0, 0), (1, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize('m,n,k', [(32, 2304, 768), (1, 4096, 4096), (5, 3072, 768)])
+@pytest.mark.parametrize('m,n,k', [(32, 2304, 768), (1, 4096, 4096), (5, 3072, 768),
+                                   # single-token "few rows, long K" shapes: the K-split one-shot kernel (gemv_ksplit.hip) -
+                                   # the 7B down-projection, ragged row / chunk counts, its K limits (5 .. 12 KiB rows)
+                                   (1, 4096, 11008), (1, 1003, 5120), (1, 13, 12288), (1, 520, 4112), (1, 64, 8192)])
 def test_smooth_quant_gemm_exact(out_dtype, per_token, per_channel, m, n, k):
     torch.manual_seed(0)
     a = torch.randint(-128, 128, (m, k), dtype=torch.int8)
