@@ -95,8 +95,8 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     }
     a.nchunks = (a.Kp + 64 * vec - 1) / (64 * vec);
     a.ngroups = swiglu ? p.N : (p.N + R - 1) / R;
-    if (gemv_sq_ksplit_applies(a) && !getenv("TLLM_NO_KSPLIT"))
-        return launch_gemv_sq_ksplit(a, stream);
+    if (gemv_ksplit_applies(a) && !getenv("TLLM_NO_KSPLIT"))
+        return launch_gemv_ksplit(a, stream);
     switch (p.wtype)
     {
     case W_FP16: return launch_gemv_fp16(a, pk, swiglu, stream);

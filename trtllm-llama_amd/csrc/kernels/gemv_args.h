@@ -44,9 +44,9 @@ int launch_gemv_fp16(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream)
 int launch_gemv_woq8(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
 int launch_gemv_woq4(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
 int launch_gemv_sq(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
-// "few rows, long K" single-token SmoothQuant projections (gemv_ksplit.hip)
-bool gemv_sq_ksplit_applies(const GemvArgs& a);
-int launch_gemv_sq_ksplit(const GemvArgs& a, hipStream_t stream);
+// "few rows, long K" single-token projections, every weight type (gemv_ksplit.hip)
+bool gemv_ksplit_applies(const GemvArgs& a);
+int launch_gemv_ksplit(const GemvArgs& a, hipStream_t stream);
 
 } // namespace kernels
 } // namespace tllm
