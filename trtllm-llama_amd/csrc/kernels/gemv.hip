@@ -95,7 +95,8 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     }
     a.nchunks = (a.Kp + 64 * vec - 1) / (64 * vec);
     a.ngroups = swiglu ? p.N : (p.N + R - 1) / R;
-    if (gemv_ksplit_applies(a) && !getenv("TLLM_NO_KSPLIT"))
+    static const bool ksplit_off = getenv("TLLM_NO_KSPLIT") != nullptr; // A/B switch
+    if (!ksplit_off && gemv_ksplit_applies(a))
         return launch_gemv_ksplit(a, stream);
     switch (p.wtype)
     {
