@@ -186,7 +186,9 @@ def test_smooth_quant_gemm_fp32_view_weight():
 @pytest.mark.parametrize('bits', [8, 4])
 @pytest.mark.parametrize('m,n,k', [(1, 1024, 4096), (3, 4096, 4096), (1, 4096, 11008), (24, 512, 1024),
                                     # prefill sizes: the fp16-expansion + LDS-DMA MFMA path (M >= 32), ragged M / N
-                                    (300, 456, 1152), (64, 1024, 4096)])
+                                    (300, 456, 1152), (64, 1024, 4096),
+                                    # single token, long K: the K-split one-shot kernel with ragged row / chunk counts
+                                    (1, 1000, 5120), (1, 16, 12288), (1, 520, 6144)])
 def test_weight_only_quant_matmul(bits, m, n, k):
     torch.manual_seed(0)
     w = (torch.rand(k, n) * 2 - 1).half()  # [in, out], as the loaders pass it
@@ -219,7 +221,8 @@ def test_weight_only_quant_matmul(bits, m, n, k):
         np.testing.assert_allclose(as_f32(out), deq, atol=max(deq.max(), 0) * rs * 1.5)
 
 
-@pytest.mark.parametrize('m,n,k', [(1, 4096, 4096), (2, 32000, 4096), (1, 4096, 11008), (19, 192, 64), (8, 24, 64)])
+@pytest.mark.parametrize('m,n,k', [(1, 4096, 4096), (2, 32000, 4096), (1, 4096, 11008), (19, 192, 64), (8, 24, 64),
+                                   (1, 1003, 5120), (1, 13, 12288), (1, 520, 2056)])  # K-split kernel, ragged rows / chunks
 def test_gemm_fp16(m, n, k):
     r = rng(5)
     x, w = h(r.standard_normal((m, k))), h(r.standard_normal((n, k)) / np.sqrt(k))
