@@ -194,15 +194,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 #pragma unroll
         for (int u = 0; u < U; ++u)
         {
-            const bool ok = ((c + u) * 64 + lane) * VEC < Kp;
+            // pure loads, nothing consumes them here (an operation on a loaded value inside a conditional block makes the
+            // compiler wait for the load inside that block): lanes beyond the row read a clamped, valid address and are
+            // neutralised when the tile is consumed - by zeroing the ACTIVATIONS that face them
             int64_t off = (int64_t) (c + u) * 1024 + lane_kbyte;
             off = off < last_vec ? off : last_vec;
 #pragma unroll
             for (int r = 0; r < R; ++r)
-            {
-                const uint4 v = ld_nt16(rowptr[r] + off);
-                wv[u][r] = make_uint4(ok ? v.x : TR::ZERO, ok ? v.y : TR::ZERO, ok ? v.z : TR::ZERO, ok ? v.w : TR::ZERO);
-            }
+                wv[u][r] = ld_nt16(rowptr[r] + off);
         }
     };
 
@@ -298,13 +297,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 #pragma unroll
             for (int j = 0; j < kNXV; ++j)
             {
-                xv[j] = make_uint4(0, 0, 0, 0);
-                if (j * 2048 < Kp) // uniform
-                {
-                    const int k = (tid + j * 256) * 8;
-                    const uint4 v = *reinterpret_cast<const uint4*>(xg + (k < K ? k : K - 8));
-                    xv[j] = make_uint4(k < K ? v.x : 0u, k < K ? v.y : 0u, k < K ? v.z : 0u, k < K ? v.w : 0u);
-                }
+                // a pure load from a clamped address, no branch and nothing consuming the value here: a select on the loaded
+                // value inside a conditional block made hipcc wait for each of these loads in turn - two serialised round
+                // trips before the first weight tile was even requested.  Vectors beyond K are zeroed by mask_x().
+                const int k = (tid + j * 256) * 8;
+                xv[j] = *reinterpret_cast<const uint4*>(xg + (k < K ? k : K - 8));
             }
         }
         else
@@ -314,13 +311,21 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 #pragma unroll
             for (int j = 0; j < kNXV; ++j)
             {
-                xv[j] = make_uint4(0, 0, 0, 0);
-                if (j * 4096 < Kp) // uniform
-                {
-                    const int k = (tid + j * 256) * 16;
-                    const uint4 v = *reinterpret_cast<const uint4*>(xg + (k < K ? k : K - 16));
-                    xv[j] = make_uint4(k < K ? v.x : 0u, k < K ? v.y : 0u, k < K ? v.z : 0u, k < K ? v.w : 0u);
-                }
+                const int k = (tid + j * 256) * 16;
+                xv[j] = *reinterpret_cast<const uint4*>(xg + (k < K ? k : K - 16));
+            }
+        }
+    };
+    // zero the activation vectors beyond K (after the loads have been issued; PK_ATTN builds exact vectors itself)
+    auto mask_x = [&]() {
+        if constexpr (PK != PK_ATTN)
+        {
+            constexpr int XVEC = X_HALF ? 8 : 16;
+#pragma unroll
+            for (int j = 0; j < kNXV; ++j)
+            {
+                const bool ok = (tid + j * 256) * XVEC < K;
+                xv[j] = make_uint4(ok ? xv[j].x : 0u, ok ? xv[j].y : 0u, ok ? xv[j].z : 0u, ok ? xv[j].w : 0u);
             }
         }
     };
@@ -331,38 +336,62 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 #pragma unroll
         for (int j = 0; j < kNXV; ++j)
         {
-            gv[j] = make_uint4(0, 0, 0, 0);
-            if (j * 2048 < Kp) // uniform
-            {
-                const int k = (tid + j * 256) * 8;
-                gv[j] = *reinterpret_cast<const uint4*>(gam + (k < K ? k : K - 8));
-            }
+            const int k = (tid + j * 256) * 8;
+            gv[j] = *reinterpret_cast<const uint4*>(gam + (k < K ? k : K - 8)); // multiplies a zeroed x beyond K
         }
     }
     const int g0 = blockIdx.x * 4 + wid;
     const int gstride = gridDim.x * 4;
     const char* rowptr[R];
-    uint4 wv[U][R];
+    uint4 wv[U][R], wv2[U][R];
     rows_of_group(g0 < a.ngroups ? g0 : 0, rowptr);
     load_tile(rowptr, 0, wv);
+    // the tile stream of this wave: (group, chunk) of the next tile to request.  (Requesting the second ring buffer here too,
+    // before the prologue, was measured: slower on every shape - QKV 10.3 -> 11.2 us, gate|up 16.5 -> 18.0 us.)
+    const int tiles_per_group = (a.nchunks + U - 1) / U;
+    const int ngroups_mine = g0 < a.ngroups ? (a.ngroups - g0 + gstride - 1) / gstride : 0;
+    const int ntiles = ngroups_mine * tiles_per_group;
+    int t_issue = 1, gi_i = 0, ci_i = 1; // tile 0 is in flight in `wv`
+    if (ci_i == tiles_per_group)
+    {
+        ci_i = 0;
+        gi_i = 1;
+    }
+    auto issue_next = [&](uint4 (&buf)[U][R]) {
+        if (t_issue < ntiles) // wave-uniform
+        {
+            if (ci_i == 0)
+                rows_of_group(g0 + gi_i * gstride, rowptr);
+            load_tile(rowptr, ci_i * U, buf);
+            ++t_issue;
+            if (++ci_i == tiles_per_group)
+            {
+                ci_i = 0;
+                ++gi_i;
+            }
+        }
+    };
 
     constexpr int NOUTS = SWIGLU ? 1 : R;         // outputs per row group
     const int my_o = lane / MB, my_m = lane % MB; // the (output, row) this lane finishes
     const bool my_active = my_o < NOUTS && my_m < p.M;
+    // raw bits of the epilogue operands: converting a loaded fp16 here, inside the conditional block that loads it, makes
+    // hipcc wait for the load (and, the counter being in-order, for every load before it) on the spot
     struct EpiOps
     {
-        float s0, s1, res;
+        float s0, s1;
+        uint16_t h0, h1, res;
     };
     auto load_ops = [&](int g) {
-        EpiOps e = {1.f, 1.f, 0.f};
+        EpiOps e = {1.f, 1.f, 0, 0, 0};
         int n = g * NOUTS + (my_o < NOUTS ? my_o : 0);
         n = n < p.N ? n : p.N - 1; // clamped: inactive lanes load a valid element and ignore it
         if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
         {
             const uint16_t* sc = reinterpret_cast<const uint16_t*>(p.scale_col);
-            e.s0 = h2f(sc[n]);
+            e.h0 = sc[n];
             if constexpr (SWIGLU)
-                e.s1 = h2f(p.scale_col_up ? reinterpret_cast<const uint16_t*>(p.scale_col_up)[n] : sc[p.N + n]);
+                e.h1 = p.scale_col_up ? reinterpret_cast<const uint16_t*>(p.scale_col_up)[n] : sc[p.N + n];
         }
         else if constexpr (SQ)
         {
@@ -377,7 +406,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         if constexpr (!SWIGLU)
         {
             if (p.epi == EPI_RESIDUAL) // uniform
-                e.res = h2f(reinterpret_cast<const uint16_t*>(p.residual)[(int64_t) (my_m < p.M ? my_m : 0) * p.ldy + n]);
+                e.res = reinterpret_cast<const uint16_t*>(p.residual)[(int64_t) (my_m < p.M ? my_m : 0) * p.ldy + n];
         }
         return e;
     };
@@ -409,6 +438,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
             continue;
         if (m > 0)
             load_x_row(m);
+        mask_x();
         if constexpr (!X_HALF)
         {
 #pragma unroll
@@ -519,9 +549,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     }
 
     // ------------------------------------------------------------------ main loop: persistent waves, double buffer
-    const int tiles_per_group = (a.nchunks + U - 1) / U;
-    const int ngroups_mine = g0 < a.ngroups ? (a.ngroups - g0 + gstride - 1) / gstride : 0;
-    const int ntiles = ngroups_mine * tiles_per_group;
     float my_row_scale = static_row_scale, my_row_scale_up = static_row_scale_up;
     if (q_dyn)
     {
@@ -538,13 +565,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         for (int m = 0; m < MB; ++m)
             acc[r][m] = 0;
 
-    uint4 wv2[U][R];
-    int t_issue = 1, gi_i = 0, ci_i = 1; // tile 0 is already in flight in `wv`
-    if (ci_i == tiles_per_group)
-    {
-        ci_i = 0;
-        gi_i = 1;
-    }
     int gi_p = 0, ci_p = 0;
 
     auto step = [&](uint4 (&cur)[U][R], uint4 (&nxt)[U][R]) {
@@ -553,52 +573,46 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         const int n = g * NOUTS + (my_o < NOUTS ? my_o : 0);
         const bool fin = last && my_active && n < p.N;
         const int64_t oidx = (int64_t) my_m * p.ldy + n;
-        // (1) the next group's epilogue operands, (2) the next tile
+        // (1) the next group's epilogue operands
         EpiOps ops_nxt = ops_cur;
         if (last)
             ops_nxt = load_ops(g + gstride < a.ngroups ? g + gstride : g);
-        if (t_issue < ntiles)
-        {
-            if (ci_i == 0)
-                rows_of_group(g0 + gi_i * gstride, rowptr);
-            load_tile(rowptr, ci_i * U, nxt);
-            ++t_issue;
-            if (++ci_i == tiles_per_group)
-            {
-                ci_i = 0;
-                ++gi_i;
-            }
-        }
+        // (2) the next tile, into the other ring buffer
+        issue_next(nxt);
         // (3) dot products of the current tile
         const int c = ci_p * U;
 #pragma unroll
         for (int u = 0; u < U; ++u)
         {
             int k0 = ((c + u) * 64 + lane) * VEC;
-            k0 = k0 < Kp ? k0 : Kp - VEC; // out-of-range lanes: the weight vector is the neutral element
+            const bool ok = k0 < Kp; // out-of-range lanes: zero activations (any weight bits are then harmless)
+            k0 = ok ? k0 : Kp - VEC;
+            auto ldx = [&](const char* ptr) {
+                const uint4 v = *reinterpret_cast<const uint4*>(ptr);
+                return make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+            };
 #pragma unroll
             for (int m = 0; m < MB; ++m)
             {
                 const char* xr = xs + ((size_t) m * Kp + k0) * XES;
                 if constexpr (WT == W_FP16)
                 {
-                    const uint4 xa = *reinterpret_cast<const uint4*>(xr);
+                    const uint4 xa = ldx(xr);
 #pragma unroll
                     for (int r = 0; r < R; ++r)
                         acc[r][m] = dot_fp16(cur[u][r], xa, acc[r][m]);
                 }
                 else if constexpr (WT == W_INT8_WOQ)
                 {
-                    const uint4 xa = *reinterpret_cast<const uint4*>(xr);
-                    const uint4 xb = *reinterpret_cast<const uint4*>(xr + 16);
+                    const uint4 xa = ldx(xr);
+                    const uint4 xb = ldx(xr + 16);
 #pragma unroll
                     for (int r = 0; r < R; ++r)
                         acc[r][m] = dot_woq8(cur[u][r], xa, xb, acc[r][m]);
                 }
                 else if constexpr (WT == W_INT4_WOQ)
                 {
-                    const uint4* xp = reinterpret_cast<const uint4*>(xr);
-                    const uint4 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+                    const uint4 x0 = ldx(xr), x1 = ldx(xr + 16), x2 = ldx(xr + 32), x3 = ldx(xr + 48);
 #pragma unroll
                     for (int r = 0; r < R; ++r)
                     {
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
                 }
                 else
                 {
-                    const uint4 xa = *reinterpret_cast<const uint4*>(xr);
+                    const uint4 xa = ldx(xr);
 #pragma unroll
                     for (int r = 0; r < R; ++r)
                         acc[r][m] = dot_sq(cur[u][r], xa, acc[r][m]);
@@ -644,10 +658,15 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
                 if (SWIGLU && r == 1 && lane == m)
                     v1 = (float) tot;
             }
-        const EpiOps e = ops_cur;
+        EpiOps e = ops_cur;
         ops_cur = ops_nxt;
         if (!fin)
             return;
+        if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
+        {
+            e.s0 = h2f(e.h0);
+            e.s1 = h2f(e.h1);
+        }
         const float r0 = v0 * (e.s0 * my_row_scale);
         if constexpr (SWIGLU)
         {
@@ -660,7 +679,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         else
         {
             if (p.epi == EPI_RESIDUAL)
-                reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(h2f(f2h(r0)) + e.res);
+                reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(h2f(f2h(r0)) + h2f(e.res));
             else if (p.out_dtype == DT_HALF)
                 reinterpret_cast<uint16_t*>(p.y)[oidx] = f2h(r0);
             else if (p.out_dtype == DT_FLOAT)

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvParams p, in
     }
     // epilogue operands of row (tid % RW): every thread loads them (no lane-dependent branch around a load - that would make
     // the compiler fence it), threads 0 .. RW - 1 use them
-    float s0 = 1.f, srow = 1.f, res = 0.f;
+    float s0 = 1.f, srow = 1.f;
+    uint16_t s0_bits = 0, res_bits = 0; // fp16 operands stay raw until the epilogue (a conversion next to the load = a wait)
     const int n = row0 + (tid % RW) < p.N ? row0 + (tid % RW) : p.N - 1;
     if constexpr (SQ)
     {
@@ -82,9 +83,9 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvParams p, in
             srow = p.scale_row[0];
     }
     else if constexpr (WT != W_FP16)
-        s0 = h2f(reinterpret_cast<const uint16_t*>(p.scale_col)[n]);
+        s0_bits = reinterpret_cast<const uint16_t*>(p.scale_col)[n];
     if (p.epi == EPI_RESIDUAL) // uniform
-        res = h2f(reinterpret_cast<const uint16_t*>(p.residual)[n]);
+        res_bits = reinterpret_cast<const uint16_t*>(p.residual)[n];
     // ---- dots, reduction over the 64 lanes, exchange between the 4 K-slices
 #pragma unroll
     for (int r = 0; r < RW; ++r)
@@ -115,6 +116,9 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvParams p, in
     if (tid < RW && row0 + tid < p.N)
     {
         const acc_t tot = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        if constexpr (!SQ && WT != W_FP16)
+            s0 = h2f(s0_bits);
+        const float res = h2f(res_bits);
         const float r0 = (float) tot * (s0 * srow); // the general kernel's expression (srow = 1 unless SmoothQuant)
         if (p.epi == EPI_RESIDUAL)
             reinterpret_cast<uint16_t*>(p.y)[n] = f2h(h2f(f2h(r0)) + res);
