@@ -405,8 +405,10 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
         }
         if constexpr (!SWIGLU)
         {
-            if (p.epi == EPI_RESIDUAL) // uniform
-                e.res = reinterpret_cast<const uint16_t*>(p.residual)[(int64_t) (my_m < p.M ? my_m : 0) * p.ldy + n];
+            // unconditional (a load inside a conditional block ends in a full s_waitcnt): without a residual the address is
+            // y's own, valid and ignored
+            const uint16_t* rp = reinterpret_cast<const uint16_t*>(p.epi == EPI_RESIDUAL ? p.residual : p.y);
+            e.res = rp[(int64_t) (my_m < p.M ? my_m : 0) * p.ldy + n];
         }
         return e;
     };

@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvParams p, in
     }
     else if constexpr (WT != W_FP16)
         s0_bits = reinterpret_cast<const uint16_t*>(p.scale_col)[n];
-    if (p.epi == EPI_RESIDUAL) // uniform
-        res_bits = reinterpret_cast<const uint16_t*>(p.residual)[n];
+    // unconditional: a load inside a conditional block ends in a full s_waitcnt (without a residual: y's own address, ignored)
+    res_bits = reinterpret_cast<const uint16_t*>(p.epi == EPI_RESIDUAL ? p.residual : p.y)[n];
     // ---- dots, reduction over the 64 lanes, exchange between the 4 K-slices
 #pragma unroll
     for (int r = 0; r < RW; ++r)
