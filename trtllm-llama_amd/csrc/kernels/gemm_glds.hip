@@ -140,6 +140,20 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
                 glds16(src[i] + (int64_t) t * BKB, lds_base + stg * STAGE + c * 1024);
         }
     };
+    // the same, spread over the k-steps of the tile being computed: this wave's DMA instructions number i with
+    // i mod PARTS == part.  Issued in one burst right after the barrier they held every wave of the SIMD out of the matrix
+    // pipe for the whole burst (an LDS-DMA instruction costs its issuer 60-185 cycles); between the MFMA groups their issue
+    // time hides under the MFMAs already queued.
+    auto issue_part = [&](int t, int part, int parts) {
+        const int stg = t % S;
+#pragma unroll
+        for (int i = 0; i < CPW; ++i)
+        {
+            const int c = i * NW + wid;
+            if (i % parts == part && (!RAGGED || i < CPW - 1 || !short_wave)) // wave-uniform
+                glds16(src[i] + (int64_t) t * BKB, lds_base + stg * STAGE + c * 1024);
+        }
+    };
 
     using acc_t = typename std::conditional<SQ, i32x16, f32x16>::type;
     acc_t acc[MT][NT];
@@ -170,8 +184,10 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
         else
             wait_vmcnt<0>();
         __syncthreads();
-        if (t + D < ntile)
-            issue(t + D);
+        // the DMA of tile t + D is spread over the k-steps of tile t (see issue_part): every k-step with stages to spare, the
+        // first two k-steps when only one stage is ahead (it must land before the next barrier).  128 x 128 / 3 ahead (O, down)
+        // 49 -> 44 us in the real prefill, 256 x 192 / 1 ahead (QKV, gate, up) 53 -> 51 us stand-alone
+        constexpr int SPREAD_PARTS = S >= 3 ? KSTEPS : (KSTEPS >= 2 ? 2 : 1);
         const char* As = lds + (t % S) * STAGE;
         const char* Bs = As + BM * BKB;
 #pragma unroll
@@ -185,6 +201,12 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 bf[j] = *reinterpret_cast<const uint4*>(Bs + swz<BKB>((wn * NT + j) * 32 + fr, ks * 2 + fk));
+            if (k2 < SPREAD_PARTS && t + D < ntile)
+            {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_part(t + D, k2, SPREAD_PARTS);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
