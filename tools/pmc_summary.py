@@ -33,7 +33,7 @@ def main():
         rows.append(dict(kernel=name, calls=r['calls'], fetch_bytes=r['kib'] * 1024 * FETCH_CORRECTION,
                          write_bytes=wr['kib'] * 1024, avg_us_under_pmc=r['avg_us']))
     rows.sort(key=lambda r: -r['fetch_bytes'] * r['calls'])
-    gem = [r for r in rows if 'gemv_kernel' in r['kernel']]
+    gem = [r for r in rows if 'gemv_kernel' in r['kernel'] or 'gemv_ksplit_kernel' in r['kernel']]
     layer_calls = max(r['calls'] for r in gem)
     layer = [r for r in gem if r['calls'] == layer_calls]
     tot = sum((r['fetch_bytes'] + r['write_bytes']) * r['calls'] for r in layer)
