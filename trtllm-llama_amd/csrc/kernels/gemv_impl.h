@@ -286,10 +286,19 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
                     }
                 }
             };
-            if (p.attn_nsmax <= 6) // uniform
-                merge(std::integral_constant<int, 6>());
-            else
-                merge(std::integral_constant<int, 8>());
+            // the slot count is exact (uniform switch): every slot is 40 bytes per thread and vector through L2 whether it is
+            // active or not - with 7 splits (the 1024-token bench context) the 7-slot variant takes 7.7 us, the 8-slot one 8.4
+            switch (p.attn_nsmax)
+            {
+            case 1:
+            case 2:
+            case 3:
+            case 4: merge(std::integral_constant<int, 4>()); break;
+            case 5: merge(std::integral_constant<int, 5>()); break;
+            case 6: merge(std::integral_constant<int, 6>()); break;
+            case 7: merge(std::integral_constant<int, 7>()); break;
+            default: merge(std::integral_constant<int, 8>()); break;
+            }
         }
         else if constexpr (X_HALF)
         {
