@@ -288,6 +288,11 @@ struct GreedyParams
     int32_t rope_half = 0, rope_table_len = 0;
     const int32_t* input_lengths = nullptr;
     int32_t max_input_len = 0;
+    // optional: gather the chosen token's embedding row into the next step's input (fp16 [B, hidden]) - one launch and one
+    // dependent round trip less per generation step than a separate embedding kernel
+    const void* emb_table = nullptr; // fp16 [vocab, hidden]
+    void* x_out = nullptr;
+    int32_t hidden = 0;
 };
 int launch_greedy_step(const GreedyParams& p, hipStream_t stream);
 

@@ -490,6 +490,20 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const GreedyParams p)
         if (sl < p.out_stride)
             p.out_ids[(int64_t) b * p.out_stride + sl] = id;
         p.cur_ids[b] = id;
+        si[0] = id;
+    }
+    if (p.emb_table) // uniform: the next step's input row, gathered here instead of by an embedding launch of its own
+    {
+        __syncthreads();
+        const int id = si[0];
+        const bool ok = id >= 0 && id < p.vocab;
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(p.emb_table) + (int64_t) (ok ? id : 0) * p.hidden;
+        uint16_t* dst = reinterpret_cast<uint16_t*>(p.x_out) + (int64_t) b * p.hidden;
+        for (int k = threadIdx.x * 8; k < p.hidden; k += blockDim.x * 8) // hidden % 8 == 0 (checked by the launcher)
+        {
+            const uint4 v = *reinterpret_cast<const uint4*>(src + k);
+            *reinterpret_cast<uint4*>(dst + k) = ok ? v : make_uint4(0, 0, 0, 0);
+        }
     }
 }
 
@@ -878,6 +892,11 @@ int launch_greedy_step(const GreedyParams& p, hipStream_t stream)
 {
     if (p.batch <= 0)
         return 0;
+    if (p.emb_table && (!p.x_out || p.hidden <= 0 || (p.hidden & 7)))
+    {
+        set_error("greedy step: fused embedding gather needs x_out and hidden %% 8 == 0 (got %d)", p.hidden);
+        return -1;
+    }
     hipLaunchKernelGGL(greedy_step_kernel, dim3(p.batch), dim3(1024), 0, stream, p);
     return check_launch("greedy_step");
 }

@@ -658,6 +658,12 @@ struct tllm_session
         gp.rope_table_len = rope_len;
         gp.input_lengths = in_len;
         gp.max_input_len = max_in;
+        if (hidden % 8 == 0)
+        {
+            gp.emb_table = emb; // the sampler leaves the next step's input row in x (run_decode_step skips its embedding launch)
+            gp.x_out = x;
+            gp.hidden = hidden;
+        }
         return timed(PC_OTHER, st, [&] { return launch_greedy_step(gp, st) ? 1 : 0; });
     }
 
@@ -671,7 +677,7 @@ struct tllm_session
             return 1;
         }
         const int ok = only_kernel;
-        if (ok < 0)
+        if (ok < 0 && (beam > 1 || D % 8 != 0)) // greedy: the sampler gathered the row already
             RUN(timed(PC_OTHER, st, [&] { return launch_embedding(x, cur_ids, emb, B, D, vocab, st); }));
         const bool r0 = rank == 0;
         for (int li = 0; li < num_layers; ++li)
@@ -1264,6 +1270,7 @@ int32_t tllm_session_fake_context(tllm_session_t s, int32_t length, uint32_t see
         RUN(launch_fill_random(s->layers[i].kv, s->int8_kv ? DT_INT8 : DT_HALF, s->kv_elems, seed + 7919u * i, 1.0f, st));
     RUN(s->run_sampler(0, st)); // prepares the RoPE row of the first generation step (the ids are overwritten next)
     RUN(launch_fill_i32(s->cur_ids, 3, B, st));
+    RUN(launch_embedding(s->x, s->cur_ids, s->emb, B, s->hidden, s->vocab, st)); // what the sampler would have left in x
     return 0;
 }
 
