@@ -16,11 +16,11 @@ from tensorrt_llm.runtime.native import NativeSession
 pytestmark = pytest.mark.gpu
 
 
-def session(mode):
+def session(mode, **extra):
     cfg = dict(bench.LLAMA_7B)
     int8_kv = mode != 'fp16'
     dev = torch.device('cuda', 0)
-    s = NativeSession(dict(cfg, quant_mode=bench.QM[mode] | (bench.INT8_KV if int8_kv else 0), tp_size=1, tp_rank=0))
+    s = NativeSession(dict(cfg, quant_mode=bench.QM[mode] | (bench.INT8_KV if int8_kv else 0), tp_size=1, tp_rank=0, **extra))
     w = bench.synth_weights(torch, cfg, mode, int8_kv, 1, 0, dev)
     for k, v in w.items():
         s.set_tensor(k, v)
@@ -28,7 +28,7 @@ def session(mode):
     return s, cfg
 
 
-@pytest.mark.parametrize('mode', ['sq', 'fp16'])
+@pytest.mark.parametrize('mode', ['sq', 'fp16', 'woq8', 'woq4'])
 def test_full_size_replay_and_batch_invariance(mode):
     s, cfg = session(mode)
     S, NEW = 96, 20
@@ -38,13 +38,16 @@ def test_full_size_replay_and_batch_invariance(mode):
     # generate(): first step eager, the rest replayed from the graph
     s.setup(1, S, NEW)
     out_graph = s.generate(ids, lens, NEW)
+    logits_graph = s.logits()
     # all steps eager
     s.setup(1, S, NEW)
     s.context(ids, lens)
     s.step(NEW - 1, use_graph=False)
     out_eager = s.output_ids()
     np.testing.assert_array_equal(out_graph, out_eager)
-    assert len(set(out_graph[0, S:].tolist())) > 1, 'degenerate generation: the comparison would prove nothing'
+    np.testing.assert_array_equal(s.logits(), logits_graph)  # the whole distribution of the last step, not only its arg-max
+    if mode in ('sq', 'fp16'):  # (the int4 synthetic model repeats one token: there the logits carry the comparison)
+        assert len(set(out_graph[0, S:].tolist())) > 1, 'degenerate generation: the token comparison would prove nothing'
     # the same prompt twice in a batch of two
     s.setup(2, S, NEW)
     out2 = s.generate(np.repeat(ids, 2, 0), np.repeat(lens, 2), NEW)
@@ -73,3 +76,20 @@ def test_full_size_context_logits_do_not_depend_on_the_padding():
     np.testing.assert_allclose(again, full, atol=2e-2 * scale)  # a different tile split of the GEMMs: fp16 summation order only
     assert int(again.argmax()) == int(full.argmax())
     s.close()
+
+
+@pytest.mark.parametrize('beam', [1, 3])
+def test_full_size_paged_cache_equals_linear(beam):
+    """Paged KV cache (64-token blocks) at the full model size: same tokens as the linear cache, greedy and beam search, with
+    a prompt that ends in the middle of a block."""
+    S, NEW = 150, 12
+    r = np.random.default_rng(29)
+    ids = r.integers(3, 32000, (1, S)).astype(np.int32)
+    lens = np.array([S], np.int32)
+    outs = []
+    for paged in (0, 1):
+        s, _ = session('sq', paged_kv_cache=paged, tokens_per_block=64)
+        s.setup(1, S, NEW, beam_width=beam)
+        outs.append(s.generate(ids, lens, NEW))
+        s.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
