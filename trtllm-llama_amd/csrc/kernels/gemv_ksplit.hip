@@ -3,7 +3,7 @@
 //
 // Why a second kernel.  The general kernel walks a row pair in 4 KiB tiles through a two-tile ring; a wave that owns ONE
 // row pair of 11 KiB therefore pays the HBM latency three times in sequence (tile 1 is issued when tile 0 is consumed,
-// tile 2 when tile 1 is) - measured 12.3 us against 8.3 us for streaming the same 45 MB.  Here a workgroup owns RW rows and
+// tile 2 when tile 1 is) - measured 12.3 us against 8.3 us for streaming the same 45 MB.  Here a workgroup owns RW (2 - 4) rows and
 // its 4 waves split K (wave w takes the 1 KiB chunks w, w + 4, w + 8, ...): every byte the workgroup needs - up to 24 weight
 // vectors per lane, the activations that face them, the epilogue's scale and residual - is requested at t = 0, ONE memory
 // round trip, then the dot products, a DPP reduction per row, a small exchange through LDS and the epilogue.  The
@@ -29,7 +29,9 @@ struct KSplit
     static constexpr int VEC = WTraits<WT>::VEC;                  // weights per 16-byte vector
     static constexpr bool SQ = WTraits<WT>::IS_SQ;
     static constexpr int XV = SQ ? 1 : VEC / 8;                   // 16-byte activation vectors per weight vector
-    static constexpr int RW = WT == W_FP16 ? 4 : 8;               // rows per workgroup
+    // rows per workgroup, measured per weight type on the 7B down-projection (us, rows 8 / 4 / 2): SmoothQuant 9.7 / 9.4 / 9.0,
+    // weight-only int8 10.05 / 9.36 / 9.85, int4 8.55 / 7.74 / -, fp16 - / 15.07 / 15.37
+    static constexpr int RW = WT == W_INT8_SQ ? 2 : 4;
     static constexpr int NCMAX = WT == W_FP16 ? 6 : (WT == W_INT4_WOQ ? 2 : 3); // chunks per wave: 24 / 16 weight vectors per lane
 };
 
