@@ -745,7 +745,12 @@ int launch_inst(const GemvArgs& a, hipStream_t stream)
         it = occ_cache.emplace(smem, nb > 8 ? 8 : nb).first;
     }
     int blocks = (a.ngroups + 3) / 4;
-    const int max_blocks = cus * (gemv_tune_blocks_per_cu > 0 ? gemv_tune_blocks_per_cu : it->second);
+    // persistent workgroups per CU: what fits (occupancy query) for the SwiGLU kernel (gate|up: 16.4 us with 4 per CU, 17.6 with
+    // 2); two for the plain projections (QKV: 9.9 us with 2, 10.4 with 3 - 4: fewer, longer-lived waves amortise the RMSNorm
+    // prologue over three row groups instead of two)
+    const int fit = it->second;
+    const int want = EK == EK_SWIGLU ? fit : (fit < 2 ? fit : 2);
+    const int max_blocks = cus * (gemv_tune_blocks_per_cu > 0 ? gemv_tune_blocks_per_cu : want);
     if (blocks > max_blocks)
     {
         const int waves = max_blocks * 4;
