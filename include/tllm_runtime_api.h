@@ -33,7 +33,8 @@ typedef struct tllm_session* tllm_session_t;
  *   remove_input_padding (0; 1: the context phase runs on the packed real tokens only),
  *   paged_kv_cache (0; 1: every layer's cache is a pool of [Hr, tokens_per_block, Dh] blocks reached through a per-sequence
  *   table of block pointers - K/kvCacheUtils.h:34-112, PY/runtime/kv_cache_manager.py; the table is filled at setup),
- *   tokens_per_block (64; a power of two).
+ *   tokens_per_block (64; a power of two),
+ *   debug_taps (0; 1: keep per-layer intermediates of the generation step for tllm_session_get_tap).
  * Returns NULL on error (tllm_last_error()). */
 tllm_session_t tllm_session_create(const char* config_text);
 
@@ -48,8 +49,16 @@ int32_t tllm_session_set_tensor(tllm_session_t s, const char* name, int32_t dtyp
 int32_t tllm_session_finalize(tllm_session_t s);
 
 /* Parse a serialized engine (format written by tensorrt_llm.Builder.build_engine: "TLLMENG1" header, config
- * text, tensor table, data) = create + set_tensor(location 0) + finalize. */
+ * text, tensor table, data) = tllm_engine_verify + create + set_tensor(location 0) + finalize. */
 tllm_session_t tllm_session_load_engine(const void* engine, size_t nbytes);
+
+/* The check tllm_session_load_engine applies before it accepts an engine, on its own (host only, no GPU needed): the traced
+ * network the engine carries (`network_json`: plugin nodes in order, their inputs, fields and the weights feeding them, the
+ * I/O tensor names of T/tensorrt_llm/runtime/generation.py:188-208) must be exactly the LLaMA schedule the session executes
+ * for the engine's configuration - "the engine is what was defined" (T/tensorrt_llm/builder.py:259-267).  A model
+ * definition that was edited (another plugin, another field value, another weight on a port, a node more or less) is
+ * refused with an error naming the first node that differs.  0 = accepted. */
+int32_t tllm_engine_verify(const void* engine, size_t nbytes);
 
 /* GenerationSession.setup (generation.py:413-488): allocates the per-layer KV cache
  * [B, 2, H/tp, max_input_len + max_new_tokens, Dh] (fp16 or int8), activations and the RoPE table. */
@@ -105,6 +114,12 @@ int32_t tllm_session_get_logits(tllm_session_t s, float* logits /* [B, vocab] */
 int32_t tllm_session_get_output_ids(tllm_session_t s, int32_t* ids /* [B, max_in + max_new] */, tllm_stream_t stream);
 /* Device pointer of a layer's KV cache (layout [B,2,H/tp,Smax,Dh]) for inspection. */
 void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer);
+/* Parity-test tap (sessions created with debug_taps=1 only): the input of layer `layer`'s O-projection GEMM as the last
+ * generation step computed it - the attention context after the split-KV merge, [B, H/tp * Dh] fp16, or int8 when the
+ * O-projection's prologue quantises it (SmoothQuant: sat(rni(ctx * attention.quantization_scaling_factor)), or the
+ * per-token flavour).  This is the tensor the reference's attention tests compare at atol 2e-3
+ * (T/tests/attention/test_gpt_attention.py:828-831).  HOST buffer of exactly that many bytes. */
+int32_t tllm_session_get_tap(tllm_session_t s, int32_t layer, void* host, size_t nbytes, tllm_stream_t stream);
 /* Bytes a generation step must move from HBM at context length L (weights + KV read + KV write): the
  * algorithmic-bytes model of SURVEY.md §8(d), evaluated for this session's configuration. */
 int64_t tllm_session_step_bytes(tllm_session_t s, int32_t context_len);

@@ -55,7 +55,8 @@ class _Linear:
         if self.kind == 'fp16':
             return O.gemm_fp16(x16, self.w)
         if self.kind == 'woq':
-            return O.woq_matmul(x16, self.q_kn, self.scales)
+            return O.woq_matmul(x16, self.q_kn, self.scales, reference_rounding=getattr(self, 'reference_rounding', False)
+                                and x16.shape[0] <= 8)
         # SmoothQuant: `in_q` = (int8 activations, per-token scales or None)
         xq, tok = in_q
         if tok is None:
@@ -63,8 +64,11 @@ class _Linear:
         return O.sq_gemm(xq, self.w_i8, tok, self.per_channel_scale)
 
 
-def _forward(model, ids, lens, n_new, feed_ids=None, capture=None):
-    """Context step + n_new-1 generation steps.  Returns ([logits per step], greedy ids [B, n_new])."""
+def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, reference_rounding=False):
+    """Context step + n_new-1 generation steps.  Returns ([logits per step], greedy ids [B, n_new]).
+    `taps` (a dict) receives 'caches' (the per-layer KV caches, live objects: their state after the last step),
+    'caches_after_context' (copies) and 'attn_ctx' = [step][layer] attention output [B, H*Dh] of every generation step
+    (the O-projection's input before its quantiser).  `reference_rounding`: see llama_oracle.mmha_decode / woq_matmul."""
     cfg = model['cfg']
     B, S = ids.shape
     H, D = cfg['num_heads'], cfg['hidden_size']
@@ -129,6 +133,10 @@ def _forward(model, ids, lens, n_new, feed_ids=None, capture=None):
 
     for li in range(L):
         x = layer(li, x, valid, ctx_attn)
+    if taps is not None:
+        taps['caches'] = caches
+        taps['caches_after_context'] = [c.copy() for c in caches]
+        taps['attn_ctx'] = []
     x = x.reshape(B, S, D)
     last = np.stack([x[b, int(lens[b]) - 1] for b in range(B)])
     logits = [(O.rmsnorm(last, model['lnf'], eps) @ model['head'].T).astype(F32)]
@@ -142,9 +150,15 @@ def _forward(model, ids, lens, n_new, feed_ids=None, capture=None):
         xs = O.f16(model['emb'][cur])
         tl = S + step
 
+        if taps is not None:
+            taps['attn_ctx'].append([])
+
         def dec_attn(qkv, cache, lw):
-            return O.mmha_decode(qkv, cache, [tl] * B, lens, S, tl, H, Dh, Dh, True, 1.0, masked, lw.get('kv_oq'),
-                                 lw.get('kv_qo'))
+            c = O.mmha_decode(qkv, cache, [tl] * B, lens, S, tl, H, Dh, Dh, True, 1.0, masked, lw.get('kv_oq'),
+                              lw.get('kv_qo'), reference_rounding=reference_rounding)
+            if taps is not None:
+                taps['attn_ctx'][-1].append(c.copy())
+            return c
 
         for li in range(L):
             xs = layer(li, xs, np.ones(B, bool), dec_attn)
@@ -170,8 +184,13 @@ def run_fp16_model(cfg, w, ids, lens, n_new, feed_ids=None):
     return _forward(_fp16_model(cfg, w), ids, lens, n_new, feed_ids)
 
 
-def run_model(qmodel, ids, lens, n_new, feed_ids=None):
-    return _forward(qmodel['oracle'], ids, lens, n_new, feed_ids)
+def run_model(qmodel, ids, lens, n_new, feed_ids=None, taps=None, reference_rounding=False):
+    m = qmodel['oracle']
+    for lw in m['layers']:
+        for n in LINEARS:
+            if lw[n].kind == 'woq':
+                lw[n].reference_rounding = reference_rounding
+    return _forward(m, ids, lens, n_new, feed_ids, taps=taps, reference_rounding=reference_rounding)
 
 
 def quantise_model(cfg, w, mode, int8_kv, calib_ids, calib_lens, alpha=0.5):

@@ -106,6 +106,57 @@ def test_paged_plugin_equals_linear(int8_kv, H, Dh, T, S):
     np.testing.assert_array_equal(gather_pool(pool, table, H, T, Dh, smax), lin.cpu().numpy())
 
 
+@pytest.mark.parametrize('int8_kv', [0, 1])
+@pytest.mark.parametrize('H,Dh,T,S,NEW', [(4, 128, 16, 40, 41), (2, 64, 8, 21, 20)])
+def test_paged_plugin_with_on_demand_block_allocation(int8_kv, H, Dh, T, S, NEW):
+    """The flow INTEGRATION.md documents and the reference's GenerationSession runs (PY/runtime/generation.py:842-848,
+    :978-983): KVCacheManager.add_sequence hands out only the blocks of the (padded) prompt plus one token, step() grows
+    the table when a sequence crosses a block boundary - so for most of the run the table holds ZERO entries for the logical
+    blocks beyond the current length, while the cache capacity the plugin sees (cache_indirection.shape[2]) covers them.
+    The kernels must never form an address from such an entry: the split-KV generation kernel points the (masked) loads of
+    those rows at the pool, the context KV write skips them.  Unequal prompt lengths; bit-identical to the linear cache."""
+    r = np.random.default_rng(S + NEW)
+    B = 2
+    smax = S + NEW
+    in_len = [S, S // 3]
+    masked = np.zeros((B, smax), np.int32)
+    masked[1, in_len[1]:S] = 1
+    scales = (20.0, 0.05) if int8_kv else None
+    kv_dtype = torch.int8 if int8_kv else torch.float16
+    M = -(-smax // T)
+    blocks = B * M + 2
+    pool = torch.zeros(blocks, 2, H, T, Dh, dtype=kv_dtype, device='cuda')
+    lin = torch.zeros(B, 2, H, smax, Dh, dtype=kv_dtype, device='cuda')
+    mgr = KVCacheManager([pool], blocks, T, M, beam_width=1)
+    for b in range(B):
+        mgr.add_sequence(GenerationSequence(b, b), S)  # the padded prompt length for every sequence, as the reference does
+    first = mgr.blocks_manager.get_number_blocks(mgr.sequences[0])
+    assert first == -(-(S + 1) // T) and first < M, 'the scenario must leave logical blocks unallocated'
+    pointers = mgr.get_pointer_arrays()[0]
+    assert (mgr.blocks_manager.pointer_array[:, 0, :, first:] == 0).all()
+    p_lin, p_pg = attention_plugin(H, Dh, int8_kv, 0), attention_plugin(H, Dh, int8_kv, 1)
+    qkv = h(r.standard_normal((B, S, 3 * H * Dh)))
+    o1 = enqueue(p_lin, qkv.clone(), lin, [S, S], 0, True, masked, in_len, S, smax, scales)
+    o2 = enqueue(p_pg, qkv.clone(), pool, [S, S], 0, True, masked, in_len, S, smax, scales, pointers)
+    assert torch.equal(o1, o2)
+    grew = 0
+    for step in range(NEW):
+        L = S + step
+        if step > 0:
+            before = mgr.blocks_manager.get_number_blocks(mgr.sequences[0])
+            mgr.step([False] * B)  # generation.py:978-983: after every step but the last
+            grew += mgr.blocks_manager.get_number_blocks(mgr.sequences[0]) - before
+            pointers = mgr.get_pointer_arrays()[0]
+        assert mgr.blocks_manager.get_number_blocks(mgr.sequences[0]) * T > L, 'the manager maps the slot being written'
+        q1 = h(r.standard_normal((B, 1, 3 * H * Dh)))
+        o1 = enqueue(p_lin, q1.clone(), lin, [L, L], L, False, masked, in_len, S, smax, scales)
+        o2 = enqueue(p_pg, q1.clone(), pool, [L, L], L, False, masked, in_len, S, smax, scales, pointers)
+        assert torch.equal(o1, o2), f'generation step {step}'
+    assert grew >= 1, 'the run must cross at least one block boundary'
+    table = mgr.blocks_manager.get_pointer_array(0)
+    np.testing.assert_array_equal(gather_pool(pool, table, H, T, Dh, smax), lin.cpu().numpy())
+
+
 @pytest.mark.parametrize('mode,int8_kv,beam', [('fp16', 0, 1), ('sq_static_pc', 1, 1), ('fp16', 0, 3), ('woq8', 1, 2)])
 @pytest.mark.parametrize('T', [8, 64])
 def test_paged_session_equals_linear(mode, int8_kv, beam, T):

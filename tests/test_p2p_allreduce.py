@@ -126,3 +126,77 @@ def test_validated_enable_path_of_the_bootstrap():
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] for r in res), res
+
+
+def _timeout_worker(rank, world, port, q):
+    import ctypes
+    import time
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'trtllm-llama_amd'))
+    from tensorrt_llm.plugin import capi
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        lib = capi.load_library()
+        lib.tllm_comm_p2p_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]
+        lib.tllm_comm_p2p_attach.argtypes = [ctypes.c_void_p]
+        lib.tllm_comm_p2p_all_reduce.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        h = (ctypes.c_char * 64)()
+        assert lib.tllm_comm_p2p_create(world, rank, 64 * 1024, h) == 0, capi.last_error()
+        mine = torch.frombuffer(bytearray(h.raw), dtype=torch.uint8)
+        allh = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        blob = b''.join(bytes(t.numpy().tobytes()) for t in allh)
+        assert lib.tllm_comm_p2p_attach(ctypes.create_string_buffer(blob, len(blob))) == 0, capi.last_error()
+        stream = torch.cuda.current_stream().cuda_stream
+        res = {}
+        if rank == 0:
+            # rank 1 never shows up for this all-reduce
+            x = torch.arange(4096, dtype=torch.float16, device='cuda')
+            keep = x.clone()
+            t0 = time.time()
+            assert lib.tllm_comm_p2p_all_reduce(x.data_ptr(), 4096, stream) == 0, capi.last_error()
+            torch.cuda.synchronize()
+            res['first_s'] = time.time() - t0
+            res['err'] = int(lib.tllm_comm_p2p_error())
+            res['untouched'] = bool(torch.equal(x, keep))
+            t0 = time.time()
+            for _ in range(64):  # the rest of a replayed step graph: every launch backs off at once
+                assert lib.tllm_comm_p2p_all_reduce(x.data_ptr(), 4096, stream) == 0
+            torch.cuda.synchronize()
+            res['later_s'] = time.time() - t0
+            res['untouched_later'] = bool(torch.equal(x, keep))
+        q.put((rank, res))
+        dist.barrier()
+        lib.tllm_comm_destroy_all()
+    except BaseException as e:
+        q.put((rank, {'exc': repr(e)}))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_timed_out_wait_is_sticky_and_leaves_the_buffer_alone():
+    """a flag wait that expires must not be followed by a sum over a stale inbox.  Rank 1 skips an
+    all-reduce: rank 0's launch gives up after its bounded spin, raises the error flag, leaves x as it was and does not
+    advance the epoch; every later launch returns immediately (the session turns the flag into a failed call:
+    runtime/session.cpp check_comm)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timeout_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    r0 = res[0]
+    assert 'exc' not in r0, r0
+    assert r0['err'] != 0, 'the expired wait must raise the error flag'
+    assert r0['untouched'] and r0['untouched_later'], 'a timed-out all-reduce must not write sums of a stale inbox'
+    assert r0['later_s'] < max(0.5, 0.2 * r0['first_s']), f'later launches must back off at once: {r0}'

@@ -144,14 +144,21 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const ContextAttnPar
             + (((int64_t) (b * p.cache_seq_stride * 2 + 0) * H + h) * p.max_seq_len + s) * DH * esz + li * 8 * esz;
         char* vc = reinterpret_cast<char*>(p.kv_cache)
             + (((int64_t) (b * p.cache_seq_stride * 2 + 1) * H + h) * p.max_seq_len + s) * DH * esz + li * 8 * esz;
+        bool mapped = true;
         if (p.block_pointers) // uniform: paged cache, block s / tokens_per_block of the sequence, row s % tokens_per_block
         {
             const int lg = 31 - __builtin_clz(p.tokens_per_block);
             const int64_t* row = p.block_pointers + (int64_t) b * p.cache_seq_stride * 2 * p.max_blocks_per_seq + (s >> lg);
             const int64_t off = (((int64_t) h * p.tokens_per_block + (s & (p.tokens_per_block - 1))) * DH + li * 8) * esz;
+            // a table entry of 0 is a logical block the cache manager has not handed out yet (KVCacheManager.add_sequence
+            // allocates ceil((len + 1) / tokens_per_block) blocks and grows on demand, PY/runtime/kv_cache_manager.py): such a
+            // block holds only padding positions, which the reference never touches (K/kvCacheUtils.h:34-112) - skip them
+            mapped = row[0] != 0 && row[p.max_blocks_per_seq] != 0;
             kc = reinterpret_cast<char*>(row[0]) + off;
             vc = reinterpret_cast<char*>(row[p.max_blocks_per_seq]) + off;
         }
+        if (!mapped)
+            return;
         if (p.int8_kv)
         {
             const float sc = p.kv_scale_orig_quant[0];

@@ -147,8 +147,13 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
             if (p.beam_width > 1) // uniform
                 seq = b - k_own + ci[t];
             const int64_t* row = p.block_pointers + (int64_t) seq * 2 * p.max_blocks_per_seq + (t >> lg);
-            kblk[i] = reinterpret_cast<const char*>(row[0]);
-            vblk[i] = reinterpret_cast<const char*>(row[p.max_blocks_per_seq]);
+            // a table entry of 0 = a logical block the cache manager has not handed out yet (KVCacheManager grows the table
+            // on demand, PY/runtime/kv_cache_manager.py).  Such a block lies beyond the current length, so its rows are
+            // dropped by the validity mask below - but the loads themselves are unconditional (no branch around a load),
+            // so they are pointed at the pool instead of at address 0 + offset.  A select, not another dependent load.
+            const int64_t kb = row[0], vb = row[p.max_blocks_per_seq];
+            kblk[i] = kb ? reinterpret_cast<const char*>(kb) : reinterpret_cast<const char*>(p.kv_cache);
+            vblk[i] = vb ? reinterpret_cast<const char*>(vb) : reinterpret_cast<const char*>(p.kv_cache);
         }
     }
     if constexpr (BEAM)
@@ -293,24 +298,31 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
     {
         int64_t off = ((int64_t) tl * DH + li * 8) * ESZ;
         char *kw = kbase + off, *vw = vbase + off;
+        bool mapped = true;
         if constexpr (PAGED)
         {
             // the sequence's OWN block (never a sibling's: a new token belongs to the hypothesis that consumed it)
             const int lg = 31 - __builtin_clz(p.tokens_per_block);
             const int64_t* row = p.block_pointers + (int64_t) b * 2 * p.max_blocks_per_seq + (tl >> lg);
             off = (((int64_t) h * p.tokens_per_block + (tl & tpb_mask)) * DH + li * 8) * ESZ;
+            // the manager must have mapped the block of slot tl before this step (KVCacheManager.step); a missing block is
+            // the caller's error and must not become a wild store
+            mapped = row[0] != 0 && row[p.max_blocks_per_seq] != 0;
             kw = reinterpret_cast<char*>(row[0]) + off;
             vw = reinterpret_cast<char*>(row[p.max_blocks_per_seq]) + off;
         }
-        if constexpr (INT8KV)
+        if (mapped)
         {
-            *reinterpret_cast<uint2*>(kw) = quant8(k_new, s_oq);
-            *reinterpret_cast<uint2*>(vw) = quant8(v_new, s_oq);
-        }
-        else
-        {
-            *reinterpret_cast<uint4*>(kw) = k_new;
-            *reinterpret_cast<uint4*>(vw) = v_new;
+            if constexpr (INT8KV)
+            {
+                *reinterpret_cast<uint2*>(kw) = quant8(k_new, s_oq);
+                *reinterpret_cast<uint2*>(vw) = quant8(v_new, s_oq);
+            }
+            else
+            {
+                *reinterpret_cast<uint4*>(kw) = k_new;
+                *reinterpret_cast<uint4*>(vw) = v_new;
+            }
         }
     }
 

@@ -11,7 +11,8 @@
 // Two generations (epoch parity): a rank can be at most one all-reduce ahead of a peer, because it cannot finish
 // all-reduce k + 1 without the peer's contribution, which the peer sends only after it has read generation k.
 // The epoch lives in device memory and is advanced by the kernel itself, so the launch is graph-replayable.
-// Every spin is bounded; a timeout raises `error` (checked by the host) instead of hanging the GPU.
+// Every spin is bounded; a timeout raises `error` instead of hanging the GPU: the launch that timed out and every later one
+// leave their buffers alone, and the host fails the call at its next synchronisation point (session.cpp check_comm).
 #include "dev_utils.h"
 #include "kernels.h"
 
@@ -28,9 +29,19 @@ __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(const P2PParams p)
 {
     __shared__ uint32_t s_epoch;
     const int tid = threadIdx.x;
+    __shared__ uint32_t s_failed;
     if (tid == 0)
+    {
         s_epoch = *p.epoch + 1;
+        s_failed = *p.error;
+    }
     __syncthreads();
+    // A time-out is sticky: once a wait has expired the inboxes and the epochs of the ranks can no longer be trusted, so every
+    // later launch (the rest of a replayed step graph) returns at once instead of summing stale slots and spinning again.
+    // The host sees the flag at its next synchronisation point, fails the call and takes this transport out of service
+    // (runtime/session.cpp check_comm; comm::p2p::destroy + create starts afresh).
+    if (s_failed)
+        return;
     const uint32_t epoch = s_epoch;
     const int gen = epoch & 1, W = p.world;
     const size_t slot16 = p.slot_bytes / 16;
@@ -69,6 +80,8 @@ __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(const P2PParams p)
     }
     __syncthreads();
     __threadfence_system();
+    if (__hip_atomic_load(p.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        return; // this launch timed out: the inbox may be stale or half written - leave x alone, do not advance the epoch
     const uint4* in = reinterpret_cast<const uint4*>(p.peer[p.rank]) + (size_t) gen * W * slot16;
     if (p.gather_out)
     {

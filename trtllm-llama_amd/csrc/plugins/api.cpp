@@ -10,7 +10,7 @@
 namespace tllm
 {
 
-static thread_local char g_err[512] = {0};
+static thread_local char g_err[2048] = {0};
 
 void set_error(const char* fmt, ...)
 {

@@ -525,6 +525,17 @@ public:
             set_error("SmoothQuantGemm: weight K=%d does not match activation K=%d", Kw, K);
             return 1;
         }
+        // the flags say how many scales the kernel reads; a tensor of a different extent is a mis-built network (e.g. a QKV
+        // scale expanded to one factor per channel behind has_per_channel_scaling = 0: K and V would silently get Q's factor)
+        const int64_t nb = rows_of(inDesc[3].dims) * inDesc[3].dims.d[inDesc[3].dims.nbDims - 1];
+        const int64_t na = rows_of(inDesc[2].dims) * inDesc[2].dims.d[inDesc[2].dims.nbDims - 1];
+        if (nb != (per_channel ? (int64_t) N : 1) || na != (per_token ? M : 1))
+        {
+            set_error("SmoothQuantGemm: scales_b holds %lld values and scales_a %lld, but has_per_channel_scaling = %d / "
+                      "has_per_token_scaling = %d ask for %lld and %lld", (long long) nb, (long long) na, per_channel, per_token,
+                (long long) (per_channel ? N : 1), (long long) (per_token ? M : 1));
+            return 1;
+        }
         GemmParams g;
         g.wtype = W_INT8_SQ;
         g.out_dtype = type_id == TLLM_HALF ? DT_HALF : (type_id == TLLM_FLOAT ? DT_FLOAT : DT_INT32);

@@ -20,6 +20,7 @@
 #include "../kernels/weight_layout.h"
 #include "../plugins/comm.h"
 #include "../plugins/plugin_base.h"
+#include "engine_check.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -137,6 +138,7 @@ struct tllm_session
     int neox = 1;
     float eps = 1e-6f;
     std::string wo_precision = "int8";
+    std::string network_json; // the traced network an engine file carries (Builder.build_engine), verified by load_engine
     // derived
     int Hr = 0, Dh = 0, Dr = 0, Ir = 0, Vr = 0;
     bool sq = false, woq = false, int8_kv = false, per_token = false, per_channel = false;
@@ -160,6 +162,9 @@ struct tllm_session
     int tokens_per_block = 64, max_blocks = 0;
     size_t kv_elems = 0; // elements of one layer's cache / pool
     bool force_comm = false; // tests: run the TP collectives on a 1-rank communicator too (RCCL inside the captured graph)
+    bool debug_taps = false; // tests: keep every layer's O-projection input of the last generation step (tllm_session_get_tap)
+    char* tap_attn = nullptr; // [num_layers][B][Dr] fp16, or s8 when the O-projection's prologue quantises (SmoothQuant)
+    int tap_layer = -1;       // layer whose K4 launch is being issued (gemv() routes x_pro_out there)
 
     // ---- runtime state (setup)
     int B = 0, max_in = 0, max_new = 0, Smax = 0;
@@ -411,6 +416,8 @@ struct tllm_session
             p.attn_tchunk = attn_tchunk;
             p.attn_nsmax = attn_ns;
         }
+        if (tap_layer >= 0 && tap_attn)
+            p.x_pro_out = tap_attn + (size_t) tap_layer * B * Dr * (sq ? 1 : 2);
         if (up)
         {
             p.w_up = up->w;
@@ -725,8 +732,19 @@ struct tllm_session
             // K4: x <- x + O(ctx)     (TP: rank 0 carries the residual into the all-reduce)
             const int pro_o = !attn_fused ? pro_q : (!sq ? PRO_ATTN : (per_token ? PRO_ATTN_QDYN : PRO_ATTN_QSTATIC));
             if (ok < 0 || ok == 4)
-            RUN(gemv(L.dense, B, pro_o, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE, ctx, Dr, nullptr, L.attn_qscale, x,
-                nullptr, x, D, DT_HALF, nullptr, st));
+            {
+                if (debug_taps && ok < 0)
+                {
+                    if (pro_o == PRO_NONE) // nothing is transformed in the prologue: the input itself is the tap
+                        HIP_OK(hipMemcpyAsync(tap_attn + (size_t) li * B * Dr * 2, ctx, (size_t) B * Dr * 2, hipMemcpyDeviceToDevice, st));
+                    else
+                        tap_layer = li;
+                }
+                const int rc4 = gemv(L.dense, B, pro_o, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE, ctx, Dr, nullptr, L.attn_qscale, x,
+                    nullptr, x, D, DT_HALF, nullptr, st);
+                tap_layer = -1;
+                RUN(rc4);
+            }
             if (ok < 0)
                 RUN(allreduce(x, (int64_t) B * D, st));
             // K5
@@ -790,6 +808,7 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->quant_mode = geti("quant_mode", 0);
     s->neox = geti("neox_rotary_style", 1);
     s->force_comm = geti("force_comm", 0) != 0;
+    s->debug_taps = geti("debug_taps", 0) != 0;
     s->packed = geti("remove_input_padding", 0) != 0;
     s->paged_kv = geti("paged_kv_cache", 0) != 0;
     s->tokens_per_block = geti("tokens_per_block", 64);
@@ -802,6 +821,8 @@ tllm_session_t tllm_session_create(const char* config_text)
         s->eps = (float) atof(kv["rms_norm_eps"].c_str());
     if (kv.count("weight_only_precision"))
         s->wo_precision = kv["weight_only_precision"];
+    if (kv.count("network_json"))
+        s->network_json = kv["network_json"];
     if (s->num_layers <= 0 || s->num_heads <= 0 || s->hidden <= 0 || s->inter <= 0 || s->vocab <= 0 || s->tp < 1
         || s->rank < 0 || s->rank >= s->tp)
     {
@@ -915,12 +936,23 @@ int32_t tllm_session_finalize(tllm_session_t s)
     return 0;
 }
 
-tllm_session_t tllm_session_load_engine(const void* engine, size_t nbytes)
+namespace
+{
+struct EngineEntry
+{
+    std::string name;
+    int32_t dtype, nd;
+    int64_t dims[8];
+    uint64_t nbytes, offset;
+};
+
+// "TLLMENG1" | u64 header length | header text | u64 tensor count | table | 64-byte aligned data (tensorrt_llm/builder.py)
+int parse_engine(const void* engine, size_t nbytes, std::string& cfg, std::vector<EngineEntry>& ents, size_t& data0)
 {
     const char* p = static_cast<const char*>(engine);
     auto fail = [](const char* why) {
-        set_error("tllm_session_load_engine: %s", why);
-        return (tllm_session_t) nullptr;
+        set_error("engine: %s", why);
+        return 1;
     };
     if (!p || nbytes < 24 || std::memcmp(p, "TLLMENG1", 8) != 0)
         return fail("not a TLLMENG1 engine");
@@ -933,20 +965,13 @@ tllm_session_t tllm_session_load_engine(const void* engine, size_t nbytes)
         return true;
     };
     uint64_t hlen = 0, nt = 0;
-    if (!rd64(&hlen) || off + hlen > nbytes)
+    if (!rd64(&hlen) || hlen > nbytes || off + hlen > nbytes)
         return fail("truncated header");
-    std::string cfg(p + off, p + off + hlen);
+    cfg.assign(p + off, p + off + hlen);
     off += hlen;
-    if (!rd64(&nt))
+    if (!rd64(&nt) || nt > nbytes / 24)
         return fail("truncated tensor table");
-    struct Ent
-    {
-        std::string name;
-        int32_t dtype, nd;
-        int64_t dims[8];
-        uint64_t nbytes, offset;
-    };
-    std::vector<Ent> ents(nt);
+    ents.assign(nt, EngineEntry());
     for (auto& e : ents)
     {
         uint32_t nl = 0;
@@ -954,7 +979,7 @@ tllm_session_t tllm_session_load_engine(const void* engine, size_t nbytes)
             return fail("truncated tensor table");
         std::memcpy(&nl, p + off, 4);
         off += 4;
-        if (off + nl + 8 > nbytes)
+        if (nl > nbytes || off + nl + 8 > nbytes)
             return fail("truncated tensor table");
         e.name.assign(p + off, p + off + nl);
         off += nl;
@@ -969,17 +994,93 @@ tllm_session_t tllm_session_load_engine(const void* engine, size_t nbytes)
         std::memcpy(&e.offset, p + off + 8, 8);
         off += 16;
     }
-    const size_t data0 = (off + 63) / 64 * 64;
+    data0 = (off + 63) / 64 * 64;
+    for (auto& e : ents)
+        if (e.offset > nbytes || e.nbytes > nbytes || data0 + e.offset + e.nbytes > nbytes)
+            return fail("tensor data out of range");
+    return 0;
+}
+
+// The engine's traced network against the schedule a session of this configuration executes (runtime/engine_check.h).
+int verify_engine_network(tllm_session_t s, const std::vector<EngineEntry>& ents)
+{
+    if (s->network_json.empty())
+    {
+        set_error("engine: no network_json in the header - not an engine built by tensorrt_llm.Builder.build_engine");
+        return 1;
+    }
+    runtime::ScheduleDesc d;
+    d.num_layers = s->num_layers;
+    d.heads_per_rank = s->Hr;
+    d.head_size = s->Dh;
+    d.tp = s->tp;
+    d.eps = s->eps;
+    d.sq = s->sq;
+    d.per_token = s->per_token;
+    d.woq = s->woq;
+    d.int4 = s->wtype == W_INT4_WOQ;
+    d.int8_kv = s->int8_kv;
+    d.paged = s->paged_kv;
+    d.packed = s->packed;
+    // has_per_channel_scaling of every SmoothQuant GEMM = what the scale tensor the engine carries implies (a "per tensor"
+    // QKV scale is stored as one factor per channel: examples/llama_quant/weight.py)
+    for (const char* n : {"attention.qkv", "attention.dense", "mlp.fc", "mlp.gate", "mlp.proj"})
+    {
+        int pc = s->per_channel ? 1 : 0;
+        const std::string want = std::string("layers.0.") + n + ".per_channel_scale";
+        for (auto& e : ents)
+            if (e.name == want)
+            {
+                int64_t numel = 1;
+                for (int i = 0; i < e.nd; ++i)
+                    numel *= e.dims[i];
+                pc = numel > 1 ? 1 : 0;
+            }
+        d.per_channel.push_back(pc);
+    }
+    std::string why;
+    if (runtime::verify_network(s->network_json, d, why))
+    {
+        set_error("engine: %s", why.c_str());
+        return 1;
+    }
+    return 0;
+}
+} // namespace
+
+int32_t tllm_engine_verify(const void* engine, size_t nbytes)
+{
+    std::string cfg;
+    std::vector<EngineEntry> ents;
+    size_t data0 = 0;
+    RUN(parse_engine(engine, nbytes, cfg, ents, data0));
+    tllm_session_t s = tllm_session_create(cfg.c_str());
+    if (!s)
+        return 1;
+    const int rc = verify_engine_network(s, ents);
+    tllm_session_destroy(s);
+    return rc;
+}
+
+tllm_session_t tllm_session_load_engine(const void* engine, size_t nbytes)
+{
+    std::string cfg;
+    std::vector<EngineEntry> ents;
+    size_t data0 = 0;
+    if (parse_engine(engine, nbytes, cfg, ents, data0))
+        return nullptr;
     tllm_session_t s = tllm_session_create(cfg.c_str());
     if (!s)
         return nullptr;
+    // the engine is what was defined: refuse a traced network that is not the schedule this session would run
+    if (verify_engine_network(s, ents))
+    {
+        tllm_session_destroy(s);
+        return nullptr;
+    }
+    const char* p = static_cast<const char*>(engine);
     for (auto& e : ents)
     {
-        if (data0 + e.offset + e.nbytes > nbytes)
-        {
-            tllm_session_destroy(s);
-            return fail("tensor data out of range");
-        }
         if (tllm_session_set_tensor(s, e.name.c_str(), e.dtype, e.dims, e.nd, p + data0 + e.offset, 0))
         {
             tllm_session_destroy(s);
@@ -1011,6 +1112,13 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
     {
         set_error("tllm_session_setup: bad sizes (batch %d, beam width %d in [1, 8], input %d, new %d)", batch_size, beam_width,
             max_input_len, max_new_tokens);
+        return 1;
+    }
+    if (beam_width > 1 && (size_t) beam_width * (max_input_len + max_new_tokens) * sizeof(int32_t) > 96 * 1024)
+    {
+        // the device-side beam step stages the cache-indirection rows it re-parents in LDS (pointwise.hip beam_step_kernel)
+        set_error("tllm_session_setup: beam_width %d x max_seq_len %d exceeds the beam step's LDS staging (24576 int32)", beam_width,
+            max_input_len + max_new_tokens);
         return 1;
     }
     s->free_runtime();
@@ -1077,6 +1185,12 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
                 mx = std::max(mx, gemm_woq_scratch_bytes(l->N, l->K));
         RUN(s->dalloc(&s->woq_scratch, mx));
     }
+    s->tap_attn = nullptr;
+    if (s->debug_taps)
+    {
+        RUN(s->dalloc(&s->tap_attn, (size_t) s->num_layers * B * s->Dr * 2));
+        HIP_OK(hipMemset(s->tap_attn, 0, (size_t) s->num_layers * B * s->Dr * 2));
+    }
     RUN(s->dalloc(&s->cu_dev, (size_t) (Bc + 1) * 4));
     RUN(s->dalloc(&s->last_rows, (size_t) Bc * 4));
     RUN(s->dalloc(&s->mmha_ws, mmha_workspace_size(B, s->Hr, s->Dh, Smax) + 256));
@@ -1128,6 +1242,35 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
         s->attn_tchunk = tc;
         s->attn_ns = ns;
         s->attn_o_off = off;
+    }
+    return 0;
+}
+
+// After a stream synchronisation: did a peer-to-peer collective of this tensor-parallel session time out?  (The kernels
+// never hang: a bounded wait that expires raises a device flag and every later launch backs off, p2p_allreduce.hip.)  Then
+// the hidden states / logits behind this point are not sums over all ranks: fail the call and take the transport out of
+// service, so that later sessions of this process fall back to RCCL.
+static int check_comm(tllm_session_t s)
+{
+    if ((s->tp == 1 && !s->force_comm) || !comm::p2p::attached())
+        return 0;
+    uint32_t e = 0;
+    if (comm::p2p::error_flag(&e) != 0)
+    {
+        set_error("session: cannot read the peer-to-peer error flag");
+        return 1;
+    }
+    if (e)
+    {
+        comm::p2p::enable(false);
+        if (s->graph) // the captured step holds the peer-to-peer launches
+        {
+            (void) hipGraphExecDestroy(s->graph);
+            s->graph = nullptr;
+        }
+        set_error("session: a peer-to-peer all-reduce timed out waiting for a rank (epoch %u); the results of this call are "
+                  "invalid and the peer-to-peer transport is disabled for this process", e);
+        return 1;
     }
     return 0;
 }
@@ -1277,7 +1420,6 @@ int32_t tllm_session_fake_context(tllm_session_t s, int32_t length, uint32_t see
 int32_t tllm_session_generate(tllm_session_t s, const int32_t* input_ids, const int32_t* input_lengths,
     int32_t max_new_tokens, int32_t end_id, int32_t pad_id, int32_t* output_ids, tllm_stream_t stream)
 {
-    (void) pad_id;
     if (!s || !s->B || !input_ids || !input_lengths || !output_ids)
     {
         set_error("tllm_session_generate: bad arguments / setup not called");
@@ -1297,10 +1439,12 @@ int32_t tllm_session_generate(tllm_session_t s, const int32_t* input_ids, const 
         s->graph = nullptr;
     }
     RUN(tllm_session_context(s, input_ids, input_lengths, stream));
+    int produced = max_new_tokens > 0 ? 1 : 0; // tokens generated per sequence (the prompt pass yields the first)
     if (max_new_tokens > 1)
     {
         // first generation step eagerly (also warms lazily-initialised state), the rest from the graph
         RUN(tllm_session_step(s, 1, 0, stream));
+        produced = 2;
         if (max_new_tokens > 2)
         {
             const int chunk = 32; // poll the finished flags every `chunk` steps instead of every step
@@ -1311,10 +1455,12 @@ int32_t tllm_session_generate(tllm_session_t s, const int32_t* input_ids, const 
                 const int n = std::min(chunk, max_new_tokens - done);
                 RUN(tllm_session_step(s, n, 1, stream));
                 done += n;
+                produced = done;
                 if (end_id >= 0 && done < max_new_tokens)
                 {
                     HIP_OK(hipMemcpyAsync(fin.data(), s->finished, s->B * 4, hipMemcpyDeviceToHost, st));
                     HIP_OK(hipStreamSynchronize(st));
+                    RUN(check_comm(s));
                     bool all = true;
                     for (auto f : fin)
                         all = all && f;
@@ -1326,7 +1472,24 @@ int32_t tllm_session_generate(tllm_session_t s, const int32_t* input_ids, const 
     }
     if (s->beam > 1)
         return tllm_session_get_beam_output(s, output_ids, nullptr, stream);
-    return tllm_session_get_output_ids(s, output_ids, stream);
+    RUN(tllm_session_get_output_ids(s, output_ids, stream));
+    // The reference runs gather_tree for beam_width 1 too (generation.py:990-994; K/decodingKernels.cu:130-156): everything
+    // after a sequence's first end token, and the tail no step wrote because every sequence had finished, is end_id - not the
+    // 0 (<unk>) the buffer was initialised with.  Without an end token (benchmarks) the unused tail is pad_id.
+    const int32_t fill = end_id >= 0 ? end_id : pad_id;
+    for (int b = 0; b < s->B; ++b)
+    {
+        int32_t* o = output_ids + (size_t) b * s->Smax;
+        bool done = false;
+        for (int t = s->max_in; t < s->Smax; ++t)
+        {
+            if (done || t >= s->max_in + produced)
+                o[t] = fill;
+            else if (end_id >= 0 && o[t] == end_id)
+                done = true;
+        }
+    }
+    return 0;
 }
 
 int32_t tllm_session_get_logits(tllm_session_t s, float* logits, tllm_stream_t stream)
@@ -1339,11 +1502,12 @@ int32_t tllm_session_get_logits(tllm_session_t s, float* logits, tllm_stream_t s
     {
         HIP_OK(hipMemcpyAsync(logits, s->logits_local, (size_t) rows * s->vocab * 4, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
-        return 0;
+        return check_comm(s);
     }
     std::vector<float> g((size_t) s->tp * rows * s->Vr);
     HIP_OK(hipMemcpyAsync(g.data(), s->logits, g.size() * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    RUN(check_comm(s));
     for (int b = 0; b < rows; ++b)
         for (int v = 0; v < s->vocab; ++v)
             logits[(size_t) b * s->vocab + v] = g[((size_t) (v / s->Vr) * rows + b) * s->Vr + v % s->Vr];
@@ -1357,7 +1521,7 @@ int32_t tllm_session_get_output_ids(tllm_session_t s, int32_t* ids, tllm_stream_
     hipStream_t st = s->pick(stream);
     HIP_OK(hipMemcpyAsync(ids, s->out_ids, (size_t) s->B * s->Smax * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
-    return 0;
+    return check_comm(s);
 }
 
 int32_t tllm_session_logit_rows(tllm_session_t s)
@@ -1392,6 +1556,7 @@ int32_t tllm_session_get_beam_output(tllm_session_t s, int32_t* ids, float* cum_
     if (cum_log_probs)
         HIP_OK(hipMemcpyAsync(cum_log_probs, s->cum_log_probs, B * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
+    RUN(check_comm(s));
     const int32_t fill = s->end_id >= 0 ? s->end_id : 0;
     for (int bb = 0; bb < B; ++bb)
     {
@@ -1439,6 +1604,30 @@ int32_t tllm_session_get_beam_state(tllm_session_t s, int32_t* parent_ids, int32
         HIP_OK(hipMemcpyAsync(finished, s->finished, (size_t) s->B * 4, hipMemcpyDeviceToHost, st));
     if (sequence_lengths)
         HIP_OK(hipMemcpyAsync(sequence_lengths, s->seq_len, (size_t) s->B * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int32_t tllm_session_get_tap(tllm_session_t s, int32_t layer, void* host, size_t nbytes, tllm_stream_t stream)
+{
+    if (!s || !s->B || !host || layer < 0 || layer >= s->num_layers)
+    {
+        set_error("tllm_session_get_tap: bad arguments / setup not called");
+        return 1;
+    }
+    if (!s->tap_attn)
+    {
+        set_error("tllm_session_get_tap: the session was not created with debug_taps=1");
+        return 1;
+    }
+    const size_t row = (size_t) s->B * s->Dr * (s->sq ? 1 : 2);
+    if (nbytes != row)
+    {
+        set_error("tllm_session_get_tap: buffer of %zu bytes, the tap holds %zu", nbytes, row);
+        return 1;
+    }
+    hipStream_t st = s->pick(stream);
+    HIP_OK(hipMemcpyAsync(host, s->tap_attn + (size_t) layer * row, row, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     return 0;
 }

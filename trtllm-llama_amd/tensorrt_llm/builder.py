@@ -96,8 +96,12 @@ class Builder():
             'network_ops': ','.join(ops[:0]),  # the node list itself goes below as one JSON line
         }
         text = '\n'.join(f'{k}={v}' for k, v in header.items())
+        # which Parameter (module path) every constant tensor of the graph is: lets the runtime check that each plugin port
+        # is fed by the weight its schedule reads there
+        path_of = {id(p): name for name, p in named}
+        constants = {tname: path_of.get(id(v), '') for tname, v in network._constants}
         text += '\nnetwork_json=' + json.dumps(dict(inputs=[t.name for t in network.get_inputs()],
-                                                    outputs=list(network._outputs.keys()),
+                                                    outputs=list(network._outputs.keys()), constants=constants,
                                                     nodes=[dict(op=n['op'], inputs=n['inputs'], outputs=n['outputs'],
                                                                 attrs={k: v for k, v in n['attrs'].items()})
                                                            for n in network.nodes if n['op'] != 'constant']))

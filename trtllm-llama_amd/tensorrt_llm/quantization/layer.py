@@ -103,9 +103,12 @@ class _SQLinearBase(Module):
             per_token_scale = self.act_scale.value
         else:
             x, per_token_scale = x  # (int8 activations, per-token scales)
+        # the plugin reads scales_b as a vector only when told so: a loader that expands "per tensor" to one factor each for
+        # Q, K and V ([1, 3 * out / tp], examples/llama_quant/weight.py) must get per-channel dequantisation for that GEMM
+        # even though the model's QuantMode says per-tensor - decided from the tensor the engine will actually carry
+        per_channel = self.quant_mode.has_per_channel_scaling() or int(tuple(self.per_channel_scale.shape)[-1]) > 1
         return smooth_quant_gemm(x, self.weight.value, per_token_scale, self.per_channel_scale.value,
-                                 self.quant_mode.has_per_token_dynamic_scaling(),
-                                 self.quant_mode.has_per_channel_scaling())
+                                 self.quant_mode.has_per_token_dynamic_scaling(), per_channel)
 
 
 class SmoothQuantLinear(_SQLinearBase):

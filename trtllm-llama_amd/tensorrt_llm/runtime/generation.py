@@ -93,8 +93,7 @@ class GenerationSession(object):
         """input_ids: int32 [batch, max_input_length] (torch tensor or ndarray), padded with pad_id.
         Returns int32 [batch, num_beams, max_input_length + max_new_tokens] like the reference (generation.py:991-997):
         greedy for num_beams == 1, beam search (hypotheses best first, back-tracked by gather_tree) otherwise."""
-        if sampling_config.top_k != 1 and sampling_config.num_beams == 1:
-            raise NotImplementedError('sampling (top_k > 1 / top_p) is not built: greedy or beam search only')
+        self._check_sampling_config(sampling_config)
         if sampling_config.num_beams != getattr(self, 'beam_width', 1):
             # the reference sizes its beam buffers inside decode() from scfg.num_beams (generation.py:365-411)
             self.setup(self.batch_size, self.max_input_length, self.max_new_tokens, sampling_config.num_beams)
@@ -109,6 +108,31 @@ class GenerationSession(object):
             import torch
             return torch.from_numpy(out).to(input_ids.device)
         return out
+
+    @staticmethod
+    def _check_sampling_config(scfg: SamplingConfig):
+        """Only what the device-side sampler honours is accepted; a field that would silently change nothing raises
+        instead (the reference feeds all of them to DynamicDecodeOp, generation.py:300-345, 949-961).
+        Greedy (num_beams 1, top_k 1): temperature and top_p cannot change an arg-max and are accepted.
+        Beam search: hypotheses are ranked by the raw cumulative log-probability, as the reference's runtime does without
+        beam_hyps - so temperature must be 1; top_k / top_p play no part in the reference's beam search either."""
+        if scfg.num_beams == 1 and scfg.top_k != 1:
+            raise NotImplementedError('sampling (top_k > 1 / top_p) is not built: greedy or beam search only')
+        if scfg.num_beams == 1 and not scfg.temperature > 0:
+            raise ValueError('temperature must be positive')
+        bad = []
+        if scfg.repetition_penalty != 1.0:
+            bad.append(f'repetition_penalty={scfg.repetition_penalty}')
+        if scfg.presence_penalty != 0.0:
+            bad.append(f'presence_penalty={scfg.presence_penalty}')
+        if scfg.min_length > 1:
+            bad.append(f'min_length={scfg.min_length}')
+        if scfg.num_beams > 1 and scfg.temperature != 1.0:
+            bad.append(f'temperature={scfg.temperature} with beam search')
+        if scfg.num_beams > 1 and scfg.length_penalty != 1.0:
+            bad.append(f'length_penalty={scfg.length_penalty}')
+        if bad:
+            raise NotImplementedError('SamplingConfig fields the device-side sampler does not honour: ' + ', '.join(bad))
 
     def decode_batch(self, input_ids, sampling_config: SamplingConfig):
         """list of 1-D id tensors -> pads to the longest and decodes (generation.py:770-780)."""

@@ -56,6 +56,8 @@ def _lib():
     lib.tllm_session_get_output_ids.restype = c.c_int32
     lib.tllm_session_kv_cache_ptr.argtypes = [c.c_void_p, c.c_int32]
     lib.tllm_session_kv_cache_ptr.restype = c.c_void_p
+    lib.tllm_session_get_tap.argtypes = [c.c_void_p, c.c_int32, c.c_void_p, c.c_size_t, c.c_void_p]
+    lib.tllm_session_get_tap.restype = c.c_int32
     lib.tllm_session_step_bytes.argtypes = [c.c_void_p, c.c_int32]
     lib.tllm_session_step_bytes.restype = c.c_int64
     lib.tllm_session_profile.argtypes = [c.c_void_p, c.c_int32, c.POINTER(c.c_float), c.POINTER(c.c_int64), c.c_void_p]
@@ -192,6 +194,12 @@ class NativeSession:
 
     def kv_cache_ptr(self, layer: int) -> int:
         return _lib().tllm_session_kv_cache_ptr(self._h, layer)
+
+    def attention_tap(self, layer: int, heads_x_dh: int, quantised: bool, stream: int = 0) -> np.ndarray:
+        """O-projection input of the last generation step (debug_taps=1): [batch * beam, H/tp * Dh] fp16, int8 for SmoothQuant."""
+        out = np.empty((self.batch * self.beam, heads_x_dh), np.int8 if quantised else np.float16)
+        _check(_lib().tllm_session_get_tap(self._h, layer, out.ctypes.data, out.nbytes, stream), 'get_tap')
+        return out
 
     def step_bytes(self, context_len: int) -> int:
         return _lib().tllm_session_step_bytes(self._h, context_len)
