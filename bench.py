@@ -42,6 +42,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prefill', dest='prefill', action='store_false', help='skip the prefill (TTFT) and SQ-GEMM MFMA reports')
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
+    ap.add_argument('--no-parity', dest='parity', action='store_false',
+                    help='skip the 7B accuracy report (GPU engines vs HF fp32 on the host CPU on identical weights)')
+    ap.add_argument('--parity-new-tokens', type=int, default=16)
     ap.add_argument('--cpu-tokens', type=int, default=0, help='CPU-baseline decode steps (0 = sized to ~20 s)')
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--cpu-sweep', default='', help='debug: comma list of thread counts to try (stderr)')
@@ -254,11 +257,11 @@ def _default_cpu_threads():
     return max(1, min(n, 64))
 
 
-def cpu_baseline(n_tokens, context, threads=0, sweep=None):
+def cpu_baseline(n_tokens, context, threads=0, sweep=None, model=None, layers=32):
     """HF transformers LlamaForCausalLM on the host CPU (the reference's run_hf.py flow,
     T/examples/llama_quant/run_hf.py:41-104, minus .cuda()): greedy decode of `n_tokens` tokens at batch 1 with a
-    `context`-token KV cache.  Bounded sample: synthetic weights tiled from a random pool, synthetic KV cache instead
-    of a CPU prefill (13 TFLOP), a handful of tokens."""
+    `context`-token KV cache.  Bounded sample: synthetic KV cache instead of a CPU prefill (13 TFLOP), a handful of tokens.
+    `model`: the fp32 CPU model of the parity run (the seeded 7B parent); without it, weights tiled from a random pool."""
     import torch
     try:
         import transformers
@@ -272,32 +275,35 @@ def cpu_baseline(n_tokens, context, threads=0, sweep=None):
         avail = psutil.virtual_memory().available
     except Exception:
         avail = 0
-    dtype = torch.float32 if avail > 80e9 else torch.bfloat16
+    dtype = torch.float32 if (avail > 80e9 or model is not None) else torch.bfloat16
     torch.set_num_threads(cores)
     cfg = LlamaConfig(hidden_size=4096, num_attention_heads=32, num_key_value_heads=32, intermediate_size=11008,
-                      vocab_size=32000, num_hidden_layers=32, max_position_embeddings=2048, rms_norm_eps=1e-6,
+                      vocab_size=32000, num_hidden_layers=layers, max_position_embeddings=2048, rms_norm_eps=1e-6,
                       attention_bias=False, tie_word_embeddings=False)
     t_build = time.perf_counter()
-    with torch.device('meta'):
-        model = LlamaForCausalLM(cfg)
-    model = model.to_empty(device='cpu').to(dtype).eval()
-    pool = (torch.rand(1 << 24) * 2 - 1).mul_(0.02).to(dtype)
-    with torch.no_grad():
-        for name, p in model.named_parameters():
-            flat = p.data.view(-1)
-            if 'norm' in name:
-                flat.fill_(1.0)
-                continue
-            n = flat.numel()
-            for off in range(0, n, pool.numel()):
-                m = min(pool.numel(), n - off)
-                flat[off:off + m].copy_(pool[:m])
-        # rotary buffers are not parameters: re-create them
-        if hasattr(model.model, 'rotary_emb'):
-            model.model.rotary_emb = type(model.model.rotary_emb)(config=cfg)
+    weights = 'the seeded fp16 parent of the parity run (identical to the GPU engines\' weights)'
+    if model is None:
+        weights = 'synthetic weights tiled from a random pool'
+        with torch.device('meta'):
+            model = LlamaForCausalLM(cfg)
+        model = model.to_empty(device='cpu').to(dtype).eval()
+        pool = (torch.rand(1 << 24) * 2 - 1).mul_(0.02).to(dtype)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                flat = p.data.view(-1)
+                if 'norm' in name:
+                    flat.fill_(1.0)
+                    continue
+                n = flat.numel()
+                for off in range(0, n, pool.numel()):
+                    m = min(pool.numel(), n - off)
+                    flat[off:off + m].copy_(pool[:m])
+            # rotary buffers are not parameters: re-create them
+            if hasattr(model.model, 'rotary_emb'):
+                model.model.rotary_emb = type(model.model.rotary_emb)(config=cfg)
     cache = DynamicCache(config=cfg) if 'config' in DynamicCache.__init__.__code__.co_varnames else DynamicCache()
     kv = (torch.rand(1, 32, context, 128) * 2 - 1).to(dtype)
-    for li in range(32):
+    for li in range(layers):
         cache.update(kv.clone(), kv.clone(), li)
     build_s = time.perf_counter() - t_build
     ids = torch.tensor([[3]])
@@ -328,9 +334,9 @@ def cpu_baseline(n_tokens, context, threads=0, sweep=None):
         dt = time.perf_counter() - t0
     return dict(value=n_tokens / dt, unit='tokens/s', cores=cores, kind='reference',
                 sample=(f'HF transformers {transformers.__version__} LlamaForCausalLM (reference run_hf.py path) on the host CPU, '
-                        f'{str(dtype).split(".")[-1]}, {cores} threads, LLaMA-7B synthetic weights, batch 1, '
+                        f'{str(dtype).split(".")[-1]}, {cores} threads, LLaMA-7B ({layers} layers), {weights}, batch 1, '
                         f'{n_tokens} greedy decode steps at context {context} (synthetic KV cache, no prefill), '
-                        f'{dt:.1f} s timed, {build_s:.0f} s untimed model build'))
+                        f'{dt:.1f} s timed, {build_s:.0f} s untimed set-up'))
 
 
 def main():
@@ -382,20 +388,46 @@ def main():
     avg_dur_s = res['kernel_us']['gate_up'] * 1e-6
     bytes_per_launch = res['gate_up_bytes']
     achieved = bytes_per_launch / avg_dur_s / 1e9 if avg_dur_s > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, 'profiles', 'r01_pmc_summary.json')
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get(args.config, {}).get('gate_up_hbm_bytes_per_launch')
-        except Exception:
-            traffic = None
+    # PMC counters cannot be read from inside the timed run: `traffic` is the committed rocprofv3 measurement of this same
+    # kernel / shape (tools/refresh_pmc.sh -> profiles/*_pmc_summary.json), named in `traffic_source` - not this run's
+    traffic = traffic_source = None
+    for rnd in ('r02', 'r01'):
+        pmc = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_summary.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.config, {}).get('gate_up_hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+            if traffic is not None:
+                traffic_source = f'profiles/{rnd}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)'
+                break
     cpu = None
+    parity = cpu_model = cpu_info = None
+    if world == 1 and args.parity and args.config == 'sq':
+        # the accuracy half of the metric, on identical weights, at BASELINE.json configs[0]'s shape (bench_parity.py)
+        try:
+            import bench_parity
+            parity, cpu_model, cpu_info = bench_parity.run(
+                torch, dev, layers=args.layers, new_tokens=args.parity_new_tokens, cpu_threads=args.cpu_threads or _default_cpu_threads(),
+                log=lambda m: print(f'[bench parity] {m}', file=sys.stderr, flush=True))
+        except Exception as e:  # the decode metric must not depend on the side report
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            parity = {'error': repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline(args.cpu_tokens, args.context, args.cpu_threads,
-                               [int(x) for x in args.cpu_sweep.split(',') if x])
+                               [int(x) for x in args.cpu_sweep.split(',') if x], model=cpu_model, layers=args.layers)
+            if cpu_info:
+                # BASELINE.json configs[0]: HF CPU, batch 1, prompt 128 - the reference's own latency definition
+                # (run_hf.py: generate() wall time; tokens/s = new tokens / latency, T/benchmarks/gpt_benchmark.py:339)
+                cpu['config0_hf_cpu_prompt128'] = {
+                    'tokens_per_s': cpu_info['tokens_per_s'], 'latency_s': cpu_info['latency_s'], 'prompt_len': cpu_info['prompt_len'],
+                    'new_tokens': cpu_info['new_tokens'], 'threads': cpu_info['threads'],
+                    'definition': 'new tokens / generate() latency, prefill included (run_hf.py semantics)'}
         except Exception as e:
             cpu = dict(value=None, unit='tokens/s', cores=os.cpu_count(), kind='reference', sample=f'failed: {e!r}')
+    del cpu_model
     names = {'sq': 'SmoothQuant per-channel int8 (act+weight) + int8 KV cache', 'woq8': 'weight-only int8 + int8 KV cache',
              'woq4': 'weight-only int4 + int8 KV cache', 'fp16': 'fp16 + fp16 KV cache'}
     line = {
@@ -416,9 +448,9 @@ def main():
                    'seq_len': args.context, 'parallelism': f'tp{world}', 'allreduce': allreduce_path,
                    'step_launch': 'hipGraph replay' if res.get('graph', True) else 'eager (graph capture failed)'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                     # name as rocprofv3 prints it: gemv_kernel<WT, PK_NORM = 1, EK_SWIGLU = 1, MB = 1, NXV = 2>
-                     'kernel': 'gemv_kernel<%d, 1, 1, 1, 2> (RMSNorm -> gate|up GEMV -> SwiGLU; 25-30 %% of a step)'
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
+                     # name as rocprofv3 prints it: gemv_kernel<WT, PK_NORM = 1, EK_SWIGLU = 1, MB = 1, NXV = 2, U = 4>
+                     'kernel': 'gemv_kernel<%d, 1, 1, 1, 2, 4> (RMSNorm -> gate|up GEMV -> SwiGLU; 25-30 %% of a step)'
                                % {'sq': 3, 'woq8': 1, 'woq4': 2, 'fp16': 0}[args.config],
                      'bytes_per_launch': bytes_per_launch, 'avg_launch_us': avg_dur_s * 1e6},
         'cpu_baseline': cpu,
@@ -441,6 +473,8 @@ def main():
             line['sq_gemm_mfma'] = sq_gemm_mfma_report(torch, dev)
         except Exception as e:  # the decode metric must not depend on the side report
             line['sq_gemm_mfma'] = {'error': repr(e)}
+    if parity is not None:
+        line['parity'] = parity
     if fp16 is not None:
         line['fp16_tokens_per_s'] = fp16['tokens_per_s']
         line['int8_over_fp16'] = res['tokens_per_s'] / fp16['tokens_per_s']

@@ -114,6 +114,18 @@ int32_t tllm_session_get_logits(tllm_session_t s, float* logits /* [B, vocab] */
 int32_t tllm_session_get_output_ids(tllm_session_t s, int32_t* ids /* [B, max_in + max_new] */, tllm_stream_t stream);
 /* Device pointer of a layer's KV cache (layout [B,2,H/tp,Smax,Dh]) for inspection. */
 void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer);
+/* The step-dependent tensors the reference's Python loop builds on the host every step (PY/runtime/generation.py:556-579,
+ * :686-689, :735-750, :812-821) live in device memory here and are advanced by the sampler kernel; this copies them out so
+ * that tests can pin them to the reference's values (any pointer may be NULL):
+ *   sequence_length [B]        cache slots in use = the reference's `sequence_length` / `past_key_value_length[0]` input of
+ *                              the NEXT generation step (max_input_len + step);
+ *   next_position   [B]        rotary position of the token the next step consumes = the reference's `position_ids` of that
+ *                              step (input_lengths + step);
+ *   masked_tokens   [B, Smax]  1 on the padding slots [input_lengths[b], max_input_len);
+ *   input_lengths   [B]. */
+int32_t tllm_session_get_step_state(tllm_session_t s, int32_t* sequence_length, int32_t* next_position, int32_t* masked_tokens,
+    int32_t* input_lengths, tllm_stream_t stream);
+
 /* Parity-test tap (sessions created with debug_taps=1 only): the input of layer `layer`'s O-projection GEMM as the last
  * generation step computed it - the attention context after the split-KV merge, [B, H/tp * Dh] fp16, or int8 when the
  * O-projection's prologue quantises it (SmoothQuant: sat(rni(ctx * attention.quantization_scaling_factor)), or the

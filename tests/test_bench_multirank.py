@@ -1,5 +1,5 @@
 """bench.py's N > 1 flow (torchrun, sharded synthetic weights, barriers, max over ranks, rank-0 JSON line) on a 1-GPU
-box: two ranks share the GPU (TLLM_TEST_SHARED_GPU=1: gloo for torch.distributed, the peer-to-peer transport for the
+box: two (7B layers at tp 2) or four ranks (tp 4: Ir = 2752, Vr = 8000 - BASELINE.json configs[4]) share the GPU (TLLM_TEST_SHARED_GPU=1: gloo for torch.distributed, the peer-to-peer transport for the
 model's all-reduces / all-gather).  The number itself means nothing (two ranks time-slice one GPU); the run and the
 finite outputs do."""
 import json
@@ -14,20 +14,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.parametrize('world,layers', [(2, 4), (4, 2)])
+def test_bench_ranks_sharing_one_gpu(world, layers):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, TLLM_TEST_SHARED_GPU='1')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-                        '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '8',
-                        '--warmup', '2', '--layers', '4', '--no-prefill', '--no-fp16-ref', '--no-cpu-baseline'],
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', '8',
+                        '--warmup', '2', '--layers', str(layers), '--no-prefill', '--no-fp16-ref', '--no-cpu-baseline'],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'tp2' and d['config']['allreduce'] == 'p2p'
+    assert d['n_gpus'] == world and d['config']['parallelism'] == f'tp{world}' and d['config']['allreduce'] == 'p2p'
     assert d['step']['outputs_finite'] and d['value'] > 0 and d['steps'] == 8
-    assert d['step']['launches_per_step']['comm'] == 2 * 4 + 0  # two all-reduces per layer (the gather is in the head)
+    assert d['step']['launches_per_step']['comm'] == 2 * layers + 0  # two all-reduces per layer (the gather is in the head)

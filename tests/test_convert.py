@@ -165,3 +165,63 @@ def test_ft_dir_to_engine_to_generation_vs_hf(tmp_path, flags):
     assert np.mean(np.abs(logits - ref)) < (1.5e-2 if sq else 4e-3) * scale
     if not sq and '--int8_kv_cache' not in flags:
         np.testing.assert_array_equal(logits.argmax(-1), ref.argmax(-1))
+
+
+@pytest.mark.parametrize('mode,flags', [
+    ('sq', dict(per_channel=True, per_token=False, int8_kv=True)),
+    ('sq', dict(per_channel=False, per_token=False, int8_kv=False)),
+    ('sq', dict(per_channel=True, per_token=True, int8_kv=False)),
+    ('sq', dict(per_channel=False, per_token=True, int8_kv=True)),
+    ('woq8', dict(int8_kv=True)),
+    ('woq4', dict(int8_kv=False)),
+    ('fp16', dict(int8_kv=False)),
+])
+def test_in_memory_conversion_equals_the_ft_directory_route(tmp_path, mode, flags):
+    """examples/llama_quant/inmemory.py (what bench.py's 7B parity run uses: no 30 GB of files) must produce, byte for byte,
+    the tensors of hf_llama_convert.py -> FT directory -> build.py's model -> weight.py::load_from_ft_llama."""
+    import torch
+    import hf_llama_convert as C
+    import inmemory
+    import smoothquant
+    from tensorrt_llm.models import LLaMAForCausalLM, smooth_quantize, weight_only_quantize
+    from tensorrt_llm.quantization import QuantMode
+    from weight import load_from_ft_llama
+    m, hf_dir = tiny_hf(tmp_path)
+    sq = mode == 'sq'
+    int8_kv = flags.get('int8_kv', False)
+    # route A: files
+    args = C.ProgArgs(out_dir=str(tmp_path / 'ft'), in_file=hf_dir, smoothquant=0.5 if sq else None, calibrate_kv_cache=int8_kv,
+                      calib_samples=4, calib_len=32)
+    ft = C.hf_llama_converter(args)
+    if sq:
+        qm = QuantMode.use_smooth_quant(flags['per_token'], flags['per_channel'])
+    elif mode.startswith('woq'):
+        qm = QuantMode.use_weight_only(mode == 'woq4')
+    else:
+        qm = QuantMode(0)
+    if int8_kv:
+        qm = qm.set_int8_kv_cache()
+    model = LLaMAForCausalLM(num_layers=2, num_heads=4, hidden_size=128, vocab_size=160, hidden_act='silu',
+                             max_position_embeddings=128, dtype='float16', mlp_hidden_size=256, tensor_parallel=1,
+                             tensor_parallel_group=[0], quant_mode=qm)
+    if sq:
+        model = smooth_quantize(model, qm)
+    elif mode.startswith('woq'):
+        model = weight_only_quantize(model, qm)
+    load_from_ft_llama(model, str(ft), 0, 1, 'float16')
+    want = {name: np.ascontiguousarray(p.raw_value) for name, p in model.named_parameters()}
+    # route B: memory, from the same calibration prompts
+    act = None
+    if sq or int8_kv:
+        act = smoothquant.capture_activation_range(m, C.calibration_samples(args, 160), num_samples=512)
+    got = inmemory.engine_tensors(dict(m.state_dict()), 2, mode=mode, act_range=act, num_heads=4, threads=2,
+                                  **{k: v for k, v in flags.items()})
+    got = {k: v.cpu().numpy() for k, v in got.items()}
+    assert set(got) == set(want), (sorted(set(got) ^ set(want)))
+    for k in sorted(want):
+        a, b = got[k], want[k]
+        assert a.nbytes == b.nbytes, (k, a.shape, a.dtype, b.shape, b.dtype)
+        if b.dtype == np.float32 and a.dtype == np.float32:
+            np.testing.assert_allclose(a.reshape(-1), b.reshape(-1), rtol=1e-6, err_msg=k)
+        else:
+            np.testing.assert_array_equal(a.reshape(-1).view(np.uint8), b.reshape(-1).view(np.uint8), err_msg=k)

@@ -1,0 +1,176 @@
+"""BASELINE.json configs[4] (SmoothQuant int8, tensor parallel) at the per-rank extents of LLaMA-7B: tp = 4 and tp = 8 sessions
+of one 7B-dimension layer + the 32000-token head, every rank a process with ITS shard, sharing the one GPU of the test box and
+exchanging partial sums through the one-shot peer-to-peer all-reduce / all-gather inside the captured step graph.
+
+What this reaches that the toy-size TP tests do not: heads per rank 8 / 4, FFN columns per rank Ir = 2752 / 1376 (the
+down-projection's K is then NOT a multiple of the 128-byte K-tile: 1376 = 10.75 tiles), attention width Dr = 1024 / 512 for the
+O-projection's merge prologue, vocabulary shard Vr = 8000 / 4000, and the 7- / 8-way peer-to-peer exchange.  Sharding rules:
+T/examples/llama/weight.py:86-172 via the product's own split helpers; SmoothQuant scales: per-channel factors split with
+the columns of column-parallel GEMMs and shared by row-parallel ones (Q/convert.py:125-141).  Reference = the un-sharded
+session on the same quantised tensors (itself held to the oracle in test_gpu_bench_geometry.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EX = os.path.join(ROOT, 'trtllm-llama_amd', 'examples', 'llama_quant')
+pytestmark = pytest.mark.gpu
+
+NEW = 8
+B, S = 2, 40
+LENS = np.array([40, 27], np.int32)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def shard_sq(et, tp, rank, num_layers):
+    """un-sharded SmoothQuant engine tensors (reference module names) -> this rank's"""
+    sys.path.insert(0, EX)
+    import weight as W
+    out = {'vocab_embedding.weight': et['vocab_embedding.weight'], 'ln_f.weight': et['ln_f.weight'],
+           'lm_head.weight': W.split(et['lm_head.weight'], tp, rank)}
+    for i in range(num_layers):
+        p = f'layers.{i}.'
+        for k, v in et.items():
+            if k.startswith(p) and k not in out:
+                out[k] = v  # norms, scalars, row-parallel scales: replicated
+        out[p + 'attention.qkv.weight'] = W.split_qkv(et[p + 'attention.qkv.weight'], tp, rank)
+        out[p + 'attention.qkv.per_channel_scale'] = W.split_qkv(et[p + 'attention.qkv.per_channel_scale'].reshape(-1, 1), tp,
+                                                                 rank).reshape(1, -1)
+        out[p + 'attention.dense.weight'] = W.split(et[p + 'attention.dense.weight'], tp, rank, dim=1)
+        for n in ('mlp.fc', 'mlp.gate'):
+            out[p + n + '.weight'] = W.split(et[p + n + '.weight'], tp, rank, dim=0)
+            out[p + n + '.per_channel_scale'] = W.split(et[p + n + '.per_channel_scale'], tp, rank, dim=1)
+        out[p + 'mlp.proj.weight'] = W.split(et[p + 'mlp.proj.weight'], tp, rank, dim=1)
+    return {k: np.ascontiguousarray(v) for k, v in out.items()}
+
+
+def run_session(et, cfg, qm, tp, rank, ids):
+    from tensorrt_llm.runtime.native import NativeSession
+    s = NativeSession(dict(cfg, quant_mode=qm, tp_size=tp, tp_rank=rank))
+    for k, v in shard_sq(et, tp, rank, cfg['num_layers']).items():
+        s.set_tensor(k, v)
+    s.finalize()
+    s.setup(B, S, NEW)
+    s.context(ids, LENS)
+    l0 = s.logits()
+    s.step(1, use_graph=False)
+    l1 = s.logits()
+    s.step(NEW - 2, use_graph=True)
+    l2 = s.logits()
+    out = s.output_ids()
+    s.close()
+    return l0, l1, l2, out
+
+
+def _rank(rank, world, port, path, q):
+    import ctypes
+    import json
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'trtllm-llama_amd'))
+    from tensorrt_llm.plugin import capi
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        lib = capi.load_library()
+        lib.tllm_comm_p2p_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]
+        lib.tllm_comm_p2p_attach.argtypes = [ctypes.c_void_p]
+        lib.tllm_comm_p2p_enable.argtypes = [ctypes.c_int32]
+        lib.tllm_comm_p2p_enable.restype = None
+        h = (ctypes.c_char * 64)()
+        assert lib.tllm_comm_p2p_create(world, rank, 128 * 1024, h) == 0, capi.last_error()
+        allh = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(allh, torch.frombuffer(bytearray(h.raw), dtype=torch.uint8))
+        blob = b''.join(bytes(x.numpy().tobytes()) for x in allh)
+        assert lib.tllm_comm_p2p_attach(ctypes.create_string_buffer(blob, len(blob))) == 0, capi.last_error()
+        lib.tllm_comm_p2p_enable(1)  # no RCCL communicator exists here: a silent fall-back would fail loudly
+        et = dict(np.load(os.path.join(path, 'engine_tensors.npz')))
+        meta = json.load(open(os.path.join(path, 'meta.json')))
+        ids = np.load(os.path.join(path, 'ids.npy'))
+        res = run_session(et, meta['cfg'], meta['quant_mode'], world, rank, ids)
+        q.put((rank, ) + res + (int(lib.tllm_comm_p2p_error()), ))
+        dist.barrier()
+        lib.tllm_comm_destroy_all()
+    except BaseException as e:
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+_prepared = {}
+
+
+def prepare(tmp_path_factory):
+    """one quantised 7B-dimension layer + full-size head, saved once for the rank processes of both world sizes"""
+    if 'path' in _prepared:
+        return _prepared
+    import json
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle import quant_oracle as QO
+    from test_gpu_session import synth_model
+    cfg, w = synth_model(29, L=1, H=32, D=4096, I=11008, V=32000)
+    r = np.random.default_rng(13)
+    ids = np.full((B, S), 2, np.int32)
+    for b in range(B):
+        ids[b, :LENS[b]] = r.integers(3, cfg['vocab_size'], LENS[b])
+    qmodel = QO.quantise_model(cfg, w, 'sq_static_pc', 1, calib_ids=ids, calib_lens=LENS)
+    path = str(tmp_path_factory.mktemp('tp7b'))
+    np.savez(os.path.join(path, 'engine_tensors.npz'), **qmodel['engine_tensors'])
+    np.save(os.path.join(path, 'ids.npy'), ids)
+    json.dump(dict(cfg=cfg, quant_mode=qmodel['quant_mode']), open(os.path.join(path, 'meta.json'), 'w'))
+    sys.path.insert(0, os.path.join(ROOT, 'trtllm-llama_amd'))
+    ref = run_session(qmodel['engine_tensors'], cfg, qmodel['quant_mode'], 1, 0, ids)
+    _prepared.update(path=path, ref=ref, cfg=cfg)
+    return _prepared
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_tp_sessions_at_7b_per_rank_extents_match_the_unsharded_session(world, tmp_path_factory):
+    import torch.multiprocessing as mp
+    prep = prepare(tmp_path_factory)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, world, port, prep['path'], q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    bad = [r for r in res if len(r) != 6]
+    assert not bad, bad
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res = sorted(res, key=lambda r: r[0])
+    ref = prep['ref']
+    scale = max(np.abs(ref[0]).max(), 1.0)
+    for rank, l0, l1, l2, out, err in res:
+        assert err == 0, f'rank {rank}: a peer-to-peer wait timed out'
+        # every rank holds the same gathered logits and so the same tokens
+        np.testing.assert_array_equal(l2, res[0][3])
+        np.testing.assert_array_equal(out, res[0][4])
+    _, l0, l1, l2, out, _ = res[0]
+    assert l0.shape == ref[0].shape == (B, 32000)
+    # a row-parallel int8 GEMM split over `world` ranks rounds `world` fp16 partial products instead of one: the logits move
+    # by a few fp16 ulps of the hidden state, amplified through the static quantisers (+-1 LSB flips) - same bound as the
+    # kernel-vs-oracle comparison of the SmoothQuant model
+    for name, got, want in (('context', l0, ref[0]), ('step 1', l1, ref[1]), (f'step {NEW - 1}', l2, ref[2])):
+        d = np.abs(got - want)
+        print(f'tp={world} {name}: max |d| {d.max():.4g} mean |d| {d.mean():.4g} (scale {scale:.4g})')
+        assert d.max() < 8e-2 * scale and d.mean() < 1.2e-2 * scale, name
+    np.testing.assert_array_equal(out[:, :S], ref[3][:, :S])
+    agree = np.mean(out[:, S:] == ref[3][:, S:])
+    print(f'tp={world}: greedy tokens identical to the un-sharded run: {agree * 100:.0f} %')
+    assert agree >= 0.75, (out[:, S:], ref[3][:, S:])

@@ -284,6 +284,7 @@ struct GreedyParams
     // input_lengths[b])  (MM/...Template.h:1425-1426), so that the attention kernel does not chase
     // length -> position -> table
     float* rope_row_out = nullptr;     // f32 [B, rope_half, 2]
+    int32_t* rope_pos_out = nullptr;   // optional int32 [B]: the position that row was taken at (parity tests read it back)
     const float* rope_table = nullptr; // f32 [rope_table_len, rope_half, 2]
     int32_t rope_half = 0, rope_table_len = 0;
     const int32_t* input_lengths = nullptr;
@@ -318,6 +319,7 @@ struct BeamParams
     int32_t end_id = -1, advance = 0;
     int32_t* cache_indirection = nullptr; // [batch * beam, out_stride]
     float* rope_row_out = nullptr;
+    int32_t* rope_pos_out = nullptr; // as GreedyParams
     const float* rope_table = nullptr;
     int32_t rope_half = 0, rope_table_len = 0;
     const int32_t* input_lengths = nullptr;

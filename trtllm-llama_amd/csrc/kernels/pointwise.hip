@@ -462,6 +462,8 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const GreedyParams p)
         pos = pos < 0 ? 0 : (pos >= p.rope_table_len ? p.rope_table_len - 1 : pos);
         reinterpret_cast<float2*>(p.rope_row_out)[(int64_t) b * p.rope_half + j]
             = reinterpret_cast<const float2*>(p.rope_table)[(int64_t) pos * p.rope_half + j];
+        if (j == 0 && p.rope_pos_out)
+            p.rope_pos_out[b] = pos;
     }
     __syncthreads();
     if (threadIdx.x == 0)
@@ -662,6 +664,8 @@ __global__ __launch_bounds__(1024) void beam_step_kernel(const BeamParams p)
         for (int i = tid; i < W * p.rope_half; i += blockDim.x)
             reinterpret_cast<float2*>(p.rope_row_out)[(int64_t) bb0 * p.rope_half + i]
                 = reinterpret_cast<const float2*>(p.rope_table)[(int64_t) pos * p.rope_half + i % p.rope_half];
+        if (p.rope_pos_out && tid < W)
+            p.rope_pos_out[bb0 + tid] = pos;
     }
 }
 

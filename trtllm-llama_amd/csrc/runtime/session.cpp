@@ -188,6 +188,7 @@ struct tllm_session
     const float* rope = nullptr;
     int rope_len = 0;
     float* rope_row = nullptr; // [B, Dh/2, 2]: cos/sin row of the next generation step (written by the sampler)
+    int32_t* rope_pos = nullptr; // [B]: the position that row belongs to (tllm_session_get_step_state)
     int attn_nit = 4, attn_tchunk = 0, attn_ns = 0;
     size_t attn_o_off = 0;
     bool attn_fused = false; // split-KV merge fused into the O-projection prologue
@@ -639,6 +640,7 @@ struct tllm_session
             bp.advance = advance;
             bp.cache_indirection = cache_ind;
             bp.rope_row_out = rope_row;
+            bp.rope_pos_out = rope_pos;
             bp.rope_table = rope;
             bp.rope_half = Dh / 2;
             bp.rope_table_len = rope_len;
@@ -660,6 +662,7 @@ struct tllm_session
         gp.end_id = end_id;
         gp.advance = advance;
         gp.rope_row_out = rope_row;
+        gp.rope_pos_out = rope_pos;
         gp.rope_table = rope;
         gp.rope_half = Dh / 2;
         gp.rope_table_len = rope_len;
@@ -1217,6 +1220,8 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
         return 1;
     RUN(s->dalloc(&s->rope_row, (size_t) B * s->Dh * sizeof(float)));
     HIP_OK(hipMemset(s->rope_row, 0, (size_t) B * s->Dh * sizeof(float)));
+    RUN(s->dalloc(&s->rope_pos, (size_t) B * 4));
+    HIP_OK(hipMemset(s->rope_pos, 0, (size_t) B * 4));
     // coarse KV splits (16 rows per lane group) + merge fused into the O-projection when that needs <= 8 partials
     // per head; otherwise the fine split with its own combine launch
     {
@@ -1604,6 +1609,27 @@ int32_t tllm_session_get_beam_state(tllm_session_t s, int32_t* parent_ids, int32
         HIP_OK(hipMemcpyAsync(finished, s->finished, (size_t) s->B * 4, hipMemcpyDeviceToHost, st));
     if (sequence_lengths)
         HIP_OK(hipMemcpyAsync(sequence_lengths, s->seq_len, (size_t) s->B * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int32_t tllm_session_get_step_state(tllm_session_t s, int32_t* sequence_length, int32_t* next_position, int32_t* masked_tokens,
+    int32_t* input_lengths, tllm_stream_t stream)
+{
+    if (!s || !s->B)
+    {
+        set_error("tllm_session_get_step_state: setup not called");
+        return 1;
+    }
+    hipStream_t st = s->pick(stream);
+    if (sequence_length)
+        HIP_OK(hipMemcpyAsync(sequence_length, s->seq_len, (size_t) s->B * 4, hipMemcpyDeviceToHost, st));
+    if (next_position)
+        HIP_OK(hipMemcpyAsync(next_position, s->rope_pos, (size_t) s->B * 4, hipMemcpyDeviceToHost, st));
+    if (masked_tokens)
+        HIP_OK(hipMemcpyAsync(masked_tokens, s->masked, (size_t) s->B * s->Smax * 4, hipMemcpyDeviceToHost, st));
+    if (input_lengths)
+        HIP_OK(hipMemcpyAsync(input_lengths, s->in_len, (size_t) s->B * 4, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     return 0;
 }

@@ -54,11 +54,19 @@ def generate_int8(weights, act_range, is_qkv=False, multi_query_mode=False):
     if is_qkv:
         scale_y_accum_quant_t = np.broadcast_to(scale_y_accum_quant_t, scale_w_orig_quant_c.shape)
         scale_w_quant_orig_t = np.broadcast_to(scale_w_quant_orig_t, scale_w_orig_quant_c.shape)
-    to_i8 = lambda x: x.round().clip(-127, 127).astype(np.int8)
-    weights = np.asarray(weights)
+    if hasattr(weights, 'detach'):
+        # a torch tensor (possibly on the GPU: a 7B model is 6.5e9 weights, minutes in numpy): the same arithmetic -
+        # float32 product, round-half-even, clip to +-127 - on the tensor's own device; the int8 results stay there
+        import torch
+        wt = weights.detach().to(torch.float32)
+        to_i8 = lambda s: (wt * torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32)).to(wt.device)).round_() \
+            .clamp_(-127, 127).to(torch.int8)
+    else:
+        weights = np.asarray(weights)
+        to_i8 = lambda s: (weights * s).round().clip(-127, 127).astype(np.int8)
     return {
-        'weight.int8': to_i8(weights * scale_w_orig_quant_t),
-        'weight.int8.col': to_i8(weights * scale_w_orig_quant_c),
+        'weight.int8': to_i8(scale_w_orig_quant_t),
+        'weight.int8.col': to_i8(scale_w_orig_quant_c),
         'scale_x_orig_quant': scale_x_orig_quant_t.astype(np.float32),
         'scale_w_quant_orig': np.asarray(scale_w_quant_orig_t).astype(np.float32),
         'scale_w_quant_orig.col': scale_w_quant_orig_c.astype(np.float32),

@@ -7,7 +7,6 @@ import time
 
 import numpy as np
 import torch
-from transformers import LlamaForCausalLM, LlamaTokenizer
 
 
 def parse_arguments():
@@ -23,7 +22,23 @@ def parse_arguments():
     return p.parse_args()
 
 
+def hf_generate(model, ids, max_output_len, num_beams=1, eos_token_id=2, pad_token_id=2, return_logits=False):
+    """The reference's generate call (run_hf.py:76-84): greedy (top_k = 1, no sampling) or beam search, EOS = PAD = 2.
+    ids: int64 [batch, prompt_len] on the model's device.  Returns the full sequences [batch, prompt_len + new]; with
+    return_logits also the raw next-token logits of every step, float32 [new, batch, vocab].  eos_token_id=None keeps
+    whatever the model's generation config says (a config without an EOS token never stops early: benchmarks)."""
+    kw = dict(max_new_tokens=max_output_len, top_k=1, num_beams=num_beams, do_sample=False, pad_token_id=pad_token_id)
+    if eos_token_id is not None:
+        kw['eos_token_id'] = eos_token_id
+    with torch.no_grad():
+        if not return_logits:
+            return model.generate(ids, **kw)
+        out = model.generate(ids, output_logits=True, return_dict_in_generate=True, **kw)
+    return out.sequences, torch.stack([l.float() for l in out.logits])
+
+
 def main():
+    from transformers import LlamaForCausalLM, LlamaTokenizer
     args = parse_arguments()
     device = args.device or ('cuda' if torch.cuda.is_available() else 'cpu')
     tok = LlamaTokenizer.from_pretrained(args.tokenizer_dir or args.hf_model_location, legacy=False)
@@ -34,9 +49,7 @@ def main():
     for _ in range(args.num_runs):
         t0 = time.time()
         ids = tok.encode(args.input_text, return_tensors='pt', add_special_tokens=False).to(device)
-        with torch.no_grad():
-            out = model.generate(ids, max_new_tokens=args.max_output_len, top_k=1, num_beams=args.num_beams, do_sample=False,
-                                 eos_token_id=2, pad_token_id=2)
+        out = hf_generate(model, ids, args.max_output_len, args.num_beams)
         text = tok.decode(out[0, ids.shape[1]:].tolist())
         if device == 'cuda':
             torch.cuda.synchronize()

@@ -56,6 +56,8 @@ def _lib():
     lib.tllm_session_get_output_ids.restype = c.c_int32
     lib.tllm_session_kv_cache_ptr.argtypes = [c.c_void_p, c.c_int32]
     lib.tllm_session_kv_cache_ptr.restype = c.c_void_p
+    lib.tllm_session_get_step_state.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.tllm_session_get_step_state.restype = c.c_int32
     lib.tllm_session_get_tap.argtypes = [c.c_void_p, c.c_int32, c.c_void_p, c.c_size_t, c.c_void_p]
     lib.tllm_session_get_tap.restype = c.c_int32
     lib.tllm_session_step_bytes.argtypes = [c.c_void_p, c.c_int32]
@@ -194,6 +196,17 @@ class NativeSession:
 
     def kv_cache_ptr(self, layer: int) -> int:
         return _lib().tllm_session_kv_cache_ptr(self._h, layer)
+
+    def step_state(self, stream: int = 0):
+        """dict(sequence_length, next_position, input_lengths [batch * beam], masked_tokens [batch * beam, max_seq_len]): the
+        device-resident counterparts of the per-step host tensors of the reference's decode loop."""
+        n, smax = self.batch * self.beam, self.max_in + self.max_new
+        d = dict(sequence_length=np.empty(n, np.int32), next_position=np.empty(n, np.int32),
+                 masked_tokens=np.empty((n, smax), np.int32), input_lengths=np.empty(n, np.int32))
+        _check(_lib().tllm_session_get_step_state(self._h, d['sequence_length'].ctypes.data, d['next_position'].ctypes.data,
+                                                  d['masked_tokens'].ctypes.data, d['input_lengths'].ctypes.data, stream),
+               'get_step_state')
+        return d
 
     def attention_tap(self, layer: int, heads_x_dh: int, quantised: bool, stream: int = 0) -> np.ndarray:
         """O-projection input of the last generation step (debug_taps=1): [batch * beam, H/tp * Dh] fp16, int8 for SmoothQuant."""
