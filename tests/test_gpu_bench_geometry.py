@@ -78,8 +78,10 @@ def test_decoder_layer_at_the_bench_geometry_vs_oracle(mode, int8_kv):
     sq = mode.startswith('sq')
     d_ctx = np.abs(logits_ctx - ref0[0])
     print(f'\n[{mode}] context logits: max |d| = {d_ctx.max():.4g}, mean |d| = {d_ctx.mean():.4g}, scale = {scale:.4g}')
-    np.testing.assert_allclose(logits_ctx, ref0[0], atol=(6e-2 if sq else 3e-2) * scale)
-    assert d_ctx.mean() < (1e-2 if sq else 5e-3) * scale
+    # observed on MI355X: SmoothQuant max 3.4e-2 / mean 8.9e-3 of the logit range (+-1 LSB quantiser flips amplified by
+    # the following GEMMs), fp16 / weight-only max 9e-4 / mean 2.5e-4
+    np.testing.assert_allclose(logits_ctx, ref0[0], atol=(5e-2 if sq else 5e-3) * scale)
+    assert d_ctx.mean() < (1.2e-2 if sq else 1e-3) * scale
     ocache = taps0['caches_after_context'][0]  # [B, 2, H, S + 1, Dh]
     got = gpu_cache_ctx[:, :, :, :S].astype(np.float32)
     want = ocache[:, :, :, :S].astype(np.float32)
@@ -119,12 +121,13 @@ def test_decoder_layer_at_the_bench_geometry_vs_oracle(mode, int8_kv):
         else:
             d = np.abs(got_taps[i].astype(np.float32) - octx)
             print(f'[{mode}] step {i} (length {S + i}): O-projection input max |d| = {d.max():.3g}')
-            np.testing.assert_allclose(got_taps[i].astype(np.float32), octx, atol=2e-3)
+            # the reference's bound (atol 2e-3 on O(1) data) + one fp16 ulp where |ctx| > 2 (ulp(2..4) = 1.95e-3)
+            np.testing.assert_allclose(got_taps[i].astype(np.float32), octx, atol=2e-3, rtol=1e-3)
         dl = np.abs(got_logits[i] - ref[i + 1])
         print(f'[{mode}] step {i}: logits max |d| = {dl.max():.4g}, mean |d| = {dl.mean():.4g} (scale {scale:.4g})')
         assert np.isfinite(got_logits[i]).all()
-        np.testing.assert_allclose(got_logits[i], ref[i + 1], atol=(6e-2 if sq else 3e-2) * scale)
-        assert dl.mean() < (1e-2 if sq else 5e-3) * scale
+        np.testing.assert_allclose(got_logits[i], ref[i + 1], atol=(5e-2 if sq else 5e-3) * scale)
+        assert dl.mean() < (1.2e-2 if sq else 1e-3) * scale
 
 
 def test_distance_to_the_reference_rounding_points():
@@ -169,7 +172,12 @@ def test_distance_to_the_reference_rounding_points():
               f'{np.abs(got_t[i] - t_r).max():.3g}  |as_built - ref_rounding| {np.abs(t_a - t_r).max():.3g}')
         print(f'step {i}: logits         |hip - as_built| {np.abs(got_l[i] - l_a).max():.3g}  |hip - ref_rounding| '
               f'{np.abs(got_l[i] - l_r).max():.3g}  |as_built - ref_rounding| {np.abs(l_a - l_r).max():.3g}  (scale {scale:.3g})')
-        np.testing.assert_allclose(got_t[i], t_a, atol=2e-3)
-        np.testing.assert_allclose(got_t[i], t_r, atol=2e-3)  # the reference's generation-attention tolerance
+        # the reference's generation-attention tolerance (atol 2e-3 on O(1) data, + one fp16 ulp relative: these outputs reach
+        # |4|) against the oracle the kernels follow.  The reference's own rounding points put ITS result up to ~4e-3 away
+        # from the single-rounding value here (16 partial sums rounded to fp16 before they are added), so against that the
+        # claim is: the HIP result is no further from the reference's rounding than exact arithmetic is, + the same tolerance
+        np.testing.assert_allclose(got_t[i], t_a, atol=2e-3, rtol=1e-3)
+        between = np.abs(t_a - t_r).max()
+        assert np.abs(got_t[i] - t_r).max() <= between + 2e-3, (np.abs(got_t[i] - t_r).max(), between)
         np.testing.assert_allclose(got_l[i], l_a, atol=3e-2 * scale)
-        np.testing.assert_allclose(got_l[i], l_r, atol=3e-2 * scale)
+        assert np.abs(got_l[i] - l_r).max() <= np.abs(l_a - l_r).max() + 1e-2 * scale

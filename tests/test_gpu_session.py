@@ -210,8 +210,11 @@ def test_quantised_paths_vs_oracle(mode, int8_kv):
     scale = max(np.abs(ref_logits[0]).max(), 1.0)
     sq = mode.startswith('sq')
     for g, r in ((got[0], ref_logits[0]), (got[1], ref_logits[1]), (got[2], ref_logits[3])):
-        np.testing.assert_allclose(g, r, atol=(8e-2 if sq else 3e-2) * scale)
-        assert np.abs(g - r).mean() < (1.2e-2 if sq else 5e-3) * scale
+        print(f'[{mode} kv8={int8_kv}] max |d| / scale = {np.abs(g - r).max() / scale:.4g}, mean |d| / scale = {np.abs(g - r).mean() / scale:.4g}')
+        # observed on MI355X (r02): SmoothQuant max <= 3.6e-2, mean <= 7.5e-3 of the logit range; weight-only max <= 5.5e-3,
+        # mean <= 1.2e-3 - the bounds are those + margin (a wrong per-channel scale on a few columns moves the max past them)
+        np.testing.assert_allclose(g, r, atol=(5e-2 if sq else 1e-2) * scale)
+        assert np.abs(g - r).mean() < (1e-2 if sq else 2.5e-3) * scale
     # and the quantised model must stay close to its fp16 parent (sanity of the scale algebra, not a kernel check)
     fp = QO.run_fp16_model(cfg, w, ids, lens, NEW, feed_ids=out[:, S:S + NEW])[0]
     tol = {'woq8': 0.15, 'woq4': 1.5, 'sq_static': 0.6, 'sq_static_pc': 0.6, 'sq_dyn': 0.4, 'sq_dyn_pc': 0.4}[mode]
@@ -251,8 +254,8 @@ def test_one_layer_at_7b_dimensions_vs_oracle(mode, int8_kv):
     sq = mode.startswith('sq')
     for g, rr in ((got[0], ref_logits[0]), (got[1], ref_logits[1]), (got[2], ref_logits[3])):
         assert np.isfinite(g).all()
-        np.testing.assert_allclose(g, rr, atol=(8e-2 if sq else 3e-2) * scale)
-        assert np.abs(g - rr).mean() < (1.2e-2 if sq else 5e-3) * scale
+        np.testing.assert_allclose(g, rr, atol=(5e-2 if sq else 1e-2) * scale)
+        assert np.abs(g - rr).mean() < (1.2e-2 if sq else 2.5e-3) * scale
 
 
 @pytest.mark.parametrize('mode,int8_kv', [('fp16', 0), ('sq_static_pc', 1)])
