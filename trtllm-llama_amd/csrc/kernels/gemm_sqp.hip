@@ -1,0 +1,529 @@
+// SmoothQuant int8 GEMM for prefill, phased pipeline:  C[m,n] = float(sum_k X[m,k] * W[n,k]) * (s_col[n] * s_row[m])
+// (A10: K/cutlass_kernels/int8_gemm/int8_gemm_template.h:56-172, epilogue
+//  K/cutlass_extensions/.../epilogue_per_row_per_col_scale.h:279-347 - exact int32 accumulation, one fp32 scale product.)
+//
+// Why a second kernel next to gemm_glds.hip: that one is a lock-step loop (one barrier per K-tile, the whole next tile
+// requested in a burst, fragment reads right in front of the MFMAs that use them, vmcnt(0) every tile) and its matrix
+// pipe sits idle ~55 % of the time (profiles/r02_mfma_pmc.txt).  This one is built around the three things that keep the
+// pipe busy on CDNA4:
+//   1. the tile's operands live in LDS as QUARTER units (X-half 0/1, W-half 0/1, each a full 128-byte K line per row) in
+//      two buffers; a unit is re-requested by LDS-DMA the moment its last reader is past it, so 4-6 units (~56 KB per CU)
+//      are always in flight and the wait in front of a barrier is a COUNTED vmcnt that never drains the queue;
+//   2. a K-tile is four phases, one C quadrant each (X-half i x W-half j); the fragments of the next phase are read into
+//      registers while the MFMAs of this phase run, so no MFMA ever waits for an LDS read it has just issued;
+//   3. the LDS-DMA instructions (60-185 cycles of issue each) sit in the MIDDLE of a phase's MFMA run, at different
+//      positions for the two waves that share a SIMD, so one wave's MFMAs cover the other's DMA issue.
+// MFMA: v_mfma_i32_16x16x64_i8 (random-operand ceiling 4.1 POP/s vs 3.5 for 32x32x32, profiles/r02_mfma_ceiling.txt).
+// W rows are the MFMA's A operand and X rows its B operand, so a lane ends up with 4 consecutive output COLUMNS of one
+// output row (D row = 4 * (lane >> 4) + r -> n, D col = lane & 15 -> m).
+//
+// LDS image of a unit: [row][128 B], 16-byte piece p of row r stored at piece p ^ g(r), g(r) = ((r>>1 & 1) << 1) | (r>>1 & 4):
+// the lane groups of a ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32) then touch 16 different 16-byte bank
+// slots for the 16x64 fragment layout (lane l: row l & 15, pieces 4 * kstep + (l >> 4)).  The DMA writes LDS lane-linearly,
+// so the same involution is applied to each lane's global SOURCE piece.
+#include "dev_utils.h"
+#include "kernels.h"
+
+namespace tllm
+{
+namespace kernels
+{
+using namespace dev;
+
+namespace
+{
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// one LDS-DMA instruction: 64 lanes x 16 bytes, global (wave-uniform base + per-lane 32-bit offset) -> LDS [m0 + lane * 16]
+__device__ __forceinline__ void glds16s(const char* base, uint32_t off, uint32_t lds_byte)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
+}
+
+// the same with 4 bytes per lane (scales)
+__device__ __forceinline__ void glds4s(const char* base, uint32_t off, uint32_t lds_byte)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
+}
+
+__device__ __forceinline__ int swz_g(int row)
+{
+    const int j = row >> 1;
+    return ((j & 1) << 1) | (j & 4);
+}
+
+template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRIO, int ABL, int RSP>
+__global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams p)
+{
+    constexpr int NW = WR * WC;
+    constexpr int AH = WR * MTH * 16, BH = WC * NTH * 16; // rows of an X-half / W-half unit
+    constexpr int BM = 2 * AH, BN = 2 * BH;
+    constexpr int ACH = AH / 8, BCH = BH / 8;           // 1 KiB DMA chunks (8 rows) per unit
+    constexpr int APW = (ACH + NW - 1) / NW, BPW = (BCH + NW - 1) / NW; // chunk slots per wave
+    static_assert(ACH % NW == 0, "X-half chunks must divide evenly over the waves");
+    static_assert((2 * BCH) % NW == 0, "the two W-halves together must divide evenly over the waves");
+    constexpr int CYC = (2 * ACH + 2 * BCH) / NW;        // DMA instructions per wave per K-tile (= per 4 consecutive units)
+    constexpr int UA = AH * 128, UB = BH * 128;          // unit bytes
+    constexpr int BUF = 2 * UA + 2 * UB;                 // one buffer: X0 | X1 | W0 | W1
+    constexpr int OFF_X0 = 0, OFF_X1 = UA, OFF_W0 = 2 * UA, OFF_W1 = 2 * UA + UB;
+    constexpr int QM = MTH * NTH * 2;                    // MFMAs per phase
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid / WC, wc = wid % WC;
+    const int grp = wid >= NW / 2 ? 1 : 0; // the second-dispatched half: its DMA sits elsewhere in the phase
+    const int nwg = gridDim.x;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tm = wg % tiles_m, tn = wg / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int M = p.M, N = p.N;
+    const int ntile = p.K / 128;
+
+    // ---- DMA sources.  Unit kinds: 0 = X0, 1 = W0, 2 = W1, 3 = X1 (issue order inside a K-tile).  Chunk c of a unit
+    // covers rows [8c, 8c+8); lane l -> row 8c + (l >> 3), LDS piece l & 7 <- global piece (l & 7) ^ g(row).
+    // W-halves may have fewer chunks than 2 per wave: W0 hands its surplus to the low waves, W1 to the high waves.
+    const char* xb = reinterpret_cast<const char*>(p.a);
+    const char* wb = reinterpret_cast<const char*>(p.w);
+    uint32_t xo[2][APW], wo[2][BPW];
+    const int wrev = NW - 1 - wid;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+    {
+#pragma unroll
+        for (int k = 0; k < APW; ++k)
+        {
+            const int c = wid + k * NW;
+            const int row = c * 8 + (lane >> 3);
+            int gr = m0 + h * AH + row;
+            gr = gr < M ? gr : M - 1;
+            xo[h][k] = (uint32_t) (gr * (int) p.lda + (((lane & 7) ^ swz_g(row)) << 4));
+        }
+#pragma unroll
+        for (int k = 0; k < BPW; ++k)
+        {
+            int c = (h == 0 ? wid : wrev) + k * NW;
+            c = c < BCH ? c : BCH - 1;
+            const int row = c * 8 + (lane >> 3);
+            int gr = n0 + h * BH + row;
+            gr = gr < N ? gr : N - 1;
+            wo[h][k] = (uint32_t) (gr * (int) p.ldw + (((lane & 7) ^ swz_g(row)) << 4));
+        }
+    }
+    const uint32_t lds_base = (uint32_t) (uintptr_t) (lds_void_t*) lds;
+    // issue unit `kind` of K-tile t into buffer t & 1
+    auto dma = [&](int kind, int t) {
+        const uint32_t bufb = lds_base + (t & 1) * BUF;
+        if (kind == 0 || kind == 3)
+        {
+            const int h = kind == 3;
+#pragma unroll
+            for (int k = 0; k < APW; ++k)
+                glds16s(xb + (int64_t) t * 128, xo[h][k], bufb + (h ? OFF_X1 : OFF_X0) + (wid + k * NW) * 1024);
+        }
+        else
+        {
+            const int h = kind == 2;
+            const int w0 = h == 0 ? wid : wrev;
+#pragma unroll
+            for (int k = 0; k < BPW; ++k)
+                if (w0 + k * NW < BCH) // wave-uniform
+                    glds16s(wb + (int64_t) t * 128, wo[h][k], bufb + (h ? OFF_W1 : OFF_W0) + (w0 + k * NW) * 1024);
+        }
+    };
+
+    // ---- fragment read offsets: lane l -> row l & 15, piece 4 * ks + (l >> 4), swizzled; + 2048 per 16-row MFMA tile
+    const int row16 = lane & 15, kq = lane >> 4, gl = swz_g(row16);
+    int xr[2], wrd[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+    {
+        xr[ks] = (wr * MTH * 16 + row16) * 128 + (((ks * 4 + kq) ^ gl) << 4);
+        wrd[ks] = (wc * NTH * 16 + row16) * 128 + (((ks * 4 + kq) ^ gl) << 4);
+    }
+
+    i32x4 acc[2][2][MTH][NTH];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < MTH; ++m)
+#pragma unroll
+                for (int n = 0; n < NTH; ++n)
+                    acc[i][j][m][n] = i32x4{0, 0, 0, 0};
+
+    i32x4 fa[2][MTH][2];     // X-half fragments [half][m][ks]
+    i32x4 fb0[2][NTH][2];    // W-half 0 fragments, two sets: the next tile's are read while this tile's are still in use
+    i32x4 fb1[NTH][2];       // W-half 1 fragments
+
+    auto read_x = [&](i32x4 (&dst)[MTH][2], const char* unit) {
+#pragma unroll
+        for (int m = 0; m < MTH; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                dst[m][ks] = *reinterpret_cast<const i32x4*>(unit + xr[ks] + m * 2048);
+    };
+    auto read_w = [&](i32x4 (&dst)[NTH][2], const char* unit) {
+#pragma unroll
+        for (int n = 0; n < NTH; ++n)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                dst[n][ks] = *reinterpret_cast<const i32x4*>(unit + wrd[ks] + n * 2048);
+    };
+
+    // phase boundary: the unit the next reads touch has landed (own chunks by the counted wait, everybody's by the barrier),
+    // own fragment reads are done.  The wait leaves the SIX younger units in flight: the DMA latency under load is ~1.1 us
+    // = 3-4 phases, and a wait that left only four in flight (one count for every phase) parked the waves for 25 % of the
+    // kernel (SQ_WAIT_ANY).  The six-unit window holds 2 X-halves-pairs + the W-halves in between: per phase and wave half
+    //   P1: X1 X0 W0 W1 X1 X0 = 8 + (w0 + w1)      P2: X0 W0 W1 X1 X0 W0 = 6 + (w0 + w1) + w0
+    //   P3: W0 W1 X1 X0 W0 W1 = 4 + 2 (w0 + w1)    P4: W1 X1 X0 W0 W1 X1 = 6 + (w0 + w1) + w1      (w0 / w1: this wave's chunks
+    //   of a W-half 0 / 1 unit, XPW of an X-half)
+#define SQP_TOP(counted, N)                                                                                            \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (counted)                                                                                                   \
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");              \
+        else                                                                                                           \
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+    } while (0)
+
+    // ---- the tile's scales go to LDS by 4-byte LDS-DMA, ahead of the operand stream (older in the vmcnt order): the
+    // epilogue then needs no global load at all.  s_col -> [0, BN) floats, s_row -> [BN, BN + BM) floats behind the buffers
+    constexpr int SC_OFF = 2 * BUF;
+    {
+        constexpr int CCH = (BN + 63) / 64, RCH = (BM + 63) / 64;
+        const char* scb = reinterpret_cast<const char*>(p.scale_col);
+        const char* srb = reinterpret_cast<const char*>(p.scale_row);
+        for (int c = wid; c < CCH + RCH; c += NW) // wave-uniform
+        {
+            if (c < CCH)
+            {
+                int col = n0 + c * 64 + lane;
+                col = col < N ? col : N - 1;
+                glds4s(scb, p.per_channel ? (uint32_t) col * 4u : 0u, lds_base + SC_OFF + c * 256);
+            }
+            else
+            {
+                int row = m0 + (c - CCH) * 64 + lane;
+                row = row < M ? row : M - 1;
+                glds4s(srb, p.per_token ? (uint32_t) row * 4u : 0u, lds_base + SC_OFF + BN * 4 + (c - CCH) * 256);
+            }
+        }
+    }
+    // ---- prologue: tiles 0 and 1 requested, X0(0) / W0(0) fragments in registers, X0(2) requested
+    dma(0, 0), dma(1, 0), dma(2, 0), dma(3, 0);
+    if (ntile > 1)
+    {
+        dma(0, 1), dma(1, 1), dma(2, 1), dma(3, 1);
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CYC) : "memory");
+    }
+    else
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    read_x(fa[0], lds + OFF_X0);
+    read_w(fb0[0], lds + OFF_W0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (ntile > 2)
+        dma(0, 2);
+
+    // one phase: the MFMAs of C quadrant (I, J); the NR fragment reads of the NEXT phase are spread evenly between them (all
+    // 8 waves reading in one burst behind the barrier fills the LDS queue and the in-order waves stall in front of their
+    // MFMAs: measured 1.17 us per K-tile without any DMA, against 0.64 of MFMA time), and the DMA of one unit sits after
+    // MFMA number `dma_pos`.  Every step is pinned: the destination registers are not used before the next phase, so the
+    // pinning costs no wait.
+    auto phase = [&](i32x4 (&c)[MTH][NTH], const i32x4 (&a)[MTH][2], const i32x4 (&b)[NTH][2], auto& rdst, auto rtiles,
+                     const char* runit, const int (&roff)[2], bool do_read, int dma_pos, int kind, int t_dma, bool do_dma) {
+        constexpr int RT = decltype(rtiles)::value, NR = RT * 2;
+        if (PRIO)
+            __builtin_amdgcn_s_setprio(1);
+        int q = 0, r = 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int m = 0; m < MTH; ++m)
+#pragma unroll
+                for (int n = 0; n < NTH; ++n)
+                {
+                    if (q == dma_pos)
+                    {
+                        if (PRIO)
+                            __builtin_amdgcn_s_setprio(0);
+                        if (do_dma && !(ABL & 1))
+                            dma(kind, t_dma);
+                        if (PRIO)
+                            __builtin_amdgcn_s_setprio(1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if constexpr (ABL & 2)
+                    {
+                        asm volatile("" ::"v"(b[n][ks]), "v"(a[m][ks]));
+                    }
+                    else
+                        c[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b[n][ks], a[m][ks], c[m][n], 0, 0, 0);
+                    if (r < NR && q == (RSP ? r * RSP : (r * QM) / NR))
+                    {
+                        // k-step 0 of every MFMA tile first: the next phase starts with those
+                        if (do_read && !(ABL & 4))
+                            rdst[r % RT][r / RT] = *reinterpret_cast<const i32x4*>(runit + roff[r / RT] + (r % RT) * 2048);
+                        ++r;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    ++q;
+                }
+        if (dma_pos >= QM && do_dma && !(ABL & 1))
+            dma(kind, t_dma);
+        if (PRIO)
+            __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using TM = std::integral_constant<int, MTH>;
+    using TN = std::integral_constant<int, NTH>;
+
+    auto tile = [&](auto parity, auto group, int t) {
+        constexpr int b = decltype(parity)::value;
+        constexpr int DP = decltype(group)::value ? DMA_POS1 : DMA_POS0;
+        const char* buf = lds + b * BUF;
+        const char* nbuf = lds + (b ^ 1) * BUF;
+        constexpr int G = decltype(group)::value;
+        // this wave's chunks per unit: X-halves APW; W-half 0: the low waves carry the surplus, W-half 1: the high waves
+        constexpr int W0C = BCH % NW == 0 ? BCH / NW : (G == 0 ? BCH / NW + 1 : BCH / NW);
+        constexpr int W1C = BCH % NW == 0 ? BCH / NW : (G == 0 ? BCH / NW : BCH / NW + 1);
+        constexpr int V1 = 4 * APW + W0C + W1C, V2 = 3 * APW + 2 * W0C + W1C, V3 = 2 * APW + 2 * (W0C + W1C),
+                      V4 = 3 * APW + W0C + 2 * W1C;
+        const bool steady = t + 2 < ntile;
+        const bool more = t + 1 < ntile;
+        // P1: quadrant (0,0); W1(t) -> registers; W0(t+2) requested
+        SQP_TOP(steady, V1);
+        phase(acc[0][0], fa[0], fb0[b], fb1, TN{}, buf + OFF_W1, wrd, true, DP, 1, t + 2, steady);
+        // P2: quadrant (0,1); X1(t) -> registers; W1(t+2) requested
+        SQP_TOP(steady, V2);
+        phase(acc[0][1], fa[0], fb1, fa[1], TM{}, buf + OFF_X1, xr, true, DP, 2, t + 2, steady);
+        // P3: quadrant (1,1); X0(t+1) -> registers; X1(t+2) requested
+        SQP_TOP(steady, V3);
+        phase(acc[1][1], fa[1], fb1, fa[0], TM{}, nbuf + OFF_X0, xr, more, DP, 3, t + 2, steady);
+        // P4: quadrant (1,0); W0(t+1) -> the other register set; X0(t+3) requested
+        SQP_TOP(steady, V4);
+        phase(acc[1][0], fa[1], fb0[b], fb0[b ^ 1], TN{}, nbuf + OFF_W0, wrd, more, DP, 0, t + 3, t + 3 < ntile);
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    if (grp == 0)
+    {
+        for (int t = 0; t < ntile; t += 2)
+        {
+            tile(P0{}, P0{}, t);
+            if (t + 1 < ntile)
+                tile(P1{}, P0{}, t + 1);
+        }
+    }
+    else
+    {
+        for (int t = 0; t < ntile; t += 2)
+        {
+            tile(P0{}, P1{}, t);
+            if (t + 1 < ntile)
+                tile(P1{}, P1{}, t + 1);
+        }
+    }
+#undef SQP_TOP
+
+    // ---- epilogue.  acc[i][j][m][n][r]: row i*AH + (wr*MTH + m)*16 + (lane & 15),
+    //                                    col j*BH + (wc*NTH + n)*16 + 4*(lane >> 4) + r      (inside the tile)
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // scales landed (ntile == 1 aside, they have long ago)
+    const float* sc_l = reinterpret_cast<const float*>(lds + SC_OFF);
+    const float* sr_l = sc_l + BN;
+    const bool vec16 = p.out_dtype == DT_HALF && !(p.ldc & 7) && !(N & 7) && !(reinterpret_cast<uintptr_t>(p.c) & 15)
+        && !(reinterpret_cast<uintptr_t>(p.residual) & 15);
+    if (ABL & 8)
+    {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int m = 0; m < MTH; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTH; ++n)
+                        asm volatile("" ::"v"(acc[i][j][m][n]));
+        return;
+    }
+    if (vec16)
+    {
+        // fp16 tile through LDS ([BM][BN] halfs, pitch + 16 bytes: the 16 rows of a ds_write_b64 lane group land on 16
+        // different bank pairs), then 16-byte stores of whole rows: 3 (BN = 192) full 128-byte lines per row
+        constexpr int PITCH = BN * 2 + 16;
+        static_assert(BM * PITCH <= 2 * BUF, "the fp16 tile must fit the operand buffers");
+        char* ot = lds;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int n = 0; n < NTH; ++n)
+            {
+                const int cl = j * BH + (wc * NTH + n) * 16 + 4 * (lane >> 4);
+                const float4 sc = *reinterpret_cast<const float4*>(sc_l + cl);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int m = 0; m < MTH; ++m)
+                    {
+                        const int rl = i * AH + (wr * MTH + m) * 16 + (lane & 15);
+                        const float sr = sr_l[rl];
+                        const i32x4 a = acc[i][j][m][n];
+                        const uint32_t lo = (uint32_t) f2h((float) a[0] * (sc.x * sr)) | ((uint32_t) f2h((float) a[1] * (sc.y * sr)) << 16);
+                        const uint32_t hi = (uint32_t) f2h((float) a[2] * (sc.z * sr)) | ((uint32_t) f2h((float) a[3] * (sc.w * sr)) << 16);
+                        *reinterpret_cast<uint2*>(ot + rl * PITCH + cl * 2) = make_uint2(lo, hi);
+                    }
+            }
+        __syncthreads();
+        constexpr int PPR = BN / 8; // 16-byte pieces per row
+#pragma unroll 4
+        for (int k = tid; k < BM * PPR; k += NW * 64)
+        {
+            const int rl = k / PPR, pc = k % PPR;
+            const int grow = m0 + rl, gcol = n0 + pc * 8;
+            if (grow < M && gcol < N)
+            {
+                uint4 v = *reinterpret_cast<const uint4*>(ot + rl * PITCH + pc * 16);
+                const int64_t o = (int64_t) grow * p.ldc + gcol;
+                if (p.residual)
+                {
+                    const uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.residual) + o);
+                    const uint32_t a4[4] = {v.x, v.y, v.z, v.w}, b4[4] = {rv.x, rv.y, rv.z, rv.w};
+                    uint32_t o4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o4[e] = (uint32_t) f2h(h2f((uint16_t) (a4[e] & 0xffffu)) + h2f((uint16_t) (b4[e] & 0xffffu)))
+                            | ((uint32_t) f2h(h2f((uint16_t) (a4[e] >> 16)) + h2f((uint16_t) (b4[e] >> 16))) << 16);
+                    v = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+                }
+                if (ABL & 16)
+                {
+                    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(u4{v.x, v.y, v.z, v.w}, reinterpret_cast<u4*>(reinterpret_cast<uint16_t*>(p.c) + o));
+                }
+                else
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.c) + o) = v;
+            }
+        }
+        return;
+    }
+    // every other output form (int32 / fp32, unaligned or ragged fp16): element stores straight from the accumulators
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int n = 0; n < NTH; ++n)
+        {
+            const int cl = j * BH + (wc * NTH + n) * 16 + 4 * (lane >> 4);
+            const int col = n0 + cl;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int m = 0; m < MTH; ++m)
+                {
+                    const int rl = i * AH + (wr * MTH + m) * 16 + (lane & 15);
+                    const int row = m0 + rl;
+                    if (row >= M)
+                        continue;
+                    const float sr = sr_l[rl];
+                    const i32x4 a = acc[i][j][m][n];
+                    const int64_t o = (int64_t) row * p.ldc + col;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                    {
+                        if (col + r >= N)
+                            continue;
+                        if (p.out_dtype == DT_INT32)
+                            reinterpret_cast<int32_t*>(p.c)[o + r] = a[r];
+                        else
+                        {
+                            const float v = (float) a[r] * (sc_l[cl + r] * sr);
+                            if (p.out_dtype == DT_FLOAT)
+                                reinterpret_cast<float*>(p.c)[o + r] = v;
+                            else
+                            {
+                                uint16_t h = f2h(v);
+                                if (p.residual)
+                                    h = f2h(h2f(h) + h2f(reinterpret_cast<const uint16_t*>(p.residual)[o + r]));
+                                reinterpret_cast<uint16_t*>(p.c)[o + r] = h;
+                            }
+                        }
+                    }
+                }
+        }
+}
+
+template <int WR, int WC, int MTH, int NTH, int DP0, int DP1, bool PRIO, int ABL = 0, int RSP = 0>
+int launch_sqp(const GemmParams& p, hipStream_t stream)
+{
+    constexpr int BM = 2 * WR * MTH * 16, BN = 2 * WC * NTH * 16;
+    constexpr size_t smem = (size_t) 2 * (BM + BN) * 128 + (BM + BN) * 4; // operand buffers + the tile's scales
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP>;
+    static bool attr_done = false;
+    if (!attr_done)
+    {
+        if (smem > 64 * 1024)
+            (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        attr_done = true;
+    }
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(64 * WR * WC), smem, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+        set_error("gemm_sqp launch failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
+}
+
+} // namespace
+
+// Shape ids (tllm_gemm_set_tile_cfg 13..): returns 1 when this kernel does not serve the problem
+int launch_gemm_sqp(const GemmParams& p, int cfg, hipStream_t stream)
+{
+    if (p.wtype != W_INT8_SQ)
+        return 1;
+    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (p.lda & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) || (p.ldw & 15)
+        || (p.K % 128) || p.K <= 0 || p.M < 32)
+        return 1;
+    if ((int64_t) p.M * p.lda >= (1ll << 31) || (int64_t) p.N * p.ldw >= (1ll << 31))
+        return 1; // 32-bit DMA offsets
+    if (p.residual && p.out_dtype != DT_HALF)
+        return 1;
+    switch (cfg)
+    {
+    //                              waves  tiles/half  DMA after MFMA # (low / high waves)  setprio
+    case 13: return launch_sqp<4, 2, 2, 3, 2, 8, true>(p, stream);  // 256 x 192
+    case 15: return launch_sqp<2, 2, 2, 2, 1, 5, true>(p, stream);  // 128 x 128, 4 waves, 2 workgroups per CU
+    case 16: return launch_sqp<4, 2, 2, 3, 0, 12, false>(p, stream); // 256 x 192, DMA at the head (low waves) / tail (high waves)
+    case 17: return launch_sqp<4, 2, 2, 3, 2, 8, false>(p, stream); // 256 x 192 without setprio
+    case 19: return launch_sqp<4, 2, 2, 3, 0, 6, false>(p, stream);
+    case 20: return launch_sqp<4, 2, 2, 3, 0, 6, false, 16>(p, stream); // non-temporal output stores
+    // fragment reads packed behind the first MFMAs of the phase (one per MFMA), DMA late - no own read outstanding at its issue
+    case 28: return launch_sqp<4, 2, 2, 3, 9, 12, false, 0, 1>(p, stream);
+    case 29: return launch_sqp<4, 2, 2, 3, 12, 12, false, 0, 1>(p, stream);
+    case 30: return launch_sqp<4, 2, 2, 3, 10, 10, false, 0, 1>(p, stream);
+    case 18: return launch_sqp<4, 2, 1, 2, 1, 3, true>(p, stream);  // 128 x 128 on 8 waves
+    // ablations of the 256 x 192 shape (wrong results on purpose; microbench only)
+    case 21: return launch_sqp<4, 2, 2, 3, 2, 8, false, 1>(p, stream); // no DMA in the loop
+    case 22: return launch_sqp<4, 2, 2, 3, 2, 8, false, 2>(p, stream); // no MFMA
+    case 23: return launch_sqp<4, 2, 2, 3, 2, 8, false, 4>(p, stream); // no fragment reads
+    case 24: return launch_sqp<4, 2, 2, 3, 2, 8, false, 3>(p, stream); // barriers + reads only
+    case 25: return launch_sqp<4, 2, 2, 3, 2, 8, false, 6>(p, stream); // DMA + barriers only
+    case 26: return launch_sqp<4, 2, 2, 3, 2, 8, false, 8>(p, stream); // no epilogue
+    case 27: return launch_sqp<4, 2, 2, 3, 2, 8, false, 5>(p, stream); // MFMA + barriers only
+    default: return 1;
+    }
+}
+
+} // namespace kernels
+} // namespace tllm
