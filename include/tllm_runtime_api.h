@@ -126,6 +126,12 @@ void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer);
 int32_t tllm_session_get_step_state(tllm_session_t s, int32_t* sequence_length, int32_t* next_position, int32_t* masked_tokens,
     int32_t* input_lengths, tllm_stream_t stream);
 
+/* Teacher forcing for parity tests (greedy sessions): replace the token the last context / generation step chose by ids[b]
+ * (host, [B]) - in the output buffer, as the next step's input id and as its input embedding row - so that two
+ * implementations can be compared step by step on the SAME prefix (the reference's tests feed HF's tokens the same way,
+ * T/tests/model/test_llama.py:300-354).  Does not touch the KV cache or the step counters. */
+int32_t tllm_session_force_tokens(tllm_session_t s, const int32_t* ids, tllm_stream_t stream);
+
 /* Parity-test tap (sessions created with debug_taps=1 only): the input of layer `layer`'s O-projection GEMM as the last
  * generation step computed it - the attention context after the split-KV merge, [B, H/tp * Dh] fp16, or int8 when the
  * O-projection's prologue quantises it (SmoothQuant: sat(rni(ctx * attention.quantization_scaling_factor)), or the

@@ -54,7 +54,11 @@ def shard_sq(et, tp, rank, num_layers):
     return {k: np.ascontiguousarray(v) for k, v in out.items()}
 
 
-def run_session(et, cfg, qm, tp, rank, ids):
+def run_session(et, cfg, qm, tp, rank, ids, feed=None):
+    """context + NEW - 1 generation steps (step 1 eager, the rest replayed from the step graph).  `feed` [B, NEW - 1]: teacher
+    forcing - the tokens another run chose, fed back after every step, so that both runs score the SAME prefix (on these
+    random weights the top-1 / top-2 margin is below the int8 noise: a free-running comparison diverges at the first flip
+    and then compares unrelated sequences)."""
     from tensorrt_llm.runtime.native import NativeSession
     s = NativeSession(dict(cfg, quant_mode=qm, tp_size=tp, tp_rank=rank))
     for k, v in shard_sq(et, tp, rank, cfg['num_layers']).items():
@@ -62,14 +66,15 @@ def run_session(et, cfg, qm, tp, rank, ids):
     s.finalize()
     s.setup(B, S, NEW)
     s.context(ids, LENS)
-    l0 = s.logits()
-    s.step(1, use_graph=False)
-    l1 = s.logits()
-    s.step(NEW - 2, use_graph=True)
-    l2 = s.logits()
+    logits = [s.logits()]
+    for i in range(NEW - 1):
+        if feed is not None:
+            s.force_tokens(feed[:, i])
+        s.step(1, use_graph=i > 0)
+        logits.append(s.logits())
     out = s.output_ids()
     s.close()
-    return l0, l1, l2, out
+    return np.stack(logits), out
 
 
 def _rank(rank, world, port, path, q):
@@ -132,8 +137,7 @@ def prepare(tmp_path_factory):
     np.save(os.path.join(path, 'ids.npy'), ids)
     json.dump(dict(cfg=cfg, quant_mode=qmodel['quant_mode']), open(os.path.join(path, 'meta.json'), 'w'))
     sys.path.insert(0, os.path.join(ROOT, 'trtllm-llama_amd'))
-    ref = run_session(qmodel['engine_tensors'], cfg, qmodel['quant_mode'], 1, 0, ids)
-    _prepared.update(path=path, ref=ref, cfg=cfg)
+    _prepared.update(path=path, cfg=cfg, et=qmodel['engine_tensors'], qm=qmodel['quant_mode'], ids=ids)
     return _prepared
 
 
@@ -148,29 +152,31 @@ def test_tp_sessions_at_7b_per_rank_extents_match_the_unsharded_session(world, t
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]
-    bad = [r for r in res if len(r) != 6]
+    bad = [r for r in res if len(r) != 4]
     assert not bad, bad
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     res = sorted(res, key=lambda r: r[0])
-    ref = prep['ref']
-    scale = max(np.abs(ref[0]).max(), 1.0)
-    for rank, l0, l1, l2, out, err in res:
+    for rank, logits, out, err in res:
         assert err == 0, f'rank {rank}: a peer-to-peer wait timed out'
         # every rank holds the same gathered logits and so the same tokens
-        np.testing.assert_array_equal(l2, res[0][3])
-        np.testing.assert_array_equal(out, res[0][4])
-    _, l0, l1, l2, out, _ = res[0]
-    assert l0.shape == ref[0].shape == (B, 32000)
+        np.testing.assert_array_equal(logits, res[0][1])
+        np.testing.assert_array_equal(out, res[0][2])
+    _, logits, out, _ = res[0]
+    # the un-sharded session on the same tensors, fed the tokens the sharded run generated
+    ref, ref_out = run_session(prep['et'], prep['cfg'], prep['qm'], 1, 0, prep['ids'], feed=out[:, S:S + NEW - 1])
+    assert logits.shape == ref.shape == (NEW, B, 32000)
+    scale = max(np.abs(ref[0]).max(), 1.0)
     # a row-parallel int8 GEMM split over `world` ranks rounds `world` fp16 partial products instead of one: the logits move
     # by a few fp16 ulps of the hidden state, amplified through the static quantisers (+-1 LSB flips) - same bound as the
-    # kernel-vs-oracle comparison of the SmoothQuant model
-    for name, got, want in (('context', l0, ref[0]), ('step 1', l1, ref[1]), (f'step {NEW - 1}', l2, ref[2])):
-        d = np.abs(got - want)
-        print(f'tp={world} {name}: max |d| {d.max():.4g} mean |d| {d.mean():.4g} (scale {scale:.4g})')
-        assert d.max() < 8e-2 * scale and d.mean() < 1.2e-2 * scale, name
-    np.testing.assert_array_equal(out[:, :S], ref[3][:, :S])
-    agree = np.mean(out[:, S:] == ref[3][:, S:])
-    print(f'tp={world}: greedy tokens identical to the un-sharded run: {agree * 100:.0f} %')
-    assert agree >= 0.75, (out[:, S:], ref[3][:, S:])
+    # kernel-vs-oracle comparison of the SmoothQuant model, at EVERY step
+    agree = 0
+    for i in range(NEW):
+        d = np.abs(logits[i] - ref[i])
+        print(f'tp={world} step {i}: max |d| {d.max():.4g} mean |d| {d.mean():.4g} (scale {scale:.4g})')
+        assert d.max() < 8e-2 * scale and d.mean() < 1.2e-2 * scale, i
+        agree += int((logits[i].argmax(-1) == ref[i].argmax(-1)).sum())
+    np.testing.assert_array_equal(out[:, :S], ref_out[:, :S])
+    print(f'tp={world}: arg-max of the sharded and the un-sharded logits on the same prefix agree on {agree} of {NEW * B} rows')
+    assert agree >= 0.75 * NEW * B

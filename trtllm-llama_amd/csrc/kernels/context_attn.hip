@@ -13,6 +13,7 @@
 // exp underflows to the same 0).
 #include "dev_utils.h"
 #include "kernels.h"
+#include <atomic>
 
 namespace tllm
 {
@@ -536,7 +537,7 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
             hipLaunchKernelGGL((v_transpose_kernel<DH>), dim3(spad / 64, p.num_heads, p.batch), dim3(256), 0, stream, p, spad);
             constexpr size_t smem = 2 * (size_t) (64 * DH * 2 + DH * 128);
             auto kfn = context_attn_mfma_kernel<DH>;
-            static bool attr_done = false;
+            static std::atomic<bool> attr_done{false};
             if (!attr_done)
             {
                 if (smem > 64 * 1024)

@@ -19,6 +19,7 @@
 // (float(acc) * (s_col * s_row)), transposed through LDS so that every lane stores 16 contiguous bytes of a C row.
 #include "dev_utils.h"
 #include "kernels.h"
+#include <atomic>
 #include <map>
 
 namespace tllm
@@ -399,7 +400,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream)
     static_assert(smem <= 160 * 1024, "LDS budget");
     static_assert(smem >= (size_t) WM * WN * KG * 32 * (NT * 64 + 16), "epilogue scratch must fit the operand stages");
     auto kfn = gemm_glds_kernel<WT, WM, WN, MT, NT, KG, BKB, S>;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false}; // idempotent; atomic so concurrent first launches do not race
     if (!attr_done)
     {
         if (smem > 64 * 1024)
@@ -476,13 +477,15 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
     if (cfg <= 0 || cfg > kNumCfg)
     {
         // fewest workgroup rounds over 256 CUs, then the largest tile (fewest operand re-reads through L2)
-        static int cus = 0;
+        static std::atomic<int> cus_cache{0};
+        int cus = cus_cache.load();
         if (!cus)
         {
             int dev = 0;
             (void) hipGetDevice(&dev);
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
                 cus = 256;
+            cus_cache.store(cus);
         }
         double best = 1e30;
         for (const Shape& s : kShapes)

@@ -23,6 +23,7 @@
 // so the same involution is applied to each lane's global SOURCE piece.
 #include "dev_utils.h"
 #include "kernels.h"
+#include <atomic>
 
 namespace tllm
 {
@@ -467,7 +468,7 @@ int launch_sqp(const GemmParams& p, hipStream_t stream)
     constexpr size_t smem = (size_t) 2 * (BM + BN) * 128 + (BM + BN) * 4; // operand buffers + the tile's scales
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP>;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};
     if (!attr_done)
     {
         if (smem > 64 * 1024)

@@ -24,6 +24,7 @@
 #include "gemv_args.h"
 #include <algorithm>
 #include <map>
+#include <mutex>
 
 // Included by one translation unit per weight type (gemv_fp16.hip, gemv_woq8.hip, gemv_woq4.hip, gemv_sq.hip) so that
 // the ~170 kernel instantiations compile in parallel; everything here has internal linkage.
@@ -720,35 +721,43 @@ int launch_inst(const GemvArgs& a, hipStream_t stream)
         set_error("gemv: K=%d x M=%d does not fit LDS", a.p.K, a.p.M);
         return -1;
     }
+    // per-instantiation launch state (LDS attribute, CU count, occupancy per LDS size): plugins may be enqueued from several
+    // host threads (one per rank is the rule, but nothing forbids more), so the lazily filled cache sits behind a mutex
+    static std::mutex launch_mu;
     static bool attr_done = false;
-    if (smem > 64 * 1024 && !attr_done)
-    {
-        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    // persistent grid: no more workgroups than the chip holds at once, every wave the same number of row groups
     static int cus = 0;
     static std::map<size_t, int> occ_cache;
-    if (!cus)
+    int fit_blocks = 2;
     {
-        int dev = 0;
-        (void) hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
-    auto it = occ_cache.find(smem);
-    if (it == occ_cache.end())
-    {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 256, smem) != hipSuccess || nb < 1)
-            nb = 2;
-        it = occ_cache.emplace(smem, nb > 8 ? 8 : nb).first;
+        std::lock_guard<std::mutex> lock(launch_mu);
+        if (smem > 64 * 1024 && !attr_done)
+        {
+            (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_done = true;
+        }
+        // persistent grid: no more workgroups than the chip holds at once, every wave the same number of row groups
+        if (!cus)
+        {
+            int dev = 0;
+            (void) hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
+        }
+        auto it = occ_cache.find(smem);
+        if (it == occ_cache.end())
+        {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 256, smem) != hipSuccess || nb < 1)
+                nb = 2;
+            it = occ_cache.emplace(smem, nb > 8 ? 8 : nb).first;
+        }
+        fit_blocks = it->second;
     }
     int blocks = (a.ngroups + 3) / 4;
     // persistent workgroups per CU: what fits (occupancy query) for the SwiGLU kernel (gate|up: 16.4 us with 4 per CU, 17.6 with
     // 2); two for the plain projections (QKV: 9.9 us with 2, 10.4 with 3 - 4: fewer, longer-lived waves amortise the RMSNorm
     // prologue over three row groups instead of two)
-    const int fit = it->second;
+    const int fit = fit_blocks;
     const int want = EK == EK_SWIGLU ? fit : (fit < 2 ? fit : 2);
     const int max_blocks = cus * (gemv_tune_blocks_per_cu > 0 ? gemv_tune_blocks_per_cu : want);
     if (blocks > max_blocks)

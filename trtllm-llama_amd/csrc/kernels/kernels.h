@@ -296,6 +296,9 @@ struct GreedyParams
     int32_t hidden = 0;
 };
 int launch_greedy_step(const GreedyParams& p, hipStream_t stream);
+// teacher forcing for parity tests: overwrite the sampler's last choice (output slot seq_len[b], step input id, next input row)
+int launch_force_token(const int32_t* ids_dev, int32_t* cur_ids, int32_t* out_ids, int32_t out_stride, const int32_t* seq_len,
+    const void* emb, void* x, int32_t batch, int32_t hidden, int32_t vocab, hipStream_t stream);
 
 // One beam-search step on the device (K/onlineSoftmaxBeamsearchKernels.cu, layers/onlineBeamSearchLayer.cu; called at
 // PY/runtime/generation.py:949-961 with beam_width > 1).  Per batch entry, over its `beam` hypotheses:

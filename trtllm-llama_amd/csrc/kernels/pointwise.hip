@@ -3,6 +3,7 @@
 // All HBM/latency-bound: 16-byte accesses, one workgroup per row, wave64 shuffles for reductions.
 #include "dev_utils.h"
 #include "kernels.h"
+#include <atomic>
 
 namespace tllm
 {
@@ -905,6 +906,39 @@ int launch_greedy_step(const GreedyParams& p, hipStream_t stream)
     return check_launch("greedy_step");
 }
 
+// Teacher forcing (parity tests): replace the token the sampler just chose by ids[b] - the output slot it wrote, the
+// step's input id and the embedding row the next step consumes.  One workgroup per sequence.
+__global__ __launch_bounds__(256) void force_token_kernel(const int32_t* ids, int32_t* cur_ids, int32_t* out_ids, int32_t out_stride,
+    const int32_t* seq_len, const void* emb, void* x, int32_t hidden, int32_t vocab)
+{
+    const int b = blockIdx.x, id = ids[b];
+    if (threadIdx.x == 0)
+    {
+        const int sl = seq_len[b];
+        if (sl < out_stride)
+            out_ids[(int64_t) b * out_stride + sl] = id;
+        cur_ids[b] = id;
+    }
+    if (emb && x)
+    {
+        const bool ok = id >= 0 && id < vocab;
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(emb) + (int64_t) (ok ? id : 0) * hidden;
+        uint16_t* dst = reinterpret_cast<uint16_t*>(x) + (int64_t) b * hidden;
+        for (int k = threadIdx.x; k < hidden; k += blockDim.x)
+            dst[k] = ok ? src[k] : (uint16_t) 0;
+    }
+}
+
+int launch_force_token(const int32_t* ids_dev, int32_t* cur_ids, int32_t* out_ids, int32_t out_stride, const int32_t* seq_len,
+    const void* emb, void* x, int32_t batch, int32_t hidden, int32_t vocab, hipStream_t stream)
+{
+    if (batch <= 0)
+        return 0;
+    hipLaunchKernelGGL(force_token_kernel, dim3(batch), dim3(256), 0, stream, ids_dev, cur_ids, out_ids, out_stride, seq_len, emb, x,
+        hidden, vocab);
+    return check_launch("force_token");
+}
+
 int launch_beam_step(const BeamParams& p, hipStream_t stream)
 {
     if (p.batch <= 0)
@@ -920,7 +954,7 @@ int launch_beam_step(const BeamParams& p, hipStream_t stream)
         set_error("beam step: beam %d x %d slots does not fit the staging buffer", p.beam, p.out_stride);
         return -1;
     }
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};
     if (!attr_done)
     {
         (void) hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

@@ -27,6 +27,7 @@ int attach(const void* handles);
 void enable(bool on);
 bool attached();
 bool usable(int world, int64_t bytes);
+int64_t slot_capacity(int world); // bytes one exchange can carry when the path is enabled for this world size, else 0
 int all_reduce_f16(void* buf, int64_t count, hipStream_t stream);
 int all_gather(const void* in, void* out, int64_t bytes_per_rank, hipStream_t stream);
 int error_flag(uint32_t* out);

@@ -119,6 +119,11 @@ bool usable(int world, int64_t bytes)
     return g.enabled && g.world == world && bytes > 0 && (size_t) bytes <= g.slot_bytes && bytes % 16 == 0;
 }
 
+int64_t slot_capacity(int world)
+{
+    return (g.enabled && g.world == world) ? (int64_t) g.slot_bytes : 0;
+}
+
 bool attached()
 {
     return g.attached;

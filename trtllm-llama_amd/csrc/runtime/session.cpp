@@ -459,6 +459,16 @@ struct tllm_session
             return 0;
         if (comm::p2p::usable(tp, n * 2))
             return timed(PC_COMM, st, [&] { return comm::p2p::all_reduce_f16(buf, n, st) ? 1 : 0; });
+        // a vector longer than one inbox slot (the prefill's [tokens, D] partial sums) goes through the peer-to-peer path in
+        // slot-sized pieces - the same kernel, one epoch per piece - instead of silently needing a second transport
+        const int64_t cap = comm::p2p::slot_capacity(tp) / 2 / 8 * 8; // fp16 elements per exchange, whole 16-byte vectors
+        if (cap > 0 && n % 8 == 0)
+            return timed(PC_COMM, st, [&] {
+                for (int64_t off = 0; off < n; off += cap)
+                    if (comm::p2p::all_reduce_f16(static_cast<char*>(buf) + off * 2, n - off < cap ? n - off : cap, st))
+                        return 1;
+                return 0;
+            });
         return timed(PC_COMM, st, [&] { return comm::all_reduce_sum(group, buf, buf, n, TLLM_HALF, st) ? 1 : 0; });
     }
 
@@ -1630,6 +1640,30 @@ int32_t tllm_session_get_step_state(tllm_session_t s, int32_t* sequence_length, 
         HIP_OK(hipMemcpyAsync(masked_tokens, s->masked, (size_t) s->B * s->Smax * 4, hipMemcpyDeviceToHost, st));
     if (input_lengths)
         HIP_OK(hipMemcpyAsync(input_lengths, s->in_len, (size_t) s->B * 4, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    return 0;
+}
+
+int32_t tllm_session_force_tokens(tllm_session_t s, const int32_t* ids, tllm_stream_t stream)
+{
+    if (!s || !s->B || !ids)
+    {
+        set_error("tllm_session_force_tokens: bad arguments / setup not called");
+        return 1;
+    }
+    if (s->beam > 1)
+    {
+        set_error("tllm_session_force_tokens: greedy sessions only");
+        return 1;
+    }
+    hipStream_t st = s->pick(stream);
+    // staged through the (idle between steps) prompt-id buffer; the greedy sampler leaves the next input row in x only when
+    // hidden % 8 == 0, otherwise the step gathers it from cur_ids itself
+    HIP_OK(hipMemcpyAsync(s->ids_in, ids, (size_t) s->B * 4, hipMemcpyHostToDevice, st));
+    const bool gather = s->hidden % 8 == 0;
+    if (tllm::kernels::launch_force_token(s->ids_in, s->cur_ids, s->out_ids, s->Smax, s->seq_len, gather ? s->emb : nullptr,
+            gather ? s->x : nullptr, s->B, s->hidden, s->vocab, st))
+        return 1;
     HIP_OK(hipStreamSynchronize(st));
     return 0;
 }

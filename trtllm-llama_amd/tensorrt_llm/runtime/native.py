@@ -60,6 +60,8 @@ def _lib():
     lib.tllm_session_get_step_state.restype = c.c_int32
     lib.tllm_session_get_tap.argtypes = [c.c_void_p, c.c_int32, c.c_void_p, c.c_size_t, c.c_void_p]
     lib.tllm_session_get_tap.restype = c.c_int32
+    lib.tllm_session_force_tokens.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p]
+    lib.tllm_session_force_tokens.restype = c.c_int32
     lib.tllm_session_step_bytes.argtypes = [c.c_void_p, c.c_int32]
     lib.tllm_session_step_bytes.restype = c.c_int64
     lib.tllm_session_profile.argtypes = [c.c_void_p, c.c_int32, c.POINTER(c.c_float), c.POINTER(c.c_int64), c.c_void_p]
@@ -207,6 +209,12 @@ class NativeSession:
                                                   d['masked_tokens'].ctypes.data, d['input_lengths'].ctypes.data, stream),
                'get_step_state')
         return d
+
+    def force_tokens(self, ids, stream: int = 0):
+        """teacher forcing: overwrite the token the last step chose (parity tests compare on identical prefixes)"""
+        ids = self._i32(ids)
+        assert ids.shape == (self.batch, )
+        _check(_lib().tllm_session_force_tokens(self._h, ids.ctypes.data, stream), 'force_tokens')
 
     def attention_tap(self, layer: int, heads_x_dh: int, quantised: bool, stream: int = 0) -> np.ndarray:
         """O-projection input of the last generation step (debug_taps=1): [batch * beam, H/tp * Dh] fp16, int8 for SmoothQuant."""
