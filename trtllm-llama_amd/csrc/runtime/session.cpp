@@ -461,8 +461,10 @@ struct tllm_session
             return timed(PC_COMM, st, [&] { return comm::p2p::all_reduce_f16(buf, n, st) ? 1 : 0; });
         // a vector longer than one inbox slot (the prefill's [tokens, D] partial sums) goes through the peer-to-peer path in
         // slot-sized pieces - the same kernel, one epoch per piece - instead of silently needing a second transport
+        // (only when no RCCL communicator exists for the group: the one-workgroup exchange kernel is built for the decode
+        // step's 8 KB vectors, a ring is the better transport for the prefill's megabytes)
         const int64_t cap = comm::p2p::slot_capacity(tp) / 2 / 8 * 8; // fp16 elements per exchange, whole 16-byte vectors
-        if (cap > 0 && n % 8 == 0)
+        if (cap > 0 && n % 8 == 0 && !comm::has_comm(group))
             return timed(PC_COMM, st, [&] {
                 for (int64_t off = 0; off < n; off += cap)
                     if (comm::p2p::all_reduce_f16(static_cast<char*>(buf) + off * 2, n - off < cap ? n - off : cap, st))
