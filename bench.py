@@ -241,6 +241,27 @@ def sq_gemm_mfma_report(torch, dev, M=1024):
         us, us_med = min(reps), sorted(reps)[len(reps) // 2]
         tops = 2.0 * M * N * K / us / 1e6
         out[name] = {'M': M, 'N': N, 'K': K, 'us': us, 'us_median': us_med, 'TOP/s': tops, 'frac_of_5POPs': tops / 5000.0}
+        # the clock the chip held under this kernel (it clocks to its power budget: dense random-operand int8 MFMA work next to
+        # the LDS / L2 traffic that feeds it runs well below 2.4 GHz): every workgroup reports its shader cycles against the
+        # constant 100 MHz counter (tllm_gemm_set_clock_probe); 5 POP/s is the nominal peak AT 2.4 GHz
+        try:
+            probe = torch.zeros(8192, dtype=torch.int64, device=dev)
+            lib.tllm_gemm_set_clock_probe.argtypes = [ctypes.c_void_p]
+            lib.tllm_gemm_set_clock_probe.restype = None
+            lib.tllm_gemm_set_clock_probe(ctypes.c_void_p(probe.data_ptr()))
+            for _ in range(8):
+                lib.tllm_gemm(ctypes.byref(q), stream)
+            torch.cuda.synchronize()
+            lib.tllm_gemm_set_clock_probe(None)
+            d = probe.view(-1, 2)[:128].double()
+            ok = d[:, 1] > 0
+            if bool(ok.any()):
+                mhz = float((d[ok, 0] / d[ok, 1]).median().item() * 100.0)
+                out[name]['shader_MHz_held'] = mhz
+                out[name]['frac_of_peak_at_held_clock'] = tops / (5000.0 * mhz / 2400.0)
+        except Exception as e:  # side report only
+            out[name]['shader_MHz_held'] = None
+            print(f'[bench] clock probe failed: {e!r}', file=sys.stderr)
     return out
 
 

@@ -214,6 +214,9 @@ typedef struct
 } tllm_gemm_params_t;
 
 int32_t tllm_gemm(const tllm_gemm_params_t* p, tllm_stream_t stream);
+/* Microbenchmark hook: while set (non-NULL), every workgroup of the phased SmoothQuant GEMM writes {shader cycles, ticks of
+ * the constant 100 MHz counter} over its lifetime to device_buffer[2 * workgroup] (uint64) - the clock the chip held. */
+void tllm_gemm_set_clock_probe(void* device_buffer);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,8 @@ class GemmParams(ctypes.Structure):
 
 lib.tllm_gemm.argtypes = [ctypes.POINTER(GemmParams), ctypes.c_void_p]
 lib.tllm_gemm.restype = ctypes.c_int32
+lib.tllm_gemm_set_clock_probe.argtypes = [ctypes.c_void_p]
+lib.tllm_gemm_set_clock_probe.restype = None
 stream = torch.cuda.current_stream().cuda_stream
 D, I = 4096, 11008
 shapes = {'qkv': (3 * D, D), 'o_proj': (D, D), 'gate_or_up': (I, D), 'down': (D, I)}
@@ -73,6 +75,16 @@ for name, (N, K) in shapes.items():
             e1.record()
             torch.cuda.synchronize()
             res[cfg][name]['us'].append(e0.elapsed_time(e1) * 1e3 / 20)
+            if os.environ.get('CLOCKS'):  # the shader clock the kernel held (s_memtime against the 100 MHz counter)
+                dbg = torch.zeros(4096, dtype=torch.int64, device=dev)
+                lib.tllm_gemm_set_clock_probe(ctypes.c_void_p(dbg.data_ptr()))
+                for _ in range(8):
+                    lib.tllm_gemm(ctypes.byref(q), stream)
+                torch.cuda.synchronize()
+                lib.tllm_gemm_set_clock_probe(None)
+                d = dbg.view(-1, 2)[:128].double()
+                mhz = (d[:, 0] / d[:, 1].clamp(min=1)).median().item() * 100.0
+                res[cfg][name].setdefault('mhz', []).append(mhz)
 lib.tllm_gemm_set_tile_cfg(0)
 for cfg in cfgs:
     line = f'cfg {cfg:2d}'
@@ -81,4 +93,6 @@ for cfg in cfgs:
         us, med = min(r['us']), sorted(r['us'])[2]
         tops = 2.0 * M * N * K / us / 1e6
         line += f' | {name} {us:6.1f} us (med {med:6.1f}) {tops:5.0f} TOP/s {tops / 5000:.3f}{"" if not r["bad"] or cfg >= 21 else " WRONG"}'
+        if r.get('mhz'):
+            line += f' @ {sorted(r["mhz"])[len(r["mhz"]) // 2]:.0f} MHz'
     print(line)

@@ -30,6 +30,7 @@ using namespace dev;
 
 int gemm_tune_cfg = 0; // test/bench override of the tile shape (0 = heuristic)
 int launch_gemm_sqp(const GemmParams& p, int cfg, hipStream_t stream); // gemm_sqp.hip: phased SmoothQuant kernel, ids 13..
+extern void* gemm_clock_probe;                                              // gemm_sqp.hip (microbench hook)
 
 namespace
 {
@@ -92,6 +93,9 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform, and the compiler knows it (LDS-DMA base)
+    // clock evidence for the microbench (tllm_gemm_set_clock_probe; the field is unused by SmoothQuant / fp16 otherwise)
+    void* const clk_probe = SQ ? p.scratch : nullptr;
+    const uint64_t clk0 = clk_probe ? __builtin_readcyclecounter() : 0, rt0 = clk_probe ? __builtin_amdgcn_s_memrealtime() : 0;
     const int kg = wid / (WM * WN), wq = wid % (WM * WN);
     const int wm = wq / WN, wn = wq % WN;
     // XCD-aware tile order: consecutive workgroup ids go to different XCDs (round-robin dispatch); give each XCD a
@@ -272,6 +276,12 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
         i_hi = i_lo + HALF;
     }
 
+    if (clk_probe && tid == 0)
+    {
+        uint64_t* dbg = reinterpret_cast<uint64_t*>(clk_probe) + 2 * blockIdx.x;
+        dbg[0] = __builtin_readcyclecounter() - clk0;
+        dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
     // ---- epilogue.  acc[i][j][r]: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const float* s_row = p.scale_row;
     const int wave_n0 = n0 + wn * NT * 32;
@@ -507,6 +517,12 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
         const int r = launch_gemm_sqp(p, 20, stream);
         if (r <= 0)
             return r;
+    }
+    if (sq && gemm_clock_probe)
+    {
+        GemmParams q = p;
+        q.scratch = gemm_clock_probe;
+        return launch_wt<W_INT8_SQ>(q, cfg, stream);
     }
     return sq ? launch_wt<W_INT8_SQ>(p, cfg, stream) : launch_wt<W_FP16>(p, cfg, stream);
 }

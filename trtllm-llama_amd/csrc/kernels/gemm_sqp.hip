@@ -74,6 +74,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // clock evidence (microbench only: GemmParams::scratch is unused by SmoothQuant): shader cycles (s_memtime) against the
+    // constant 100 MHz counter (s_memrealtime) over this workgroup's lifetime -> the clock the chip actually held
+    const uint64_t clk0 = p.scratch ? __builtin_readcyclecounter() : 0, rt0 = p.scratch ? __builtin_amdgcn_s_memrealtime() : 0;
     const int wr = wid / WC, wc = wid % WC;
     const int grp = wid >= NW / 2 ? 1 : 0; // the second-dispatched half: its DMA sits elsewhere in the phase
     const int nwg = gridDim.x;
@@ -190,7 +193,16 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
 #define SQP_TOP(counted, N)                                                                                            \
     do                                                                                                                 \
     {                                                                                                                  \
-        if (counted)                                                                                                   \
+        if (ABL & 32) /* ablation: no barrier (wrong results) */                                                       \
+        {                                                                                                              \
+            if (counted)                                                                                               \
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(N) : "memory");                       \
+            else                                                                                                       \
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        }                                                                                                              \
+        else if (ABL & 64) /* ablation: barrier, no DMA wait (wrong results) */                                        \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                            \
+        else if (counted)                                                                                              \
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");              \
         else                                                                                                           \
             asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                      \
@@ -290,10 +302,13 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
 
     auto tile = [&](auto parity, auto group, int t) {
         constexpr int b = decltype(parity)::value;
-        constexpr int DP = decltype(group)::value ? DMA_POS1 : DMA_POS0;
+        // DMA position inside the phase: per wave half, or - DMA_POS0 < 0 - per wave PAIR (four code paths), so that the waves'
+        // LDS-DMA instructions reach the CU's one address unit spread over the phase instead of in two bunches
+        constexpr int GQ = decltype(group)::value; // wave pair (wid / 2) when DMA_POS0 < 0, else wave half
+        constexpr int DP = DMA_POS0 < 0 ? (GQ * QM) / 4 + (GQ & 1) : (GQ ? DMA_POS1 : DMA_POS0);
         const char* buf = lds + b * BUF;
         const char* nbuf = lds + (b ^ 1) * BUF;
-        constexpr int G = decltype(group)::value;
+        constexpr int G = DMA_POS0 < 0 ? decltype(group)::value / 2 : decltype(group)::value;
         // this wave's chunks per unit: X-halves APW; W-half 0: the low waves carry the surplus, W-half 1: the high waves
         constexpr int W0C = BCH % NW == 0 ? BCH / NW : (G == 0 ? BCH / NW + 1 : BCH / NW);
         constexpr int W1C = BCH % NW == 0 ? BCH / NW : (G == 0 ? BCH / NW : BCH / NW + 1);
@@ -316,29 +331,40 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     };
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
-    if (grp == 0)
-    {
+    auto loop = [&](auto group) {
         for (int t = 0; t < ntile; t += 2)
         {
-            tile(P0{}, P0{}, t);
+            tile(P0{}, group, t);
             if (t + 1 < ntile)
-                tile(P1{}, P0{}, t + 1);
+                tile(P1{}, group, t + 1);
+        }
+    };
+    if constexpr (DMA_POS0 < 0)
+    {
+        static_assert(NW == 8, "per-pair DMA slots are laid out for 8 waves");
+        switch (wid >> 1) // wave-uniform
+        {
+        case 0: loop(std::integral_constant<int, 0>{}); break;
+        case 1: loop(std::integral_constant<int, 1>{}); break;
+        case 2: loop(std::integral_constant<int, 2>{}); break;
+        default: loop(std::integral_constant<int, 3>{}); break;
         }
     }
+    else if (grp == 0)
+        loop(P0{});
     else
-    {
-        for (int t = 0; t < ntile; t += 2)
-        {
-            tile(P0{}, P1{}, t);
-            if (t + 1 < ntile)
-                tile(P1{}, P1{}, t + 1);
-        }
-    }
+        loop(P1{});
 #undef SQP_TOP
 
     // ---- epilogue.  acc[i][j][m][n][r]: row i*AH + (wr*MTH + m)*16 + (lane & 15),
     //                                    col j*BH + (wc*NTH + n)*16 + 4*(lane >> 4) + r      (inside the tile)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // scales landed (ntile == 1 aside, they have long ago)
+    if (p.scratch && tid == 0)
+    {
+        uint64_t* dbg = reinterpret_cast<uint64_t*>(p.scratch) + 2 * blockIdx.x;
+        dbg[0] = __builtin_readcyclecounter() - clk0;
+        dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+    }
     const float* sc_l = reinterpret_cast<const float*>(lds + SC_OFF);
     const float* sr_l = sc_l + BN;
     const bool vec16 = p.out_dtype == DT_HALF && !(p.ldc & 7) && !(N & 7) && !(reinterpret_cast<uintptr_t>(p.c) & 15)
@@ -488,9 +514,14 @@ int launch_sqp(const GemmParams& p, hipStream_t stream)
 
 } // namespace
 
+// microbench hook (tllm_gemm_set_clock_probe): device buffer of 2 x uint64 per workgroup = {shader cycles, 100 MHz ticks}
+void* gemm_clock_probe = nullptr;
+
 // Shape ids (tllm_gemm_set_tile_cfg 13..): returns 1 when this kernel does not serve the problem
-int launch_gemm_sqp(const GemmParams& p, int cfg, hipStream_t stream)
+int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
 {
+    GemmParams p = pin;
+    p.scratch = gemm_clock_probe;
     if (p.wtype != W_INT8_SQ)
         return 1;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (p.lda & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) || (p.ldw & 15)
@@ -511,7 +542,7 @@ int launch_gemm_sqp(const GemmParams& p, int cfg, hipStream_t stream)
     case 20: return launch_sqp<4, 2, 2, 3, 0, 6, false, 16>(p, stream); // non-temporal output stores
     // fragment reads packed behind the first MFMAs of the phase (one per MFMA), DMA late - no own read outstanding at its issue
     case 28: return launch_sqp<4, 2, 2, 3, 9, 12, false, 0, 1>(p, stream);
-    case 29: return launch_sqp<4, 2, 2, 3, 12, 12, false, 0, 1>(p, stream);
+    case 29: return launch_sqp<4, 2, 2, 3, -1, 0, false, 16>(p, stream); // every wave its own DMA slot in the phase
     case 30: return launch_sqp<4, 2, 2, 3, 10, 10, false, 0, 1>(p, stream);
     case 18: return launch_sqp<4, 2, 1, 2, 1, 3, true>(p, stream);  // 128 x 128 on 8 waves
     // ablations of the 256 x 192 shape (wrong results on purpose; microbench only)
@@ -522,6 +553,9 @@ int launch_gemm_sqp(const GemmParams& p, int cfg, hipStream_t stream)
     case 25: return launch_sqp<4, 2, 2, 3, 2, 8, false, 6>(p, stream); // DMA + barriers only
     case 26: return launch_sqp<4, 2, 2, 3, 2, 8, false, 8>(p, stream); // no epilogue
     case 27: return launch_sqp<4, 2, 2, 3, 2, 8, false, 5>(p, stream); // MFMA + barriers only
+    case 31: return launch_sqp<4, 2, 2, 3, 0, 6, false, 32>(p, stream); // everything, without the barriers
+    case 32: return launch_sqp<4, 2, 2, 3, 0, 6, false, 64>(p, stream); // everything, without the DMA waits
+    case 33: return launch_sqp<4, 2, 2, 3, 0, 6, false, 32 + 5>(p, stream); // MFMA only, no barriers
     default: return 1;
     }
 }

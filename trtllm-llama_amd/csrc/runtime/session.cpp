@@ -40,6 +40,7 @@ namespace kernels
 {
 extern int gemv_tune_blocks_per_cu;
 extern int gemm_tune_cfg;
+extern void* gemm_clock_probe;
 }
 } // namespace tllm
 
@@ -1853,6 +1854,11 @@ int32_t tllm_gemm(const tllm_gemm_params_t* q, tllm_stream_t stream)
 void tllm_gemv_set_blocks_per_cu(int32_t n)
 {
     tllm::kernels::gemv_tune_blocks_per_cu = n;
+}
+
+void tllm_gemm_set_clock_probe(void* device_buffer)
+{
+    tllm::kernels::gemm_clock_probe = device_buffer;
 }
 
 void tllm_gemm_set_tile_cfg(int32_t cfg)
