@@ -33,10 +33,13 @@ def main():
         gui = r.get('GRBM_GUI_ACTIVE')
         if gui:
             gui = gui / XCDS
-            print(f"  -> achieved clock GRBM_GUI_ACTIVE / {XCDS} XCDs / duration = {gui / r['us'] / 1e3:.3f} GHz")
+            # not the shader clock: the in-kernel measurement (s_memtime against the 100 MHz counter, tools/gemm_sweep.py CLOCKS=1,
+            # profiles/r02_sqgemm_ablation.txt) reads 0.2 - 0.4 GHz lower under the same kernels
+            print(f"  -> GRBM_GUI_ACTIVE / {XCDS} XCDs / duration = {gui / r['us'] / 1e3:.3f} GHz (GRBM-domain cycles; the shader clock "
+                  f"held is measured in-kernel, see profiles/r02_sqgemm_ablation.txt)")
             busy = r.get('SQ_VALU_MFMA_BUSY_CYCLES')
             if busy:
-                print(f'  -> MFMA utilisation = MFMA_BUSY_CYCLES / (GUI_ACTIVE / {XCDS} x {SIMDS} SIMDs) = {busy / (gui * SIMDS):.3f}')
+                print(f'  -> MFMA busy = MFMA_BUSY_CYCLES / (GUI_ACTIVE / {XCDS} x {SIMDS} SIMDs) = {busy / (gui * SIMDS):.3f} of the GRBM cycles')
         mops = r.get('SQ_INSTS_VALU_MFMA_MOPS_I8')
         if mops:
             print(f'  -> int8 MFMA ops = MOPS_I8 x 512 = {mops * 512:.4g}')
