@@ -214,6 +214,12 @@ typedef struct
 } tllm_gemm_params_t;
 
 int32_t tllm_gemm(const tllm_gemm_params_t* p, tllm_stream_t stream);
+/* The SmoothQuant MLP's fc and gate projections in one launch (static activation scales): c = int8 [M, ldc] =
+ * sat(rni(fp16(silu16(fp16(A W^T s)) * fp16(A W_up^T s_up)) * quant_scale[0])) - the rounding points of GEMM + GEMM + SwiGLU +
+ * quantiser run separately (PY/layers/mlp.py:68-73 with K/quantization.cu's static quantiser), which it replaces in the
+ * prefill.  p->w / p->scale_col: the matrix that goes through SiLU; p->c: int8 output. */
+int32_t tllm_gemm_swiglu_quant(const tllm_gemm_params_t* p, const void* w_up, const void* scale_col_up, const float* quant_scale,
+    tllm_stream_t stream);
 /* Microbenchmark hook: while set (non-NULL), every workgroup of the phased SmoothQuant GEMM writes {shader cycles, ticks of
  * the constant 100 MHz counter} over its lifetime to device_buffer[2 * workgroup] (uint64) - the clock the chip held. */
 void tllm_gemm_set_clock_probe(void* device_buffer);

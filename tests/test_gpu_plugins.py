@@ -560,3 +560,53 @@ def test_allreduce_allgather_single_rank_rccl():
             run_plugin(bad, [x], [y])
     finally:
         assert lib.tllm_comm_destroy_all() == 0
+
+
+# ---------------------------------------------------------------------------------------------- fused MLP GEMM
+@pytest.mark.parametrize('m,n,k', [(300, 456, 1152), (1024, 1376, 512), (64, 96, 128), (257, 200, 256)])
+def test_dual_gemm_swiglu_quant_equals_the_unfused_chain(m, n, k):
+    """tllm_gemm_swiglu_quant (fc and gate of the SmoothQuant MLP in one kernel, SwiGLU + static quantiser in its epilogue,
+    kernels/gemm_sqp.hip DUAL) against the chain it replaces in the prefill - two exact SmoothQuant GEMMs to fp16
+    (tests above), SwiGLU with the reference graph's fp16 rounding points (PY/layers/mlp.py:68-73) and the static int8
+    quantiser: every int8 must be identical.  Ragged M / N edges, several K-tiles, N not a multiple of 16 (scalar stores)."""
+    import ctypes
+    lib = capi.load_library()
+
+    class GemmParams(ctypes.Structure):
+        _fields_ = [('wtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32), ('M', ctypes.c_int32), ('N', ctypes.c_int32),
+                    ('K', ctypes.c_int32), ('a', ctypes.c_void_p), ('lda', ctypes.c_int64), ('w', ctypes.c_void_p),
+                    ('ldw', ctypes.c_int64), ('scale_col', ctypes.c_void_p), ('scale_row', ctypes.c_void_p),
+                    ('per_channel', ctypes.c_int32), ('per_token', ctypes.c_int32), ('c', ctypes.c_void_p),
+                    ('ldc', ctypes.c_int64)]
+
+    lib.tllm_gemm_swiglu_quant.argtypes = [ctypes.POINTER(GemmParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    lib.tllm_gemm_swiglu_quant.restype = ctypes.c_int32
+    torch.manual_seed(m + n)
+    a = torch.randint(-128, 128, (m, k), dtype=torch.int8)
+    w1 = torch.randint(-128, 128, (n, k), dtype=torch.int8)
+    w2 = torch.randint(-128, 128, (n, k), dtype=torch.int8)
+    s1 = (torch.randint(1, 13, (n, )).float() * 2e-5)
+    s2 = (torch.randint(1, 13, (n, )).float() * 2e-5)
+    sr = torch.tensor([0.75], dtype=torch.float32)
+    qs = torch.tensor([23.0], dtype=torch.float32)
+    # the un-fused chain on the CPU with the oracle's rounding points
+    acc1 = (a.double() @ w1.double().t()).float()
+    acc2 = (a.double() @ w2.double().t()).float()
+    g16 = (acc1 * (s1[None, :] * sr)).half().float()
+    u16 = (acc2 * (s2[None, :] * sr)).half().float()
+    a16 = (g16 / (1.0 + torch.exp(-g16))).half().float()
+    o16 = (a16 * u16).half().float()
+    ref = torch.clamp(torch.round(o16 * qs), -128, 127).to(torch.int8)
+    d = {k_: v.cuda() for k_, v in dict(a=a, w1=w1, w2=w2, s1=s1, s2=s2, sr=sr, qs=qs).items()}
+    out = torch.full((m, n), 77, dtype=torch.int8, device='cuda')
+    q = GemmParams(3, 2, m, n, k, d['a'].data_ptr(), k, d['w1'].data_ptr(), k, d['s1'].data_ptr(), d['sr'].data_ptr(), 1, 0,
+                   out.data_ptr(), n)
+    rc = lib.tllm_gemm_swiglu_quant(ctypes.byref(q), d['w2'].data_ptr(), d['s2'].data_ptr(), d['qs'].data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, capi.last_error()
+    torch.cuda.synchronize()
+    got = out.cpu()
+    # exp() on the GPU (v_exp_f32) and in torch differ in the last ulp: a result that sits on an fp16 / int8 rounding boundary may
+    # flip by one LSB - allow a handful, never more than 1
+    diff = (got.int() - ref.int()).abs()
+    assert int(diff.max()) <= 1 and int((diff > 0).sum()) <= max(4, m * n // 2000), (int(diff.max()), int((diff > 0).sum()))

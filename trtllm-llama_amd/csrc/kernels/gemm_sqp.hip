@@ -43,6 +43,12 @@ __device__ __forceinline__ void glds16s(const char* base, uint32_t off, uint32_t
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
 }
 
+// 4 bytes per lane from per-lane 64-bit addresses (scales of two different tensors in one chunk)
+__device__ __forceinline__ void glds4v(const void* gptr, uint32_t lds_byte)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
+}
+
 // the same with 4 bytes per lane (scales)
 __device__ __forceinline__ void glds4s(const char* base, uint32_t off, uint32_t lds_byte)
 {
@@ -55,7 +61,7 @@ __device__ __forceinline__ int swz_g(int row)
     return ((j & 1) << 1) | (j & 4);
 }
 
-template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRIO, int ABL, int RSP>
+template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRIO, int ABL, int RSP, bool DUAL = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams p)
 {
     constexpr int NW = WR * WC;
@@ -87,7 +93,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     }
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tm = wg % tiles_m, tn = wg / tiles_m;
-    const int m0 = tm * BM, n0 = tn * BN;
+    // DUAL: W-half 0 = rows [n0, n0 + BH) of the first matrix, W-half 1 = the SAME rows of the second one; BH output columns
+    const int m0 = tm * BM, n0 = tn * (DUAL ? BH : BN);
     const int M = p.M, N = p.N;
     const int ntile = p.K / 128;
 
@@ -96,6 +103,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     // W-halves may have fewer chunks than 2 per wave: W0 hands its surplus to the low waves, W1 to the high waves.
     const char* xb = reinterpret_cast<const char*>(p.a);
     const char* wb = reinterpret_cast<const char*>(p.w);
+    const char* wb2 = DUAL ? reinterpret_cast<const char*>(p.w2) : wb;
     uint32_t xo[2][APW], wo[2][BPW];
     const int wrev = NW - 1 - wid;
 #pragma unroll
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
             int c = (h == 0 ? wid : wrev) + k * NW;
             c = c < BCH ? c : BCH - 1;
             const int row = c * 8 + (lane >> 3);
-            int gr = n0 + h * BH + row;
+            int gr = n0 + (DUAL ? 0 : h * BH) + row;
             gr = gr < N ? gr : N - 1;
             wo[h][k] = (uint32_t) (gr * (int) p.ldw + (((lane & 7) ^ swz_g(row)) << 4));
         }
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
 #pragma unroll
             for (int k = 0; k < BPW; ++k)
                 if (w0 + k * NW < BCH) // wave-uniform
-                    glds16s(wb + (int64_t) t * 128, wo[h][k], bufb + (h ? OFF_W1 : OFF_W0) + (w0 + k * NW) * 1024);
+                    glds16s((h ? wb2 : wb) + (int64_t) t * 128, wo[h][k], bufb + (h ? OFF_W1 : OFF_W0) + (w0 + k * NW) * 1024);
         }
     };
 
@@ -220,9 +228,11 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         {
             if (c < CCH)
             {
-                int col = n0 + c * 64 + lane;
+                const int j = c * 64 + lane; // column slot of the tile: DUAL keeps the second matrix's scales in [BH, 2 BH)
+                int col = n0 + (DUAL ? (j < BH ? j : j - BH) : j);
                 col = col < N ? col : N - 1;
-                glds4s(scb, p.per_channel ? (uint32_t) col * 4u : 0u, lds_base + SC_OFF + c * 256);
+                const char* base = (DUAL && j >= BH) ? reinterpret_cast<const char*>(p.scale_col2) : scb;
+                glds4v(base + (p.per_channel ? (int64_t) col * 4 : 0), lds_base + SC_OFF + c * 256);
             }
             else
             {
@@ -382,6 +392,67 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                         asm volatile("" ::"v"(acc[i][j][m][n]));
         return;
     }
+    if constexpr (DUAL)
+    {
+        // SwiGLU + static quantisation: quadrant (i, 0) holds fc (through SiLU), (i, 1) gate, same output column.  Rounding
+        // points of the un-fused path: each product to fp16, silu to fp16, the product of the two to fp16, then sat(rni(. * qs))
+        const float qs = p.swiglu_qscale[0];
+        const float sr2 = p.scale_row2 ? p.scale_row2[0] : p.scale_row[0]; // static scales: one value per GEMM
+        constexpr int PITCH = BH + 16; // int8 tile [BM][BH] through LDS, then 16-byte row pieces
+        static_assert(BM * PITCH <= 2 * BUF, "the int8 tile must fit the operand buffers");
+        const bool vec = !(p.ldc & 15) && !(N & 15) && !(reinterpret_cast<uintptr_t>(p.c) & 15);
+        char* ot = lds;
+#pragma unroll
+        for (int n = 0; n < NTH; ++n)
+        {
+            const int cl = (wc * NTH + n) * 16 + 4 * (lane >> 4);
+            const float4 sg = *reinterpret_cast<const float4*>(sc_l + cl);
+            const float4 su = *reinterpret_cast<const float4*>(sc_l + BH + cl);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int m = 0; m < MTH; ++m)
+                {
+                    const int rl = i * AH + (wr * MTH + m) * 16 + (lane & 15);
+                    const float sr = sr_l[rl];
+                    const i32x4 ag = acc[i][0][m][n], au = acc[i][1][m][n];
+                    const float sgv[4] = {sg.x, sg.y, sg.z, sg.w}, suv[4] = {su.x, su.y, su.z, su.w};
+                    uint32_t q4 = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                    {
+                        const float g16 = h2f(f2h((float) ag[r] * (sgv[r] * sr)));
+                        const float u16 = h2f(f2h((float) au[r] * (suv[r] * sr2)));
+                        const float a16 = h2f(f2h(g16 / (1.f + __expf(-g16))));
+                        const float o16 = h2f(f2h(a16 * u16));
+                        q4 |= ((uint32_t) (uint8_t) f2i8_rni_sat(o16 * qs)) << (8 * r);
+                    }
+                    if (vec)
+                        *reinterpret_cast<uint32_t*>(ot + rl * PITCH + cl) = q4;
+                    else
+                    {
+                        const int row = m0 + rl;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (row < M && n0 + cl + r < N)
+                                reinterpret_cast<int8_t*>(p.c)[(int64_t) row * p.ldc + n0 + cl + r] = (int8_t) (q4 >> (8 * r));
+                    }
+                }
+        }
+        if (!vec)
+            return;
+        __syncthreads();
+        constexpr int PPR = BH / 16;
+        for (int k = tid; k < BM * PPR; k += NW * 64)
+        {
+            const int rl = k / PPR, pc = k % PPR;
+            const int grow = m0 + rl, gcol = n0 + pc * 16;
+            if (grow < M && gcol < N)
+                *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(p.c) + (int64_t) grow * p.ldc + gcol)
+                    = *reinterpret_cast<const uint4*>(ot + rl * PITCH + pc * 16);
+        }
+        return;
+    }
     if (vec16)
     {
         // fp16 tile through LDS ([BM][BN] halfs, pitch + 16 bytes: the 16 rows of a ds_write_b64 lane group land on 16
@@ -487,13 +558,13 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         }
 }
 
-template <int WR, int WC, int MTH, int NTH, int DP0, int DP1, bool PRIO, int ABL = 0, int RSP = 0>
+template <int WR, int WC, int MTH, int NTH, int DP0, int DP1, bool PRIO, int ABL = 0, int RSP = 0, bool DUAL = false>
 int launch_sqp(const GemmParams& p, hipStream_t stream)
 {
     constexpr int BM = 2 * WR * MTH * 16, BN = 2 * WC * NTH * 16;
     constexpr size_t smem = (size_t) 2 * (BM + BN) * 128 + (BM + BN) * 4; // operand buffers + the tile's scales
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP>;
+    auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP, DUAL>;
     static std::atomic<bool> attr_done{false};
     if (!attr_done)
     {
@@ -501,7 +572,8 @@ int launch_sqp(const GemmParams& p, hipStream_t stream)
             (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
         attr_done = true;
     }
-    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    constexpr int BNO = DUAL ? BN / 2 : BN; // output columns per tile
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BNO - 1) / BNO);
     hipLaunchKernelGGL(kfn, dim3(tiles), dim3(64 * WR * WC), smem, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -558,6 +630,18 @@ int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
     case 33: return launch_sqp<4, 2, 2, 3, 0, 6, false, 32 + 5>(p, stream); // MFMA only, no barriers
     default: return 1;
     }
+}
+
+int launch_gemm_swiglu(const GemmParams& p, hipStream_t stream)
+{
+    if (p.wtype != W_INT8_SQ || !p.w2 || !p.scale_col2 || !p.swiglu_qscale || p.per_token || p.residual)
+        return 1;
+    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (p.lda & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)
+        || (reinterpret_cast<uintptr_t>(p.w2) & 15) || (p.ldw & 15) || (p.K % 128) || p.K <= 0 || p.M < 32)
+        return 1;
+    if ((int64_t) p.M * p.lda >= (1ll << 31) || (int64_t) p.N * p.ldw >= (1ll << 31))
+        return 1;
+    return launch_sqp<4, 2, 2, 3, 0, 6, false, 0, 0, true>(p, stream); // 256 rows x 96 columns of both matrices
 }
 
 } // namespace kernels

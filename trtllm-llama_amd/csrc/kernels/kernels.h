@@ -239,11 +239,21 @@ struct GemmParams
     void* c = nullptr;
     int64_t ldc = 0;
     const void* residual = nullptr; // optional fp16 [M, ldc]: C = fp16(fp16(gemm) + residual) (may alias c); fp16 output only
+    // SmoothQuant dual GEMM (prefill MLP, static activation scales): w2 / scale_col2 = the second weight matrix [N, ldw] and
+    // its per-channel scales; c = int8 [M, ldc] = sat(rni(fp16(silu16(A W^T) * fp16(A W2^T)) * swiglu_qscale[0])) with the
+    // fp16 rounding points of the un-fused path (two fp16 GEMM outputs, SwiGLU in fp16, static quantiser); launch_gemm_swiglu
+    const void* w2 = nullptr;
+    const void* scale_col2 = nullptr;
+    const float* scale_row2 = nullptr; // static dequantisation scale of the second GEMM [1] (null: scale_row)
+    const float* swiglu_qscale = nullptr;
     // weight-only types at M >= 32: scratch of gemm_woq_scratch_bytes(N, K) bytes lets the GEMM expand the integers to
     // fp16 once (exact) and run the LDS-DMA staged fp16 kernel with the per-channel scale in its epilogue
     void* scratch = nullptr;
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);
+// fc and gate projections of the SmoothQuant MLP in one kernel with SwiGLU + static int8 quantisation in its epilogue
+// (gemm_sqp.hip); returns 1 when the problem is not served (caller runs the two GEMMs + launch_swiglu_quant instead)
+int launch_gemm_swiglu(const GemmParams& p, hipStream_t stream);
 size_t gemm_woq_scratch_bytes(int32_t N, int32_t K);
 
 // One-shot peer-to-peer sum all-reduce of an fp16 vector, in place (kernels/p2p_allreduce.hip; plugins/p2p.cpp owns the

@@ -571,9 +571,47 @@ struct tllm_session
             else
                 r.y = tmp;
             RUN(launch_rmsnorm(r, st));
+            const void* p_in = inter_buf;
+            bool mlp_fused = false;
+            if (sq && !per_token && M >= 32 && !getenv("TLLM_NO_DUAL_GEMM"))
+            {
+                // fc and gate in one kernel with SwiGLU + the static quantiser in its epilogue (gemm_sqp.hip, DUAL): the two fp16
+                // [M, Ir] intermediates and the pointwise pass between the GEMMs disappear.  The int8 result goes to inter_buf
+                // (q8 is this kernel's INPUT)
+                GemmParams d;
+                d.wtype = L.fc.wtype;
+                d.out_dtype = DT_INT8;
+                d.M = M;
+                d.N = L.fc.N;
+                d.K = L.fc.K;
+                d.a = a_in;
+                d.lda = L.fc.K;
+                d.w = L.fc.w;
+                d.ldw = L.fc.ldw;
+                d.scale_col = L.fc.scale_col;
+                d.scale_row = L.fc.act_scale;
+                d.per_channel = L.fc.per_channel;
+                d.per_token = 0;
+                d.c = inter_buf;
+                d.ldc = L.fc.N;
+                d.w2 = L.gate.w;
+                d.scale_col2 = L.gate.scale_col;
+                d.scale_row2 = L.gate.act_scale;
+                d.swiglu_qscale = L.mlp_qscale;
+                if (L.gate.ldw == L.fc.ldw && L.gate.per_channel == L.fc.per_channel && L.gate.N == L.fc.N && L.gate.K == L.fc.K)
+                {
+                    const int rc = launch_gemm_swiglu(d, st);
+                    if (rc < 0)
+                        return 1;
+                    mlp_fused = rc == 0;
+                }
+            }
+            if (mlp_fused)
+                p_in = inter_buf;
+            else
+            {
             RUN(gemm(L.fc, M, a_in, sq && per_token ? qscale : nullptr, sq && per_token, g, DT_HALF, st));
             RUN(gemm(L.gate, M, a_in, sq && per_token ? qscale : nullptr, sq && per_token, u, DT_HALF, st));
-            const void* p_in = inter_buf;
             if (sq && !per_token)
             {
                 RUN(launch_swiglu_quant(q8, g, u, (int64_t) M * Ir, L.mlp_qscale, st)); // SwiGLU and its quantiser in one pass
@@ -587,6 +625,7 @@ struct tllm_session
                     RUN(launch_quantize_per_token(q8, inter_buf, DT_HALF, M, Ir, qscale, st));
                     p_in = q8;
                 }
+            }
             }
             if (fuse_res)
             {
@@ -1854,6 +1893,39 @@ int32_t tllm_gemm(const tllm_gemm_params_t* q, tllm_stream_t stream)
 void tllm_gemv_set_blocks_per_cu(int32_t n)
 {
     tllm::kernels::gemv_tune_blocks_per_cu = n;
+}
+
+int32_t tllm_gemm_swiglu_quant(const tllm_gemm_params_t* q, const void* w_up, const void* scale_col_up, const float* quant_scale,
+    tllm_stream_t stream)
+{
+    if (!q || !w_up || !scale_col_up || !quant_scale)
+    {
+        set_error("tllm_gemm_swiglu_quant: null argument");
+        return 1;
+    }
+    GemmParams g;
+    g.wtype = q->wtype;
+    g.out_dtype = DT_INT8;
+    g.M = q->M;
+    g.N = q->N;
+    g.K = q->K;
+    g.a = q->a;
+    g.lda = q->lda;
+    g.w = q->w;
+    g.ldw = q->ldw;
+    g.scale_col = q->scale_col;
+    g.scale_row = q->scale_row;
+    g.per_channel = q->per_channel;
+    g.per_token = q->per_token;
+    g.c = q->c;
+    g.ldc = q->ldc;
+    g.w2 = w_up;
+    g.scale_col2 = scale_col_up;
+    g.swiglu_qscale = quant_scale;
+    const int rc = tllm::kernels::launch_gemm_swiglu(g, reinterpret_cast<hipStream_t>(stream));
+    if (rc == 1)
+        set_error("tllm_gemm_swiglu_quant: problem not served by the fused kernel (SmoothQuant static, K %% 128 == 0, M >= 32, 16-byte aligned operands)");
+    return rc ? 1 : 0;
 }
 
 void tllm_gemm_set_clock_probe(void* device_buffer)
