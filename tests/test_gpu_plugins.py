@@ -610,3 +610,44 @@ def test_dual_gemm_swiglu_quant_equals_the_unfused_chain(m, n, k):
     # flip by one LSB - allow a handful, never more than 1
     diff = (got.int() - ref.int()).abs()
     assert int(diff.max()) <= 1 and int((diff > 0).sum()) <= max(4, m * n // 2000), (int(diff.max()), int((diff > 0).sum()))
+
+
+def test_gemm_clock_probe_reports_a_plausible_shader_clock():
+    """tllm_gemm_set_clock_probe ("the chip clocks to its power budget"): while set, every workgroup of
+    the SmoothQuant prefill GEMMs writes {shader cycles, ticks of the constant 100 MHz counter}; the ratio is the clock the
+    chip held - between a deep-throttle floor and the 2.4 GHz maximum - and the GEMM's result is unaffected.  Unset: nothing
+    is written."""
+    import ctypes
+    lib = capi.load_library()
+    lib.tllm_gemm_set_clock_probe.argtypes = [ctypes.c_void_p]
+    lib.tllm_gemm_set_clock_probe.restype = None
+    torch.manual_seed(3)
+    m, n, k = 1024, 1536, 2048   # 256 x 192 tiles: the phased kernel; then 128 x 128: the lock-step one
+    for n_ in (n, 512):
+        a = torch.randint(-128, 128, (m, k), dtype=torch.int8)
+        w = torch.randint(-128, 128, (n_, k), dtype=torch.int8)
+        sa = (torch.randint(1, 13, (m, 1)).float() * 1e-2)
+        sb = (torch.randint(1, 13, (1, n_)).float() * 1e-2)
+        p = make_plugin('SmoothQuantGemm', [('has_per_channel_scaling', i32(1)), ('has_per_token_scaling', i32(1)),
+                                            ('type_id', i32([capi.HALF]))])
+        ref = O.sq_gemm(a.numpy(), w.numpy(), sa.numpy(), sb.numpy(), 'float16')
+        probe = torch.zeros(8192, dtype=torch.int64, device='cuda')
+        out = torch.empty((m, n_), dtype=torch.float16, device='cuda')
+        try:
+            lib.tllm_gemm_set_clock_probe(ctypes.c_void_p(probe.data_ptr()))
+            for _ in range(4):
+                run_plugin(p, [a.cuda(), w.cuda(), sa.cuda(), sb.cuda()], [out])
+            torch.cuda.synchronize()
+        finally:
+            lib.tllm_gemm_set_clock_probe(None)
+        np.testing.assert_array_equal(as_f32(out), ref)
+        d = probe.view(-1, 2).cpu().numpy()
+        used = d[d[:, 1] > 0]
+        assert len(used) >= 8, 'no workgroup reported'
+        mhz = np.median(used[:, 0] / used[:, 1]) * 100.0
+        print(f'N = {n_}: {len(used)} workgroups, shader clock held {mhz:.0f} MHz')
+        assert 500.0 < mhz < 2600.0, mhz
+        probe.zero_()
+        run_plugin(p, [a.cuda(), w.cuda(), sa.cuda(), sb.cuda()], [out])
+        torch.cuda.synchronize()
+        assert int(probe.abs().sum().item()) == 0

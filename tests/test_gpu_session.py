@@ -85,6 +85,40 @@ def test_tiny_llama_fp16_logits_vs_hf_and_oracle():
     s.close()
 
 
+def test_force_tokens_feeds_the_next_step():
+    """tllm_session_force_tokens (teacher forcing for parity tests): the forced ids replace the sampler's choice in the output
+    buffer, as the next step's input id and as its input embedding row - the following step's logits are the oracle's for the
+    forced token, eager and replayed from the step graph, and the step counters are untouched."""
+    t, w = load_tiny()
+    ids, lens = t['ids'], t['input_lengths']
+    B, S = ids.shape
+    H, Dh, smax = 2, 32, S + 6
+    ow = oracle_weights(w)
+    masked = np.zeros((B, smax), np.int32)
+    for b in range(B):
+        masked[b, lens[b]:S] = 1
+    s = NativeSession(dict(TINY_CFG, quant_mode=0))
+    for k, v in w.items():
+        s.set_tensor(k, v)
+    s.finalize()
+    s.setup(B, S, 6)
+    s.context(ids, lens)
+    caches = [np.zeros((B, 2, H, smax, Dh), np.float16) for _ in range(2)]
+    O.llama_logits_context(ids, ow, caches, lens, H)
+    r = np.random.default_rng(5)
+    seq0 = s.step_state()['sequence_length'].copy()
+    for step in range(4):
+        forced = r.integers(3, TINY_CFG['vocab_size'], B).astype(np.int32)
+        assert not np.array_equal(forced, s.output_ids()[:, S + step])  # a real override
+        s.force_tokens(forced)
+        np.testing.assert_array_equal(s.output_ids()[:, S + step], forced)
+        np.testing.assert_array_equal(s.step_state()['sequence_length'], seq0 + step)  # counters untouched by the override
+        s.step(1, use_graph=step >= 2)
+        ref = O.llama_logits_decode(forced, ow, caches, [S + step] * B, lens, S, S + step, H, masked)
+        np.testing.assert_allclose(s.logits(), ref, atol=2e-2)
+    s.close()
+
+
 def test_generate_graph_equals_eager():
     """The captured generation step must reproduce the eager one token for token."""
     t, w = load_tiny()
