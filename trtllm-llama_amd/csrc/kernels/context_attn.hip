@@ -345,8 +345,11 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const ContextAttnParam
 }
 
 // grid (ceil(S / 128), H, B), 256 threads; heavy (late) query blocks first.
+// Waves 0 - 3 compute (32 queries each); waves 4 - 7 only issue the LDS-DMA of the K / V^T tiles: an LDS-DMA instruction holds
+// its issuer for 100 - 185 cycles, and with ONE compute wave per SIMD nothing covered the 8 of them per key block (r02:
+// ~1/4 of the time per block).  The loaders share the SIMDs with the compute waves (2 x ~180 VGPRs fit) and run one block ahead.
 template <int DH>
-__global__ __launch_bounds__(256) void context_attn_mfma_kernel(const ContextAttnParams p, int spad)
+__global__ __launch_bounds__(512) void context_attn_mfma_kernel(const ContextAttnParams p, int spad)
 {
     constexpr int NSUB = DH / 64;              // 128-byte sub-tiles of a K row
     constexpr int KST = DH / 16;               // k-steps of the QK product
@@ -356,7 +359,9 @@ __global__ __launch_bounds__(256) void context_attn_mfma_kernel(const ContextAtt
     constexpr int CHUNKS = STAGE / 1024, CPW = CHUNKS / 4;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave >= 4;
+    const int wid = wave & 3; // query quarter (compute waves) / chunk set (loaders)
     const int qb = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int H = p.num_heads, S = p.seq;
     const int q0 = qb * 128 + wid * 32; // first query of this wave
@@ -416,13 +421,19 @@ __global__ __launch_bounds__(256) void context_attn_mfma_kernel(const ContextAtt
     float m = -INFINITY, l = 0.f;
     const int krow = (ql & ~12) | ((ql & 4) << 1) | ((ql & 8) >> 1); // pi(ql): bits 2 and 3 swapped
 
-    issue(0);
+    if (loader)
+        issue(0);
     for (int t = 0; t < nkb; ++t)
     {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < nkb)
-            issue(t + 1);
+        if (loader)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // block t is in LDS for everybody; the compute waves are done with block t - 1
+        if (loader)
+        {
+            if (t + 1 < nkb)
+                issue(t + 1); // into the stage block t - 1 occupied (a third stage with a counted wait: no gain, 40.2 vs 41.0 us)
+            continue;
+        }
         const int kv0 = t * 64;
         if (kv0 > q0 + 31) // every key of this block is in the future of every query of this wave (wave-uniform)
             continue;
@@ -500,6 +511,8 @@ __global__ __launch_bounds__(256) void context_attn_mfma_kernel(const ContextAtt
     const float inv = (q < len) ? 1.f / (l + 1.e-6f) : 0.f; // padding queries produce zero rows
     constexpr int PITCH = DH * 2 + 16;
     __syncthreads(); // every wave is done with the operand stages
+    if (loader)
+        return;
     char* scr = lds + wid * (32 * PITCH);
 #pragma unroll
     for (int i = 0; i < DT; ++i)
@@ -544,7 +557,7 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
                     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
                 attr_done = true;
             }
-            hipLaunchKernelGGL(kfn, dim3((p.seq + 127) / 128, p.num_heads, p.batch), dim3(256), smem, stream, p, spad);
+            hipLaunchKernelGGL(kfn, dim3((p.seq + 127) / 128, p.num_heads, p.batch), dim3(512), smem, stream, p, spad);
         }
     }
     if (!mfma)
