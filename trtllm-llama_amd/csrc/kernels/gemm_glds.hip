@@ -54,6 +54,12 @@ __device__ __forceinline__ void glds16(const void* gptr, uint32_t lds_byte)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
 }
 
+// the same from a wave-uniform base + a per-lane 32-bit offset
+__device__ __forceinline__ void glds16s(const char* base, uint32_t off, uint32_t lds_byte)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
+}
+
 // byte offset of 16-byte piece c16 of tile row `row`: XOR swizzle so that the 16 lanes of a ds_read_b128 phase
 // (16 consecutive rows, same k-piece) hit 16 different 16-byte bank groups
 template <int BKB>
@@ -72,12 +78,18 @@ __device__ __forceinline__ void wait_vmcnt()
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WT, int WM, int WN, int MT, int NT, int KG, int BKB, int S>
-__global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const GemmParams p)
+// LW > 0: LW extra waves that do nothing but issue the LDS-DMA.  One wave sustains about one LDS-DMA instruction per ~150
+// cycles whatever else it does (the instruction holds its issuer for 100 - 185 cycles), which in the 8-wave 256 x 192 shape is a
+// third of every compute wave's issue time; loaders (the shape's 160 VGPRs leave room for a third wave per SIMD) take that
+// over and run the ring's look-ahead.
+template <int WT, int WM, int WN, int MT, int NT, int KG, int BKB, int S, int LW = 0>
+__global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void gemm_glds_kernel(const GemmParams p)
 {
     constexpr bool SQ = WT == W_INT8_SQ;
     constexpr int ES = SQ ? 1 : 2; // bytes per A / W element
-    constexpr int NW = WM * WN * KG;              // KG groups of WM x WN waves split the k-steps of every stage
+    constexpr int NWC = WM * WN * KG;             // compute waves: KG groups of WM x WN waves split the k-steps of every stage
+    constexpr int NW = LW > 0 ? LW : NWC;         // waves that issue the DMA
+    static_assert(LW == 0 || KG == 1, "loader waves: one K-group");
     constexpr int KSTEPS = BKB / 32 / KG;         // k-steps per stage per group
     static_assert(KG == 1 || (KG == 2 && BKB == 128 && MT % 2 == 0), "K-groups: 2, on 128-byte stages");
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
@@ -96,6 +108,8 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
     // clock evidence for the microbench (tllm_gemm_set_clock_probe; the field is unused by SmoothQuant / fp16 otherwise)
     void* const clk_probe = SQ ? p.scratch : nullptr;
     const uint64_t clk0 = clk_probe ? __builtin_readcyclecounter() : 0, rt0 = clk_probe ? __builtin_amdgcn_s_memrealtime() : 0;
+    const bool loader = LW > 0 && wid >= NWC;     // wave-uniform
+    const int iw = LW > 0 ? (wid >= NWC ? wid - NWC : 0) : wid; // index among the issuing waves
     const int kg = wid / (WM * WN), wq = wid % (WM * WN);
     const int wm = wq / WN, wn = wq % WN;
     // XCD-aware tile order: consecutive workgroup ids go to different XCDs (round-robin dispatch); give each XCD a
@@ -115,24 +129,35 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
     // ---- DMA source addresses: chunk c (RPC tile rows) -> lane l: row c * RPC + l / PPR, LDS piece l % PPR
     const char* a_base = reinterpret_cast<const char*>(p.a);
     const char* w_base = reinterpret_cast<const char*>(p.w);
-    const char* src[CPW];
-    const bool short_wave = RAGGED && (CPW - 1) * NW + wid >= CHUNKS; // this wave has CPW - 1 DMA instructions
+    const char* src[LW > 0 ? 1 : CPW];
+    // loader waves carry twice the chunks of a compute wave: 32-bit offsets from the two (wave-uniform) operand bases instead
+    // of 64-bit addresses, or the 168-register budget of three waves per SIMD spills
+    uint32_t soff[LW > 0 ? CPW : 1];
+    constexpr int ACH = BM / RPC; // chunks of the A part of a stage
+    static_assert(LW == 0 || ACH % LW == 0, "loader waves: A / W chunk boundary must not split a loader's turn");
+    const bool short_wave = RAGGED && (CPW - 1) * NW + iw >= CHUNKS; // this wave has CPW - 1 DMA instructions
 #pragma unroll
     for (int i = 0; i < CPW; ++i)
     {
-        int c = i * NW + wid;
+        int c = i * NW + iw;
         c = c < CHUNKS ? c : CHUNKS - 1;
         const int row = c * RPC + lane / PPR;
         const int col = BKB == 128 ? (lane & 7) ^ ((row >> 1) & 7) : (lane & 3) ^ ((row >> 2) & 3);
         if (row < BM)
         {
             const int gr = m0 + row < M ? m0 + row : M - 1;
-            src[i] = a_base + (int64_t) gr * p.lda * ES + col * 16;
+            if constexpr (LW > 0)
+                soff[i] = (uint32_t) ((int64_t) gr * p.lda * ES + col * 16);
+            else
+                src[i] = a_base + (int64_t) gr * p.lda * ES + col * 16;
         }
         else
         {
             const int gr = n0 + row - BM < N ? n0 + row - BM : N - 1;
-            src[i] = w_base + (int64_t) gr * p.ldw + col * 16;
+            if constexpr (LW > 0)
+                soff[i] = (uint32_t) ((int64_t) gr * p.ldw + col * 16);
+            else
+                src[i] = w_base + (int64_t) gr * p.ldw + col * 16;
         }
     }
     const uint32_t lds_base = (uint32_t) (uintptr_t) (lds_void_t*) lds;
@@ -141,8 +166,13 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
 #pragma unroll
         for (int i = 0; i < CPW; ++i)
         {
-            const int c = i * NW + wid;
-            if (!RAGGED || i < CPW - 1 || !short_wave) // wave-uniform
+            const int c = i * NW + iw;
+            if constexpr (LW > 0)
+            {
+                if (!RAGGED || i < CPW - 1 || !short_wave) // wave-uniform
+                    glds16s((i < ACH / LW ? a_base : w_base) + (int64_t) t * BKB, soff[i], lds_base + stg * STAGE + c * 1024);
+            }
+            else if (!RAGGED || i < CPW - 1 || !short_wave) // wave-uniform
                 glds16(src[i] + (int64_t) t * BKB, lds_base + stg * STAGE + c * 1024);
         }
     };
@@ -155,9 +185,10 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
 #pragma unroll
         for (int i = 0; i < CPW; ++i)
         {
-            const int c = i * NW + wid;
-            if (i % parts == part && (!RAGGED || i < CPW - 1 || !short_wave)) // wave-uniform
-                glds16(src[i] + (int64_t) t * BKB, lds_base + stg * STAGE + c * 1024);
+            const int c = i * NW + iw;
+            if constexpr (LW == 0)
+                if (i % parts == part && (!RAGGED || i < CPW - 1 || !short_wave)) // wave-uniform
+                    glds16(src[i] + (int64_t) t * BKB, lds_base + stg * STAGE + c * 1024);
         }
     };
 
@@ -172,24 +203,64 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
                 acc[i][j][r] = 0;
 
     const int fr = lane & 31, fk = lane >> 5;
+    const bool vec_out = p.out_dtype == DT_HALF && !(p.ldc & 7) && !(N & 7) && !(reinterpret_cast<uintptr_t>(p.c) & 15)
+        && !(reinterpret_cast<uintptr_t>(p.residual) & 15);
+    if constexpr (LW > 0)
+    {
+        // the loaders' whole life: request, wait, barrier, request ... - a loop of its own, so that none of the compute waves'
+        // registers (accumulators, fragments) is live in it and vice versa
+        if (loader)
+        {
 #pragma unroll
-    for (int t = 0; t < D; ++t)
-        if (t < ntile)
-            issue(t);
+            for (int t = 0; t < D; ++t)
+                if (t < ntile)
+                    issue(t);
+            for (int t = 0; t < ntile; ++t)
+            {
+                if (t + D - 1 < ntile)
+                {
+                    if (short_wave)
+                        wait_vmcnt<(D - 1) * (CPW - 1)>();
+                    else
+                        wait_vmcnt<(D - 1) * CPW>();
+                }
+                else
+                    wait_vmcnt<0>();
+                __syncthreads();
+                if (t + D < ntile)
+                    issue(t + D);
+            }
+            if (vec_out)
+                __syncthreads(); // the epilogue's barrier
+            return;
+        }
+    }
+    const bool issuer = LW == 0;
+    if (issuer)
+    {
+#pragma unroll
+        for (int t = 0; t < D; ++t)
+            if (t < ntile)
+                issue(t);
+    }
     for (int t = 0; t < ntile; ++t)
     {
         // stage t has landed: own DMA by the counted wait (the D - 1 younger stages stay in flight), everyone's by the
         // barrier; the same barrier says nobody still reads stage t - 1, whose buffer the next DMA overwrites
-        if (t + D - 1 < ntile)
+        if (issuer)
         {
-            if (short_wave)
-                wait_vmcnt<(D - 1) * (CPW - 1)>();
+            if (t + D - 1 < ntile)
+            {
+                if (short_wave)
+                    wait_vmcnt<(D - 1) * (CPW - 1)>();
+                else
+                    wait_vmcnt<(D - 1) * CPW>();
+            }
             else
-                wait_vmcnt<(D - 1) * CPW>();
+                wait_vmcnt<0>();
         }
-        else
-            wait_vmcnt<0>();
         __syncthreads();
+
         // the DMA of tile t + D is spread over the k-steps of tile t (see issue_part): every k-step with stages to spare, the
         // first two k-steps when only one stage is ahead (it must land before the next barrier).  128 x 128 / 3 ahead (O, down)
         // 49 -> 44 us in the real prefill, 256 x 192 / 1 ahead (QKV, gate, up) 53 -> 51 us stand-alone
@@ -207,7 +278,7 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 bf[j] = *reinterpret_cast<const uint4*>(Bs + swz<BKB>((wn * NT + j) * 32 + fr, ks * 2 + fk));
-            if (k2 < SPREAD_PARTS && t + D < ntile)
+            if (LW == 0 && k2 < SPREAD_PARTS && t + D < ntile)
             {
                 __builtin_amdgcn_sched_barrier(0);
                 issue_part(t + D, k2, SPREAD_PARTS);
@@ -300,8 +371,6 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
             sc[j] = p.per_channel ? reinterpret_cast<const float*>(p.scale_col)[col < N ? col : N - 1]
                                   : reinterpret_cast<const float*>(p.scale_col)[0];
     }
-    const bool vec_out = p.out_dtype == DT_HALF && !(p.ldc & 7) && !(N & 7) && !(reinterpret_cast<uintptr_t>(p.c) & 15)
-        && !(reinterpret_cast<uintptr_t>(p.residual) & 15);
     if (vec_out)
     {
         // fp16 rows through a wave-private LDS scratch: [32 rows][NT * 32 halfs], pitch chosen so that the two lane
@@ -402,14 +471,14 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void gemm_glds_kernel(const Gemm
         }
 }
 
-template <int WT, int WM, int WN, int MT, int NT, int KG, int BKB, int S>
+template <int WT, int WM, int WN, int MT, int NT, int KG, int BKB, int S, int LW = 0>
 int launch_cfg(const GemmParams& p, hipStream_t stream)
 {
     constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
     constexpr size_t smem = (size_t) S * (BM + BN) * BKB;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static_assert(smem >= (size_t) WM * WN * KG * 32 * (NT * 64 + 16), "epilogue scratch must fit the operand stages");
-    auto kfn = gemm_glds_kernel<WT, WM, WN, MT, NT, KG, BKB, S>;
+    auto kfn = gemm_glds_kernel<WT, WM, WN, MT, NT, KG, BKB, S, LW>;
     static std::atomic<bool> attr_done{false}; // idempotent; atomic so concurrent first launches do not race
     if (!attr_done)
     {
@@ -418,7 +487,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream)
         attr_done = true;
     }
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(64 * WM * WN * KG), smem, stream, p);
+    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(64 * (WM * WN * KG + LW)), smem, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
     {
@@ -456,7 +525,10 @@ int launch_wt(const GemmParams& p, int cfg, hipStream_t stream)
     case 9: return launch_cfg<WT, 2, 2, 4, 3, 1, 128, 2>(p, stream); // 256 x 192 on 4 waves (128 x 96 per wave)
     case 10: return launch_cfg<WT, 2, 2, 4, 4, 1, 128, 2>(p, stream); // 256 x 256 on 4 waves (128 x 128 per wave)
     case 11: return launch_cfg<WT, 2, 2, 4, 3, 2, 128, 2>(p, stream); // 256 x 192, 2 K-groups of 4 waves (128 x 96 per wave)
-    default: return launch_cfg<WT, 2, 2, 2, 2, 2, 128, 2>(p, stream);  // 128 x 128, 2 K-groups of 4 waves (64 x 64 per wave)
+    case 12: return launch_cfg<WT, 2, 2, 2, 2, 2, 128, 2>(p, stream);  // 128 x 128, 2 K-groups of 4 waves (64 x 64 per wave)
+    case 36: return launch_cfg<WT, 4, 2, 2, 3, 1, 64, 5, 4>(p, stream);  // 256 x 192, 64-byte stages 4 ahead, 8 compute + 4 loader waves
+    case 37: return launch_cfg<WT, 4, 2, 2, 3, 1, 128, 2, 4>(p, stream); // 256 x 192, one 128-byte stage ahead, 8 + 4 waves
+    default: return launch_cfg<WT, 2, 2, 2, 2, 1, 128, 4>(p, stream);
     }
 }
 
@@ -477,14 +549,15 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
     if (p.residual && (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)))
         return 1; // the fused residual lives in the vector epilogue
     int cfg = gemm_tune_cfg;
-    if (sq && cfg > kNumCfg)
+    const bool glds_id = (cfg >= 1 && cfg <= kNumCfg) || cfg == 36 || cfg == 37; // ids served by this file's table
+    if (sq && cfg > kNumCfg && !glds_id)
     {
         const int r = launch_gemm_sqp(p, cfg, stream);
         if (r <= 0)
             return r;
         cfg = 0; // not served there (shape / alignment): the heuristic below picks a lock-step shape
     }
-    if (cfg <= 0 || cfg > kNumCfg)
+    if (cfg <= 0 || !((cfg >= 1 && cfg <= kNumCfg) || cfg == 36 || cfg == 37))
     {
         // fewest workgroup rounds over 256 CUs, then the largest tile (fewest operand re-reads through L2)
         static std::atomic<int> cus_cache{0};
