@@ -10,7 +10,7 @@ namespace kernels
 namespace gemv_detail
 {
 constexpr int R = 2, U = 4; // weight tile: 2 rows x 4 chunks of 1 KiB (int4 rows of <= 2 KiB use 2 chunks: kernel template)
-constexpr int kRedBytes = 256;
+constexpr int kRedBytes = 384; // reduction scratch: 32 floats sum of squares, 32 amax, 32 activation sums (weight-only int8)
 constexpr int kNXVMax = 6; // 16-byte x vectors a thread keeps in registers: K <= 256 * 8 * 6 = 12288 halfs
 constexpr int kNXVSmall = 2; // bucket for K <= 4096 halfs (every 7B hidden-size GEMV): 32 fewer VGPRs -> one more wave/SIMD
 

@@ -98,6 +98,25 @@ __device__ __forceinline__ float dot_woq8(const uint4& w, const uint4& xa, const
     return acc;
 }
 
+// The same on the RAW splice (1024 + (q + 128)): the general kernel takes 1152 * sum_k x[k] - one number per activation row -
+// off the finished sum instead of 1152 off every weight (2 of 6 VALU instructions per 4 weights)
+__device__ __forceinline__ float dot_u8x4_raw(uint32_t w, uint32_t x01, uint32_t x23, float acc)
+{
+    const uint32_t magic = 0x64646464u;
+    acc = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, w, 0x04010400u)), u32_as_h2(x01), acc, false);
+    acc = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, w, 0x04030402u)), u32_as_h2(x23), acc, false);
+    return acc;
+}
+
+__device__ __forceinline__ float dot_woq8_raw(const uint4& w, const uint4& xa, const uint4& xb, float acc)
+{
+    acc = dot_u8x4_raw(w.x, xa.x, xa.y, acc);
+    acc = dot_u8x4_raw(w.y, xa.z, xa.w, acc);
+    acc = dot_u8x4_raw(w.z, xb.x, xb.y, acc);
+    acc = dot_u8x4_raw(w.w, xb.z, xb.w, acc);
+    return acc;
+}
+
 // 8 nibbles (layout of weight_layout.h) vs 8 halfs of x (one uint4)
 __device__ __forceinline__ float dot_u4x8(uint32_t w, const uint4& x, float acc)
 {
@@ -115,6 +134,19 @@ __device__ __forceinline__ float dot_u4x8(uint32_t w, const uint4& x, float acc)
     acc = __builtin_amdgcn_fdot2(e45, u32_as_h2(x.z), acc, false);
     acc = __builtin_amdgcn_fdot2(e67, u32_as_h2(x.w), acc, false);
     return acc;
+}
+
+// The same on the raw splices, two sums: `a` over the nibbles spliced as 1024 + n (elements 0 1 4 5 of the word), `b` over those
+// spliced as 1024 + 16 n (elements 2 3 6 7).  sum_k (n_k - 8) x_k = a + b / 16 - 1032 sum(x_a) - 72 sum(x_b): the two
+// activation sums are per-row constants the general kernel takes off the finished dot product (4 of 12 VALU per 8 weights)
+__device__ __forceinline__ void dot_u4x8_raw(uint32_t w, const uint4& x, float& a, float& b)
+{
+    const uint32_t m = 0x64006400u;
+    const uint32_t w8 = w >> 8;
+    a = __builtin_amdgcn_fdot2(u32_as_h2((w & 0x000f000fu) | m), u32_as_h2(x.x), a, false);
+    b = __builtin_amdgcn_fdot2(u32_as_h2((w & 0x00f000f0u) | m), u32_as_h2(x.y), b, false);
+    a = __builtin_amdgcn_fdot2(u32_as_h2((w8 & 0x000f000fu) | m), u32_as_h2(x.z), a, false);
+    b = __builtin_amdgcn_fdot2(u32_as_h2((w8 & 0x00f000f0u) | m), u32_as_h2(x.w), b, false);
 }
 
 __device__ __forceinline__ int dot_sq(const uint4& w, const uint4& x, int acc)
@@ -527,6 +559,30 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
                     p.dyn_scale_out[m] = amax / 127.f;
             }
         }
+        if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
+        {
+            // sums of the activations the dots will see (fp16 values, fp32 sums): the biases of the raw weight splices come off
+            // once per row.  int4: separately over the halves that face the two kinds of splice (words x, z / y, w of a vector)
+            float sa = 0.f, sb = 0.f;
+#pragma unroll
+            for (int j = 0; j < kNXV; ++j)
+            {
+                const uint32_t ws[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                {
+                    const h2_t h = u32_as_h2(ws[q]);
+                    if (q & 1)
+                        sb += (float) h.x + (float) h.y;
+                    else
+                        sa += (float) h.x + (float) h.y;
+                }
+            }
+            const float bias = WT == W_INT8_WOQ ? 1152.f * (sa + sb) : 1032.f * sa + 72.f * sb;
+            const float bsum = wave_sum(bias);
+            if (lane == 0)
+                red[64 + m * 4 + wid] = bsum; // read behind the barrier that publishes the activations
+        }
 #pragma unroll
         for (int j = 0; j < kNXV; ++j)
         {
@@ -561,6 +617,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     }
 
     // ------------------------------------------------------------------ main loop: persistent waves, double buffer
+    float my_xbias = 0.f; // weight-only: the splice bias of row my_m (int8: 1152 sum x; int4: 1032 sum x_a + 72 sum x_b)
+    if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
+    {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            if (m == my_m)
+                my_xbias = red[64 + m * 4] + red[64 + m * 4 + 1] + red[64 + m * 4 + 2] + red[64 + m * 4 + 3];
+    }
     float my_row_scale = static_row_scale, my_row_scale_up = static_row_scale_up;
     if (q_dyn)
     {
@@ -571,11 +635,16 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     }
 
     acc_t acc[R][MB];
+    float acc16[WT == W_INT4_WOQ ? R : 1][WT == W_INT4_WOQ ? MB : 1]; // int4: the sum over the 1024 + 16 n splices
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int m = 0; m < MB; ++m)
+        {
             acc[r][m] = 0;
+            if constexpr (WT == W_INT4_WOQ)
+                acc16[r][m] = 0.f;
+        }
 
     int gi_p = 0, ci_p = 0;
 
@@ -620,7 +689,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
                     const uint4 xb = ldx(xr + 16);
 #pragma unroll
                     for (int r = 0; r < R; ++r)
-                        acc[r][m] = dot_woq8(cur[u][r], xa, xb, acc[r][m]);
+                        acc[r][m] = dot_woq8_raw(cur[u][r], xa, xb, acc[r][m]);
                 }
                 else if constexpr (WT == W_INT4_WOQ)
                 {
@@ -628,12 +697,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 #pragma unroll
                     for (int r = 0; r < R; ++r)
                     {
-                        float tt = acc[r][m];
-                        tt = dot_u4x8(cur[u][r].x, x0, tt);
-                        tt = dot_u4x8(cur[u][r].y, x1, tt);
-                        tt = dot_u4x8(cur[u][r].z, x2, tt);
-                        tt = dot_u4x8(cur[u][r].w, x3, tt);
-                        acc[r][m] = tt;
+                        float ta = acc[r][m], tb = acc16[r][m];
+                        dot_u4x8_raw(cur[u][r].x, x0, ta, tb);
+                        dot_u4x8_raw(cur[u][r].y, x1, ta, tb);
+                        dot_u4x8_raw(cur[u][r].z, x2, ta, tb);
+                        dot_u4x8_raw(cur[u][r].w, x3, ta, tb);
+                        acc[r][m] = ta;
+                        acc16[r][m] = tb;
                     }
                 }
                 else
@@ -660,8 +730,13 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
 #pragma unroll
             for (int m = 0; m < MB; ++m)
             {
-                const acc_t tot = wave_sum(acc[r][m]);
+                acc_t tot = wave_sum(acc[r][m]);
                 acc[r][m] = 0;
+                if constexpr (WT == W_INT4_WOQ)
+                {
+                    tot += wave_sum(acc16[r][m]) * 0.0625f;
+                    acc16[r][m] = 0.f;
+                }
                 if (r < NOUTS && lane == r * MB + m)
                 {
                     ai = (int) tot;
@@ -669,6 +744,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
                 }
                 if (SWIGLU && r == 1 && lane == m)
                     v1 = (float) tot;
+                if constexpr (WT == W_INT8_WOQ || WT == W_INT4_WOQ)
+                {
+                    // (my_m == m on the lanes that keep a value)
+                    if (r < NOUTS && lane == r * MB + m)
+                        v0 -= my_xbias;
+                    if (SWIGLU && r == 1 && lane == m)
+                        v1 -= my_xbias;
+                }
             }
         EpiOps e = ops_cur;
         ops_cur = ops_nxt;
