@@ -396,9 +396,11 @@ def main():
         allreduce_path = None
 
     res = run_config(torch, dist, args, args.config, rank, world, dev)
-    fp16 = None
+    fp16 = woq8 = None
     if args.config != 'fp16' and not args.no_fp16_ref:
         fp16 = run_config(torch, dist, args, 'fp16', rank, world, dev)
+        if args.config == 'sq':  # BASELINE.json configs[2] next to configs[1] and [3]: weight-only int8 + int8 KV (side report)
+            woq8 = run_config(torch, dist, args, 'woq8', rank, world, dev)
     if rank != 0:
         if dist:
             dist.destroy_process_group()
@@ -498,6 +500,8 @@ def main():
         line['parity'] = parity
     if fp16 is not None:
         line['fp16_tokens_per_s'] = fp16['tokens_per_s']
+        if woq8 is not None:
+            line['woq8_tokens_per_s'] = woq8['tokens_per_s']
         line['int8_over_fp16'] = res['tokens_per_s'] / fp16['tokens_per_s']
     print(json.dumps(line))
     if dist:
