@@ -117,7 +117,7 @@ def run_config(torch, dist, args, mode, rank, world, dev):
         sess.set_tensor(k, v)
     sess.finalize()
     K, W = args.steps, args.warmup
-    sess.setup(1, args.context, K + W + 4)
+    sess.setup(1, args.context, 2 * K + W + 4)  # the timed K steps + the same K once more under an event pair (below)
     stream = torch.cuda.current_stream().cuda_stream
     sess.fake_context(args.context, seed=1, stream=stream)
     sess.step(2, use_graph=False, stream=stream)  # eager: lazy init outside the capture
@@ -138,16 +138,22 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # The timed region holds NOTHING but the K steps: a timing-event pair recorded around the graph launches (as this file
+    # did in round 1) makes the same K replays take 9 % longer on the GPU (1.62 -> 1.78 ms per step, measured both ways on one
+    # box: the record in front of the first hipGraphLaunch takes the launches off the runtime's back-to-back path).
     t0 = time.perf_counter()
-    e0.record()
     sess.step(K, use_graph=use_graph, stream=stream)
-    e1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    # device time of the same K steps under a HIP event pair, in a pass of its own (side information, see above)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    sess.step(K, use_graph=use_graph, stream=stream)
+    e1.record()
+    torch.cuda.synchronize()
     dev_ms = e0.elapsed_time(e1)
     if world > 1:
         tt = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -478,7 +484,7 @@ def main():
                      'bytes_per_launch': bytes_per_launch, 'avg_launch_us': avg_dur_s * 1e6},
         'cpu_baseline': cpu,
         'step': {'hbm_bytes': res['step_bytes'], 'hbm_frac_of_peak': res['step_bytes'] / (res['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 'device_ms_per_step': res['dev_ms'] / args.steps, 'outputs_finite': res['finite'],
+                 'device_ms_per_step_under_event_pair': res['dev_ms'] / args.steps, 'outputs_finite': res['finite'],
                  'layer_kernel_us': res['kernel_us'],
                  'profile_ms_per_step': {k: v[0] / prof_steps for k, v in prof.items()},
                  'launches_per_step': {k: v[1] / prof_steps for k, v in prof.items()}},
