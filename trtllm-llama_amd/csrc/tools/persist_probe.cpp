@@ -4,6 +4,7 @@
 // previous phase wrote".  No arithmetic of interest - this measures the launch structure only.
 //   build/persist_probe [layers=16] [iters=20] [wg_per_cu=1]
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -278,7 +279,18 @@ int main(int argc, char** argv)
     }
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us_a = ms * 1e3 / iters / L;
-    printf("A  launches (5 per layer, graph)        : %7.2f us/layer  %6.0f GB/s\n", us_a, per_layer / us_a / 1e3);
+    printf("A  launches (5 per layer, graph)        : %7.2f us/layer  %6.0f GB/s   (between a HIP event pair)\n", us_a, per_layer / us_a / 1e3);
+    {
+        // the same replays timed by the host clock between two stream synchronisations, NO event recorded next to them: an
+        // event pair around graph replays costs ~0.9 us per kernel node on this runtime (bench.py)
+        CK(hipStreamSynchronize(st));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iters; ++i)
+            CK(hipGraphLaunch(ge, st));
+        CK(hipStreamSynchronize(st));
+        const double us_h = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / iters / L;
+        printf("A  launches (5 per layer, graph)        : %7.2f us/layer  %6.0f GB/s   (host clock, no events)\n", us_h, per_layer / us_h / 1e3);
+    }
 
     // (A') each phase size on its own: the pure-streaming floor of one launch of that size inside a graph
     for (int p = 0; p < 5; ++p)
