@@ -531,7 +531,25 @@ __global__ __launch_bounds__(512) void context_attn_mfma_kernel(const ContextAtt
         const int row = i / PPR, pc = i % PPR;
         const uint4 v = *reinterpret_cast<const uint4*>(scr + row * PITCH + pc * 16);
         if (q0 + row < nrows)
-            *reinterpret_cast<uint4*>(outp + (int64_t) (q0 + row) * H * DH + pc * 8) = v;
+        {
+            if (p.out_q8) // uniform: the static quantiser of the O-projection's input, on the fp16-rounded values
+            {
+                const float qs = p.out_q_scale[0];
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+                uint32_t o2[2] = {0, 0};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                {
+                    const uint32_t b0 = (uint8_t) f2i8_rni_sat(h2f((uint16_t) (w4[e] & 0xffffu)) * qs);
+                    const uint32_t b1 = (uint8_t) f2i8_rni_sat(h2f((uint16_t) (w4[e] >> 16)) * qs);
+                    o2[e >> 1] |= (b0 | (b1 << 8)) << (16 * (e & 1));
+                }
+                int8_t* qp = p.out_q8 + (seq_row0(p, b) + q0 + row) * (int64_t) H * DH + (int64_t) h * DH + pc * 8;
+                *reinterpret_cast<uint2*>(qp) = make_uint2(o2[0], o2[1]);
+            }
+            else
+                *reinterpret_cast<uint4*>(outp + (int64_t) (q0 + row) * H * DH + pc * 8) = v;
+        }
     }
 }
 
@@ -561,7 +579,20 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
         }
     }
     if (!mfma)
+    {
         hipLaunchKernelGGL((context_attn_kernel<DH>), dim3((p.seq + 3) / 4, p.num_heads, p.batch), dim3(256), 0, stream, p);
+        if (p.out_q8) // the quantiser as a pass of its own behind this kernel
+        {
+            const int64_t rows = p.cu_seqlens ? -1 : (int64_t) p.batch * p.seq;
+            if (rows < 0)
+            {
+                set_error("context attention: the fused output quantiser needs padded inputs on this path");
+                return -1;
+            }
+            if (launch_quantize_tensor(p.out_q8, p.out, DT_HALF, rows * p.num_heads * DH, p.out_q_scale, stream))
+                return -1;
+        }
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
     {

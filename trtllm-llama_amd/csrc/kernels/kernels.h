@@ -203,6 +203,11 @@ struct ContextAttnParams
     const float* rope_table = nullptr;
     int32_t rope_table_len = 0;
     void* out = nullptr; // fp16 [B, S, H*Dh]; rows >= input_len[b] are zero
+    // optional static quantiser behind the attention (SmoothQuant's O-projection input, K/quantization.cu): when set the result
+    // goes to out_q8 = sat(rni(float(fp16(ctx)) * out_q_scale[0])), int8 [B, S, H*Dh], and the MFMA kernel does not write `out`
+    // at all (the other kernels write `out` and a quantiser pass follows - same values either way)
+    int8_t* out_q8 = nullptr;
+    const float* out_q_scale = nullptr;
     void* workspace = nullptr; // context_attention_workspace_size() bytes; NULL -> the (slow) wave-per-query kernel
     // packed inputs (remove_input_padding, P/gptAttentionPlugin/gptAttentionPlugin.cpp:344-356): qkv / out hold only the real
     // tokens, [sum(len), ...]; token s of sequence b is row cu_seqlens[b] + s.  `seq` stays the longest sequence (grid bound).

@@ -527,13 +527,21 @@ struct tllm_session
             c.out = ctx;
             c.workspace = ctx_ws;
             c.cu_seqlens = packed ? cu_dev : nullptr;
+            // SmoothQuant static: the O-projection's input quantiser rides in the attention's epilogue (padded inputs; with
+            // packed inputs M counts real tokens only and the pass below covers exactly those)
+            const bool q_in_attn = sq && !per_token && !packed && !getenv("TLLM_NO_ATTN_QUANT_FUSE");
+            if (q_in_attn)
+            {
+                c.out_q8 = q8;
+                c.out_q_scale = L.attn_qscale;
+            }
             RUN(launch_context_attention(c, st));
             const void* d_in = ctx;
             if (sq)
             {
                 if (per_token)
                     RUN(launch_quantize_per_token(q8, ctx, DT_HALF, M, Dr, qscale, st));
-                else
+                else if (!q_in_attn)
                     RUN(launch_quantize_tensor(q8, ctx, DT_HALF, (int64_t) M * Dr, L.attn_qscale, st));
                 d_in = q8;
             }
