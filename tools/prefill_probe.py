@@ -14,7 +14,7 @@ sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=1, tp_rank=0))
 w = bench.synth_weights(torch, cfg, mode, int8_kv, 1, 0, dev)
 for k, v in w.items(): sess.set_tensor(k, v)
 sess.finalize()
-S = 1024
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 sess.setup(1, S, 8)
 ids = np.random.default_rng(1).integers(3, 32000, (1, S)).astype(np.int32)
 lens = np.array([S], np.int32)

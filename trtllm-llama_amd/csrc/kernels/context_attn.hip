@@ -14,6 +14,7 @@
 #include "dev_utils.h"
 #include "kernels.h"
 #include <atomic>
+#include <cstdlib>
 
 namespace tllm
 {
@@ -58,26 +59,42 @@ __device__ __forceinline__ int64_t seq_row0(const ContextAttnParams& p, int b)
     return p.cu_seqlens ? (int64_t) p.cu_seqlens[b] : (int64_t) b * p.seq;
 }
 
-// grid (S, ceil(H / HG), B), 256 threads: DH/8 lanes own the 8-element pieces of one head of one token, HG = 256 / (DH/8)
-// heads per workgroup (one (token, head) per 64-thread workgroup with 16 active lanes took 19 us per layer at S = 1024).
-template <int DH>
-__global__ __launch_bounds__(256) void rope_kv_write_kernel(const ContextAttnParams p)
+// One (token s, head h) of sequence b, handled by a group of DH / 8 consecutive lanes (li = lane in the group): RoPE on q and k in
+// place, padding rows zeroed, k / v appended to the cache (rope_kv_load + rope_kv_finish).  rope_kv_finish returns this lane's 8 v
+// elements as attention will see them (zero for padding positions); every lane of the group must call it (shuffles inside the group).
+struct RopeRow
 {
-    constexpr int LPR = DH / 8, HG = 256 / LPR;
-    const int s = blockIdx.x, h = blockIdx.y * HG + threadIdx.x / LPR, b = blockIdx.z;
-    const int li = threadIdx.x % LPR;
-    if (h >= p.num_heads) // whole lane groups (the shuffles below stay inside a group)
-        return;
-    const int H = p.num_heads, S = p.seq;
-    const bool valid = s < p.input_lengths[b];
-    const bool has_row = valid || !p.cu_seqlens; // packed buffers hold no padding rows
-    uint16_t* row = reinterpret_cast<uint16_t*>(p.qkv) + (seq_row0(p, b) + (has_row ? s : 0)) * 3 * H * DH;
-    uint16_t* qp = row + (int64_t) h * DH + li * 8;
-    uint16_t* kp = row + (int64_t) (H + h) * DH + li * 8;
-    uint16_t* vp = row + (int64_t) (2 * H + h) * DH + li * 8;
-    uint4 q4 = *reinterpret_cast<const uint4*>(qp);
-    uint4 k4 = *reinterpret_cast<const uint4*>(kp);
-    uint4 v4 = *reinterpret_cast<const uint4*>(vp);
+    uint4 q4, k4, v4;
+    uint16_t *qp, *kp, *vp;
+    bool valid, has_row;
+};
+
+// the loads of one (token, head) - split from the rest so that a caller with several rows can have all of them in flight
+template <int DH>
+__device__ __forceinline__ RopeRow rope_kv_load(const ContextAttnParams& p, int s, int h, int b, int li)
+{
+    RopeRow r;
+    const int H = p.num_heads;
+    r.valid = s < p.input_lengths[b];
+    r.has_row = r.valid || !p.cu_seqlens; // packed buffers hold no padding rows
+    uint16_t* row = reinterpret_cast<uint16_t*>(p.qkv) + (seq_row0(p, b) + (r.has_row ? s : 0)) * 3 * H * DH;
+    r.qp = row + (int64_t) h * DH + li * 8;
+    r.kp = row + (int64_t) (H + h) * DH + li * 8;
+    r.vp = row + (int64_t) (2 * H + h) * DH + li * 8;
+    r.q4 = *reinterpret_cast<const uint4*>(r.qp);
+    r.k4 = *reinterpret_cast<const uint4*>(r.kp);
+    r.v4 = *reinterpret_cast<const uint4*>(r.vp);
+    return r;
+}
+
+template <int DH>
+__device__ __forceinline__ uint4 rope_kv_finish(const ContextAttnParams& p, int s, int h, int b, int li, const RopeRow& r)
+{
+    constexpr int LPR = DH / 8;
+    const int H = p.num_heads;
+    const bool valid = r.valid, has_row = r.has_row;
+    uint16_t *qp = r.qp, *kp = r.kp, *vp = r.vp;
+    uint4 q4 = r.q4, k4 = r.k4, v4 = r.v4;
     if (!valid)
     {
         // padding rows are zeroed (K/unfusedAttentionKernels.cu:1411-1423)
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const ContextAttnPar
             vc = reinterpret_cast<char*>(row[p.max_blocks_per_seq]) + off;
         }
         if (!mapped)
-            return;
+            return v4;
         if (p.int8_kv)
         {
             const float sc = p.kv_scale_orig_quant[0];
@@ -171,6 +188,67 @@ __global__ __launch_bounds__(256) void rope_kv_write_kernel(const ContextAttnPar
             *reinterpret_cast<uint4*>(kc) = k4;
             *reinterpret_cast<uint4*>(vc) = v4;
         }
+    }
+    return v4;
+}
+
+// grid (S, ceil(H / HG), B), 256 threads: DH/8 lanes own the 8-element pieces of one head of one token, HG = 256 / (DH/8)
+// heads per workgroup (one (token, head) per 64-thread workgroup with 16 active lanes took 19 us per layer at S = 1024).
+template <int DH>
+__global__ __launch_bounds__(256) void rope_kv_write_kernel(const ContextAttnParams p)
+{
+    constexpr int LPR = DH / 8, HG = 256 / LPR;
+    const int s = blockIdx.x, h = blockIdx.y * HG + threadIdx.x / LPR, b = blockIdx.z;
+    if (h >= p.num_heads) // whole lane groups (the shuffles stay inside a group)
+        return;
+    const int li = threadIdx.x % LPR;
+    const RopeRow r = rope_kv_load<DH>(p, s, h, b, li);
+    (void) rope_kv_finish<DH>(p, s, h, b, li, r);
+}
+
+// The same per-row work for a tile of 64 tokens of ONE head, plus the V^T image the MFMA kernel stages its PV operand from
+// ([B, H, DH, spad] fp16, keys contiguous; keys beyond the sequence are zero): the v values pass through an LDS tile and leave
+// transposed, so V is read once instead of by a transpose launch of its own (14.1 + 6.7 us per layer at S = 1024 before).
+// grid (spad / 64, H, B), 256 threads.
+template <int DH>
+__global__ __launch_bounds__(256) void rope_kv_vt_kernel(const ContextAttnParams p, int spad)
+{
+    constexpr int LPR = DH / 8, RPP = 256 / LPR; // token rows per pass
+    constexpr int PITCH = DH + 2;                // halfs; odd number of dwords -> the column reads below are conflict-free
+    __shared__ uint16_t tile[64 * PITCH];
+    const int kv0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int li = threadIdx.x % LPR;
+    constexpr int NP = 64 / RPP;
+    RopeRow rr[NP];
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) // every row's q / k / v requested before the first one is touched
+    {
+        const int s = kv0 + pass * RPP + threadIdx.x / LPR;
+        rr[pass] = rope_kv_load<DH>(p, s < p.seq ? s : p.seq - 1, h, b, li);
+    }
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass)
+    {
+        const int key = pass * RPP + threadIdx.x / LPR, s = kv0 + key;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (s < p.seq) // group-uniform
+            v = rope_kv_finish<DH>(p, s, h, b, li, rr[pass]);
+        uint32_t* d = reinterpret_cast<uint32_t*>(tile + key * PITCH + li * 8);
+        d[0] = v.x;
+        d[1] = v.y;
+        d[2] = v.z;
+        d[3] = v.w;
+    }
+    __syncthreads();
+    uint16_t* vt = reinterpret_cast<uint16_t*>(p.workspace) + ((int64_t) (b * p.num_heads + h) * DH) * spad + kv0;
+    for (int i = threadIdx.x; i < DH * 8; i += 256)
+    {
+        const int g = i % 8, d = i / 8; // 8 keys g * 8 .. + 8 of column d: eight consecutive lanes fill one 128-byte line of V^T
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            w[j] = (uint32_t) tile[(g * 8 + 2 * j) * PITCH + d] | ((uint32_t) tile[(g * 8 + 2 * j + 1) * PITCH + d] << 16);
+        *reinterpret_cast<uint4*>(vt + (int64_t) d * spad + g * 8) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 
@@ -553,11 +631,250 @@ __global__ __launch_bounds__(512) void context_attn_mfma_kernel(const ContextAtt
     }
 }
 
+// Key-split variant of the kernel above, the one launch_dh uses: 2 NQ compute waves (NQ = 4: two per SIMD), no loader waves.
+// Waves w and w + NQ serve the same 32 queries and split every 64-key block between them (keys 32 kh .. 32 kh + 31, kh = w / NQ):
+// per block each wave runs half the QK^T MFMAs, the softmax of 16 scores per lane and half the PV MFMAs on its own running
+// (m, l, O), so that one wave's MFMAs run under the other's softmax arithmetic on the same SIMD - with one compute wave per SIMD
+// the three stages were strictly serial (r02 ablation at S = 1024: 40 us = 23 us of VALU-only + 20 us of MFMA-only work on the
+// longest workgroup).  Each wave issues an eighth of the LDS-DMA pieces of the next block right after the barrier; the issue
+// stall is covered by the sibling wave.  The two partial results are merged once, after the last block, through LDS
+// (flash-decoding style: O = O0 a0 + O1 a1, l likewise, a = exp2((m_i - max) c2)).
+// Arithmetic: scores stay unscaled, p = exp2(s c2 - m c2) with c2 = scale log2(e) is one FMA + v_exp per score and the running
+// max is kept in score units (scale > 0, checked by the launcher); exp2(-inf) = 0 removes the masked scores without a select; the
+// mask runs only on the half-blocks that cross the diagonal; the accumulator rescale is skipped while no lane's maximum moved.
+// grid (H, ceil(S / (32 NQ)), B), 128 NQ threads; heads fastest, heavy (late) query blocks first: the dispatcher sees the longest
+// workgroups first and every query block of head h runs on XCD h mod 8, whose L2 serves that head's K / V^T tiles to all of them.
+template <int DH, int NQ>
+__global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const ContextAttnParams p, int spad)
+{
+    constexpr int NSUB = DH / 64;              // 128-byte sub-tiles of a K row
+    constexpr int KST = DH / 16;               // k-steps of the QK product
+    constexpr int DT = DH / 32;                // 32-row tiles of O^T / V^T
+    constexpr int K_BYTES = 64 * DH * 2;       // K tile  [NSUB][64][128 B]
+    constexpr int STAGE = K_BYTES + DH * 128;  // + V^T tile [DH][128 B]
+    constexpr int NWV = 2 * NQ;                // waves: NQ query slices of 32 x 2 key halves
+    constexpr int QB = 32 * NQ;                // queries per workgroup
+    constexpr int CHUNKS = STAGE / 1024, CPW = CHUNKS / NWV;
+    constexpr int SLAB = (2 + 16 * DT) * 64 * 4; // merge record of one wave: m, l, O per lane
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qs = wave % NQ, kh = wave / NQ; // query slice, key half
+    const int qb = gridDim.y - 1 - blockIdx.y, h = blockIdx.x, b = blockIdx.z;
+    const int H = p.num_heads, S = p.seq;
+    const int q0 = qb * QB + qs * 32; // first query of this wave
+    const int ql = lane & 31, hf = lane >> 5;
+    const int q = q0 + ql;
+    const int len = p.input_lengths[b];
+    const int64_t rs = (int64_t) 3 * H * DH * 2; // bytes per token row of the fused QKV buffer
+    const char* qkv = reinterpret_cast<const char*>(p.qkv) + seq_row0(p, b) * rs;
+    const int nrows = p.cu_seqlens ? len : S; // token rows of this sequence that exist in the buffers
+    const char* vt = reinterpret_cast<const char*>(p.workspace) + ((int64_t) (b * H + h) * DH) * spad * 2;
+
+    // Q fragments (B operand): lane (q, half) holds d = 16 s + 8 half .. + 8 for every k-step s
+    uint4 qf[KST];
+    {
+        const char* qrow = qkv + (int64_t) (q < nrows ? q : nrows - 1) * rs + (int64_t) h * DH * 2;
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+            qf[s] = *reinterpret_cast<const uint4*>(qrow + (16 * s + 8 * hf) * 2);
+    }
+
+    if (qb * QB >= nrows) // packed inputs: this query block lies entirely beyond the sequence (block-uniform)
+        return;
+    const int kv_end = (qb * QB + QB < nrows ? qb * QB + QB : nrows); // causal: keys <= the block's last query
+    const int nkb = (kv_end + 63) / 64;
+    const uint32_t lds_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void*) lds;
+    auto issue = [&](int t) {
+        const int kv0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < CPW; ++i)
+        {
+            const int c = i * NWV + wave;
+            const int r8 = lane >> 3;
+            const char* src;
+            if (c < 8 * NSUB)
+            {
+                const int sub = c / 8, row = (c % 8) * 8 + r8;
+                const int col = (lane & 7) ^ ((row >> 1) & 7);
+                const int key = kv0 + row < nrows ? kv0 + row : nrows - 1;
+                src = qkv + (int64_t) key * rs + (int64_t) (H + h) * DH * 2 + sub * 128 + col * 16;
+            }
+            else
+            {
+                const int d = (c - 8 * NSUB) * 8 + r8;
+                const int col = (lane & 7) ^ ((d >> 1) & 7);
+                src = vt + ((int64_t) d * spad + kv0) * 2 + col * 16;
+            }
+            glds16(src, lds_base + (t & 1) * STAGE + c * 1024);
+        }
+    };
+    f32x16_t oacc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            oacc[i][r] = 0.f;
+    float m = -INFINITY, l = 0.f; // m in units of the unscaled score
+    const float c2 = p.inv_sqrt_dh * 1.4426950408889634f;
+    const int krow = (ql & ~12) | ((ql & 4) << 1) | ((ql & 8) >> 1); // pi(ql): bits 2 and 3 swapped
+
+    issue(0);
+    for (int t = 0; t < nkb; ++t)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of block t (and, the first time, its Q fragments)
+        __syncthreads(); // block t is in LDS for everybody; everybody is done with block t - 1
+        const bool more = t + 1 < nkb; // block t + 1 goes into the stage block t - 1 occupied
+        const int kb0 = t * 64 + 32 * kh; // first key of this wave's half-block
+        if (more)
+            issue(t + 1); // right behind the barrier: between the MFMAs (+4.5 us), behind them (+2.8) or inside the softmax (+1) all lost
+        if (kb0 > q0 + 31) // every key of it lies in the future of every query of this wave (wave-uniform)
+            continue;
+        const char* Ks = lds + (t & 1) * STAGE;
+        const char* Vs = Ks + K_BYTES;
+        f32x16_t sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+        {
+            const uint4 kk = *reinterpret_cast<const uint4*>(Ks + (s >> 2) * (64 * 128) + swz128(kh * 32 + krow, (2 * s + hf) & 7));
+            f16x8_t ak, bq;
+            __builtin_memcpy(&ak, &kk, 16);
+            __builtin_memcpy(&bq, &qf[s], 16);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ak, bq, sacc, 0, 0, 0);
+        }
+        if (kb0 + 31 > q0) // wave-uniform: the half-block crosses the diagonal for some query of this wave
+        {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+            {
+                const int key = kb0 + 16 * (r >> 3) + 8 * hf + (r & 7);
+                sacc[r] = key <= q ? sacc[r] : -INFINITY;
+            }
+        }
+        float mt = sacc[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r)
+            mt = fmaxf(mt, sacc[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        // a query whose keys in this half-block are all masked (the first half-blocks of the diagonal) keeps m = -inf: its p
+        // must be 0, not exp2(-inf + inf)
+        const float mn = fmaxf(m, mt);
+        const float alpha = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m - mn) * c2);
+        m = mn;
+        const float mc = (mn == -INFINITY) ? 0.f : -mn * c2;
+        l *= alpha;
+        if (!__all(alpha == 1.f)) // wave-uniform
+        {
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    oacc[i][r] *= alpha;
+        }
+        // probabilities -> fp16 B fragments (8 consecutive keys per register octet), PV product over this wave's 32 keys
+#pragma unroll
+        for (int s2l = 0; s2l < 2; ++s2l)
+        {
+            f16x8_t bp;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+            {
+                const float pr = __builtin_amdgcn_exp2f(fmaf(sacc[8 * s2l + j], c2, mc));
+                l += pr;
+                bp[j] = (_Float16) pr;
+            }
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+            {
+                const uint4 vv = *reinterpret_cast<const uint4*>(Vs + swz128(i * 32 + ql, 2 * (2 * kh + s2l) + hf));
+                f16x8_t av;
+                __builtin_memcpy(&av, &vv, 16);
+                oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bp, oacc[i], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- merge the key halves: wave (qs, 1) hands (m, l, O) to wave (qs, 0), lane to lane
+    __syncthreads(); // every wave is done with the operand stages
+    float* slab = reinterpret_cast<float*>(lds + qs * SLAB);
+    if (kh == 1)
+    {
+        slab[lane] = m;
+        slab[64 + lane] = l;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                slab[(2 + 16 * i + r) * 64 + lane] = oacc[i][r];
+    }
+    __syncthreads();
+    if (kh == 1)
+        return;
+    {
+        const float m1 = slab[lane], l1 = slab[64 + lane];
+        const float mn = fmaxf(m, m1); // m is finite: block 0 holds key 0 of every query
+        const float a0 = __builtin_amdgcn_exp2f((m - mn) * c2);
+        const float a1 = (m1 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m1 - mn) * c2);
+        l = l * a0 + l1 * a1;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                oacc[i][r] = oacc[i][r] * a0 + slab[(2 + 16 * i + r) * 64 + lane] * a1;
+    }
+
+    // ---- normalise, transpose through LDS (inside this wave's own slab, read completely above), store whole rows
+    l += __shfl_xor(l, 32, 64);
+    const float inv = (q < len) ? 1.f / (l + 1.e-6f) : 0.f; // padding queries produce zero rows
+    constexpr int PITCH = DH * 2 + 16;
+    static_assert(32 * PITCH <= SLAB, "the output scratch must fit the wave's slab");
+    char* scr = lds + qs * SLAB;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+        {
+            const uint32_t w0 = pack_h2(oacc[i][4 * g] * inv, oacc[i][4 * g + 1] * inv);
+            const uint32_t w1 = pack_h2(oacc[i][4 * g + 2] * inv, oacc[i][4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(scr + ql * PITCH + (32 * i + 8 * g + 4 * hf) * 2) = make_uint2(w0, w1);
+        }
+    constexpr int PPR = DH / 8; // 16-byte pieces per output row
+    uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) + seq_row0(p, b) * H * DH + (int64_t) h * DH;
+#pragma unroll
+    for (int i = lane; i < 32 * PPR; i += 64)
+    {
+        const int row = i / PPR, pc = i % PPR;
+        const uint4 v = *reinterpret_cast<const uint4*>(scr + row * PITCH + pc * 16);
+        if (q0 + row < nrows)
+        {
+            if (p.out_q8) // uniform: the static quantiser of the O-projection's input, on the fp16-rounded values
+            {
+                const float qsc = p.out_q_scale[0];
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+                uint32_t o2[2] = {0, 0};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                {
+                    const uint32_t b0 = (uint8_t) f2i8_rni_sat(h2f((uint16_t) (w4[e] & 0xffffu)) * qsc);
+                    const uint32_t b1 = (uint8_t) f2i8_rni_sat(h2f((uint16_t) (w4[e] >> 16)) * qsc);
+                    o2[e >> 1] |= (b0 | (b1 << 8)) << (16 * (e & 1));
+                }
+                int8_t* qp = p.out_q8 + (seq_row0(p, b) + q0 + row) * (int64_t) H * DH + (int64_t) h * DH + pc * 8;
+                *reinterpret_cast<uint2*>(qp) = make_uint2(o2[0], o2[1]);
+            }
+            else
+                *reinterpret_cast<uint4*>(outp + (int64_t) (q0 + row) * H * DH + pc * 8) = v;
+        }
+    }
+}
+
 template <int DH>
 int launch_dh(const ContextAttnParams& p, hipStream_t stream)
 {
     constexpr int HG = 256 / (DH / 8);
-    hipLaunchKernelGGL((rope_kv_write_kernel<DH>), dim3(p.seq, (p.num_heads + HG - 1) / HG, p.batch), dim3(256), 0, stream, p);
     bool mfma = false;
     if constexpr (DH == 64 || DH == 128)
     {
@@ -565,21 +882,49 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
         {
             mfma = true;
             const int spad = (p.seq + 63) / 64 * 64;
-            hipLaunchKernelGGL((v_transpose_kernel<DH>), dim3(spad / 64, p.num_heads, p.batch), dim3(256), 0, stream, p, spad);
-            constexpr size_t smem = 2 * (size_t) (64 * DH * 2 + DH * 128);
-            auto kfn = context_attn_mfma_kernel<DH>;
-            static std::atomic<bool> attr_done{false};
-            if (!attr_done)
+            static const bool unfused_vt = getenv("TLLM_CTX_ATTN_UNFUSED_VT") != nullptr; // A/B switch
+            if (unfused_vt)
             {
-                if (smem > 64 * 1024)
-                    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
-                attr_done = true;
+                hipLaunchKernelGGL((rope_kv_write_kernel<DH>), dim3(p.seq, (p.num_heads + HG - 1) / HG, p.batch), dim3(256), 0, stream, p);
+                hipLaunchKernelGGL((v_transpose_kernel<DH>), dim3(spad / 64, p.num_heads, p.batch), dim3(256), 0, stream, p, spad);
             }
-            hipLaunchKernelGGL(kfn, dim3((p.seq + 127) / 128, p.num_heads, p.batch), dim3(512), smem, stream, p, spad);
+            else
+                hipLaunchKernelGGL((rope_kv_vt_kernel<DH>), dim3(spad / 64, p.num_heads, p.batch), dim3(256), 0, stream, p, spad);
+            static const bool old_kernel = getenv("TLLM_CTX_ATTN_OLD") != nullptr; // A/B switch: the 4 + 4 wave kernel
+            static std::atomic<bool> attr_done{false};
+            if (old_kernel || !(p.inv_sqrt_dh > 0.f))
+            {
+                constexpr size_t smem = 2 * (size_t) (64 * DH * 2 + DH * 128);
+                auto kfn = context_attn_mfma_kernel<DH>;
+                hipLaunchKernelGGL(kfn, dim3((p.seq + 127) / 128, p.num_heads, p.batch), dim3(512), smem, stream, p, spad);
+            }
+            else
+            {
+                // 64-query workgroups while 128-query ones would not fill the chip (TLLM_CTX_ATTN_NQ overrides: A/B switch)
+                static const int nq_env = getenv("TLLM_CTX_ATTN_NQ") ? atoi(getenv("TLLM_CTX_ATTN_NQ")) : 0;
+                const bool narrow = nq_env ? nq_env == 2 : (int64_t) ((p.seq + 127) / 128) * p.num_heads * p.batch < 256;
+                constexpr size_t stages = 2 * (size_t) (64 * DH * 2 + DH * 128), slab = (size_t) (2 + 16 * (DH / 32)) * 64 * 4;
+                const size_t smem = stages > (narrow ? 2 : 4) * slab ? stages : 4 * slab;
+                auto kfn = narrow ? context_attn_mfma_ks_kernel<DH, 2> : context_attn_mfma_ks_kernel<DH, 4>;
+                if (!attr_done)
+                {
+                    if (stages > 64 * 1024 || 4 * slab > 64 * 1024)
+                    {
+                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                    }
+                    attr_done = true;
+                }
+                const int qbw = narrow ? 64 : 128;
+                hipLaunchKernelGGL(kfn, dim3(p.num_heads, (p.seq + qbw - 1) / qbw, p.batch), dim3(narrow ? 256 : 512), smem, stream, p, spad);
+            }
         }
     }
     if (!mfma)
     {
+        hipLaunchKernelGGL((rope_kv_write_kernel<DH>), dim3(p.seq, (p.num_heads + HG - 1) / HG, p.batch), dim3(256), 0, stream, p);
         hipLaunchKernelGGL((context_attn_kernel<DH>), dim3((p.seq + 3) / 4, p.num_heads, p.batch), dim3(256), 0, stream, p);
         if (p.out_q8) // the quantiser as a pass of its own behind this kernel
         {
