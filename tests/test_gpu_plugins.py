@@ -106,6 +106,35 @@ def test_rmsnorm_quantization(dyn):
 
 
 @pytest.mark.parametrize('dyn', [0, 1])
+@pytest.mark.parametrize('shape', [(1024, 4096), (7, 2048), (3, 5120), (5, 72)])
+def test_rmsnorm_register_kernel_is_bit_identical_to_the_lds_row_kernel(dyn, shape, monkeypatch):
+    """Rows of at most 8192 elements take the register-resident kernel (rmsnorm_reg_kernel, the prefill's shape); it keeps
+    the arithmetic order of the LDS-row kernel, so y, q and the per-token scales are the same bits (TLLM_RMSNORM_LDS=1 is
+    the A/B switch)."""
+    r = rng(40 + shape[1])
+    x = h(r.standard_normal(shape) * 2)
+    g = h(1 + 0.1 * r.uniform(-1, 1, shape[-1]))
+    scale = torch.tensor([23.5], dtype=torch.float32, device='cuda')
+    res = {}
+    for tag in ('reg', 'lds'):
+        if tag == 'lds':
+            monkeypatch.setenv('TLLM_RMSNORM_LDS', '1')
+        else:
+            monkeypatch.delenv('TLLM_RMSNORM_LDS', raising=False)
+        y = torch.empty_like(x)
+        run_plugin(make_plugin('Rmsnorm', [('eps', f32(1e-6)), ('type_id', i32([capi.HALF]))]), [x, g], [y])
+        q = torch.empty(shape, dtype=torch.int8, device='cuda')
+        outs = [q]
+        if dyn:
+            outs.append(torch.empty(shape[:-1] + (1, ), dtype=torch.float32, device='cuda'))
+        run_plugin(make_plugin('RmsnormQuantization', [('eps', f32(1e-6)), ('dyn_act_scaling', i32([dyn])),
+                                                       ('type_id', i32([capi.HALF]))]), [x, g, scale], outs)
+        res[tag] = [y.cpu().numpy().view(np.uint16)] + [o.cpu().numpy() for o in outs]
+    for a, b in zip(res['reg'], res['lds']):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize('dyn', [0, 1])
 @pytest.mark.parametrize('diff_sq', [0, 1])
 @pytest.mark.parametrize('shape', [(5, 768), (3, 4096), (2, 100)])
 def test_layernorm_quantization(dyn, diff_sq, shape):

@@ -4,6 +4,7 @@
 #include "dev_utils.h"
 #include "kernels.h"
 #include <atomic>
+#include <cstdlib>
 
 namespace tllm
 {
@@ -171,6 +172,127 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const RmsnormParams p)
     {
         for (int k = tid; k < N; k += 256)
             q[k] = f2i8_rni_sat(h2f(row[k]) * qs);
+    }
+}
+
+// The RMSNorm flavour of the kernel above for vector rows of at most 2048 NV elements (LLaMA-7B: NV = 2), the prefill's shape
+// ([tokens, hidden], one launch in front of the QKV GEMM and one in front of the MLP GEMMs of every layer).  Same arithmetic in
+// the same order - per-thread partial sums over ascending k, the same block reductions, the same rounding points - so the two
+// kernels are bit-identical; what differs is the data path: the row stays in registers instead of LDS, and gamma (and the
+// static scale) are requested together with the row, not after the reduction (there the gamma load was a second, dependent
+// round trip on every row: 7.6 us per launch at [1024, 4096] for 12 MB of traffic).
+template <int NV>
+__global__ __launch_bounds__(256) void rmsnorm_reg_kernel(const RmsnormParams p)
+{
+    __shared__ float red[32];
+    const int m = blockIdx.x, tid = threadIdx.x, N = p.N;
+    const uint16_t* x = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * N;
+    const uint16_t* res = p.residual ? reinterpret_cast<const uint16_t*>(p.residual) + (int64_t) m * N : nullptr;
+    uint16_t* so = p.sum_out ? reinterpret_cast<uint16_t*>(p.sum_out) + (int64_t) m * N : nullptr;
+    const uint16_t* g = reinterpret_cast<const uint16_t*>(p.gamma);
+    uint4 xv[NV], rv[NV], gv[NV];
+    // every request of this thread before the first value is looked at; vectors beyond N read a clamped address and are dropped
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+    {
+        const int k = (tid + j * 256) * 8;
+        const int kc = k < N ? k : N - 8;
+        xv[j] = *reinterpret_cast<const uint4*>(x + kc);
+        rv[j] = res ? *reinterpret_cast<const uint4*>(res + kc) : make_uint4(0, 0, 0, 0);
+        gv[j] = *reinterpret_cast<const uint4*>(g + kc);
+    }
+    const float qs_static = (p.q && !p.dyn_scale_out) ? p.static_scale[0] : 0.f;
+    auto unpack = [](const uint4& v, uint16_t* e) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+        {
+            e[2 * j] = (uint16_t) (w[j] & 0xffffu);
+            e[2 * j + 1] = (uint16_t) (w[j] >> 16);
+        }
+    };
+    auto pack = [](const uint16_t* e) {
+        return make_uint4(e[0] | ((uint32_t) e[1] << 16), e[2] | ((uint32_t) e[3] << 16), e[4] | ((uint32_t) e[5] << 16),
+            e[6] | ((uint32_t) e[7] << 16));
+    };
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+    {
+        const int k = (tid + j * 256) * 8;
+        if (k < N)
+        {
+            uint16_t e[8], r[8];
+            unpack(xv[j], e);
+            if (res)
+            {
+                unpack(rv[j], r);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    e[i] = f2h(h2f(e[i]) + h2f(r[i]));
+                xv[j] = pack(e);
+                *reinterpret_cast<uint4*>(so + k) = xv[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+            {
+                const float f = h2f(e[i]);
+                ss += f * f;
+            }
+        }
+    }
+    ss = block_sum(ss, red);
+    const float inv = 1.0f / sqrtf(ss / (float) N + p.eps);
+    uint16_t* y = p.y ? reinterpret_cast<uint16_t*>(p.y) + (int64_t) m * N : nullptr;
+    int8_t* q = p.q ? p.q + (int64_t) m * N : nullptr;
+    float amax = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+    {
+        const int k = (tid + j * 256) * 8;
+        if (k < N)
+        {
+            uint16_t e[8], ge[8];
+            unpack(xv[j], e);
+            unpack(gv[j], ge);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+            {
+                e[i] = f2h(h2f(f2h(h2f(e[i]) * inv)) * h2f(ge[i]));
+                amax = fmaxf(amax, fabsf(h2f(e[i])));
+            }
+            xv[j] = pack(e);
+            if (y)
+                *reinterpret_cast<uint4*>(y + k) = xv[j];
+        }
+    }
+    if (!q)
+        return;
+    float qs;
+    if (p.dyn_scale_out)
+    {
+        amax = block_max(amax, red);
+        amax = fmaxf(amax, h2f(f2h(1e-6f)));
+        qs = 127.f / amax;
+        if (tid == 0)
+            p.dyn_scale_out[m] = amax / 127.f;
+    }
+    else
+        qs = qs_static;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+    {
+        const int k = (tid + j * 256) * 8;
+        if (k < N)
+        {
+            uint16_t e[8];
+            unpack(xv[j], e);
+            uint32_t o[2] = {0, 0};
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                o[i >> 2] |= ((uint32_t) (uint8_t) f2i8_rni_sat(h2f(e[i]) * qs)) << (8 * (i & 3));
+            *reinterpret_cast<uint2*>(q + k) = make_uint2(o[0], o[1]);
+        }
     }
 }
 
@@ -747,7 +869,17 @@ int launch_rmsnorm(const RmsnormParams& p, hipStream_t stream)
         set_error("layernorm: bias is required");
         return -1;
     }
-    if (vec)
+    const bool no_reg = getenv("TLLM_RMSNORM_LDS") != nullptr; // A/B switch (read per launch): the LDS-row kernel for every shape
+    if (vec && !p.layernorm && !no_reg && p.N >= 8 && p.N <= 2048 * 4)
+    {
+        if (p.N <= 2048)
+            hipLaunchKernelGGL(rmsnorm_reg_kernel<1>, dim3(p.M), dim3(256), 0, stream, p);
+        else if (p.N <= 4096)
+            hipLaunchKernelGGL(rmsnorm_reg_kernel<2>, dim3(p.M), dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL(rmsnorm_reg_kernel<4>, dim3(p.M), dim3(256), 0, stream, p);
+    }
+    else if (vec)
         hipLaunchKernelGGL(rmsnorm_kernel<8>, dim3(p.M), dim3(256), smem, stream, p);
     else
         hipLaunchKernelGGL(rmsnorm_kernel<1>, dim3(p.M), dim3(256), smem, stream, p);
