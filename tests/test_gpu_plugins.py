@@ -489,7 +489,10 @@ def test_kv_cache_append_bit_exact(int8_kv):
 @pytest.mark.parametrize('int8_kv', [0, 1])
 @pytest.mark.parametrize('H,Dh,S', [(4, 128, 90), (2, 32, 128), (4, 64, 33), (4, 128, 300), (2, 64, 257), (2, 128, 1024),
                                     # block boundaries of the MFMA kernel (64-key blocks, 128-query workgroups) and n_positions
-                                    (2, 128, 64), (2, 128, 65), (2, 64, 127), (2, 128, 129), (1, 128, 2048)])
+                                    (2, 128, 64), (2, 128, 65), (2, 64, 127), (2, 128, 129), (1, 128, 2048),
+                                    # >= 256 workgroups: the 8-wave kernel with paired 64-query blocks (16 blocks; 15 blocks: the
+                                    # middle one has no partner; 13 blocks with a ragged last one)
+                                    (16, 128, 1024), (16, 128, 960), (32, 128, 400), (32, 128, 1024)])
 def test_context_attention_vs_oracle(int8_kv, H, Dh, S):
     r = rng(200 + S)
     B, smax = 2, S + 8
@@ -520,8 +523,11 @@ def test_context_attention_vs_oracle(int8_kv, H, Dh, S):
 
 
 @pytest.mark.parametrize('int8_kv', [0, 1])
-@pytest.mark.parametrize('H,Dh,S', [(4, 128, 200), (2, 64, 70), (2, 32, 40)])
-def test_packed_context_attention_equals_padded(int8_kv, H, Dh, S):
+@pytest.mark.parametrize('H,Dh,S,paired', [(4, 128, 200, 0), (2, 64, 70, 0), (2, 32, 40, 0), (32, 128, 1000, 0), (32, 128, 1000, 1),
+                                           (4, 128, 200, 1), (4, 64, 333, 1)])
+def test_packed_context_attention_equals_padded(int8_kv, H, Dh, S, paired, monkeypatch):
+    if paired:  # the paired-block kernel whatever the workgroup count (by default only when the launch is one round)
+        monkeypatch.setenv('TLLM_CTX_ATTN_PAIRED', '1')
     """remove_input_padding (gptAttentionPlugin.cpp:344-356): the tokens of all sequences back to back in [1, T, 3 D];
     the plugin must produce, for every real token, what the padded run produces, and the same KV cache."""
     r = rng(300 + S)

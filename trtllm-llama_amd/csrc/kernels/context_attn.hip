@@ -644,9 +644,18 @@ __global__ __launch_bounds__(512) void context_attn_mfma_kernel(const ContextAtt
 // mask runs only on the half-blocks that cross the diagonal; the accumulator rescale is skipped while no lane's maximum moved.
 // grid (H, ceil(S / (32 NQ)), B), 128 NQ threads; heads fastest, heavy (late) query blocks first: the dispatcher sees the longest
 // workgroups first and every query block of head h runs on XCD h mod 8, whose L2 serves that head's K / V^T tiles to all of them.
-template <int DH, int NQ>
+//
+// PAIR (NQ = 4 only): the workgroup serves TWO 64-query blocks instead of one 128-query block - the heaviest remaining one
+// (block nblk - 1 - y: nblk - y key blocks) on query slices 0 / 1 and the lightest (block y: y + 1 key blocks) on slices 2 / 3 -
+// over the same K / V^T stages.  With one 128-query workgroup per CU (256 workgroups at S = 1024 and 32 heads: exactly one
+// round) the launch lasted as long as its last query block (16 key blocks) while the CU of the first one was done after 2;
+// paired, every workgroup runs nblk + 1 half-blocks of work.  The light slices fall out of the loop body through the causal
+// skip that was there already (they still arrive at the barriers), and the waves are dealt so that every SIMD hosts one
+// heavy and one light wave: wave kh * 4 + s takes slice s (kh = 0) or slice (s + 2) % 4 (kh = 1).
+template <int DH, int NQ, bool PAIR = false>
 __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const ContextAttnParams p, int spad)
 {
+    static_assert(!PAIR || NQ == 4, "pairing deals four query slices");
     constexpr int NSUB = DH / 64;              // 128-byte sub-tiles of a K row
     constexpr int KST = DH / 16;               // k-steps of the QK product
     constexpr int DT = DH / 32;                // 32-row tiles of O^T / V^T
@@ -659,10 +668,16 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int qs = wave % NQ, kh = wave / NQ; // query slice, key half
-    const int qb = gridDim.y - 1 - blockIdx.y, h = blockIdx.x, b = blockIdx.z;
+    const int kh = wave / NQ;                                     // key half
+    const int qs = (PAIR && kh) ? (wave + 2) % NQ : wave % NQ;    // query slice
+    const int h = blockIdx.x, b = blockIdx.z;
     const int H = p.num_heads, S = p.seq;
-    const int q0 = qb * QB + qs * 32; // first query of this wave
+    // PAIR: 64-query blocks, heavy = the y-th from the end (slices 0 / 1), light = the y-th from the start (slices 2 / 3; nobody
+    // when the two meet in the middle block of an odd count)
+    const int nblk64 = (S + 63) / 64;
+    const int heavy = PAIR ? nblk64 - 1 - (int) blockIdx.y : 0, light = PAIR ? (int) blockIdx.y : 0;
+    const int qb = PAIR ? heavy : gridDim.y - 1 - blockIdx.y; // the block that sets this workgroup's key range
+    const int q0 = PAIR ? (qs < 2 ? heavy : light) * 64 + (qs & 1) * 32 : qb * QB + qs * 32; // first query of this wave
     const int ql = lane & 31, hf = lane >> 5;
     const int q = q0 + ql;
     const int len = p.input_lengths[b];
@@ -680,17 +695,42 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
             qf[s] = *reinterpret_cast<const uint4*>(qrow + (16 * s + 8 * hf) * 2);
     }
 
-    if (qb * QB >= nrows) // packed inputs: this query block lies entirely beyond the sequence (block-uniform)
-        return;
-    const int kv_end = (qb * QB + QB < nrows ? qb * QB + QB : nrows); // causal: keys <= the block's last query
+    bool valid = true; // this wave's slice exists (PAIR: wave-uniform; else block-uniform and handled by the return below)
+    int kv_end;
+    if constexpr (PAIR)
+    {
+        // packed inputs: blocks beyond this sequence do not exist - the key range is that of the heaviest block that does
+        const int top = heavy * 64 < nrows ? heavy : (light * 64 < nrows ? light : -1);
+        if (top < 0) // block-uniform
+            return;
+        valid = q0 < nrows && !(qs >= 2 && light == heavy);
+        kv_end = top * 64 + 64 < nrows ? top * 64 + 64 : nrows;
+    }
+    else
+    {
+        if (qb * QB >= nrows) // packed inputs: this query block lies entirely beyond the sequence (block-uniform)
+            return;
+        kv_end = (qb * QB + QB < nrows ? qb * QB + QB : nrows); // causal: keys <= the block's last query
+    }
     const int nkb = (kv_end + 63) / 64;
     const uint32_t lds_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void*) lds;
+    // PAIR: once the light block's last key block is behind (t > light: all four light waves skip the body from there on) its
+    // waves take over the whole LDS-DMA issue - an instruction holds its issuer for 100 - 185 cycles, and from that point the
+    // heavy waves are alone on their SIMDs with nothing to cover it
+    const bool is_light = PAIR && qs >= 2;
+    const int li = (qs - 2) * 2 + kh; // 0 .. 3 among the light waves
     auto issue = [&](int t) {
         const int kv0 = t * 64;
+        const bool handed = PAIR && (t - 1 > light || light == heavy); // block t is issued at step t - 1 (workgroup-uniform)
+        if (handed && !is_light)
+            return;
+        constexpr int NI = PAIR ? 2 * CPW : CPW;
 #pragma unroll
-        for (int i = 0; i < CPW; ++i)
+        for (int i = 0; i < NI; ++i)
         {
-            const int c = i * NWV + wave;
+            if (i >= CPW && !handed)
+                break;
+            const int c = handed ? i * 4 + li : i * NWV + wave;
             const int r8 = lane >> 3;
             const char* src;
             if (c < 8 * NSUB)
@@ -728,14 +768,16 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
         const int kb0 = t * 64 + 32 * kh; // first key of this wave's half-block
         if (more)
             issue(t + 1); // right behind the barrier: between the MFMAs (+4.5 us), behind them (+2.8) or inside the softmax (+1) all lost
-        if (kb0 > q0 + 31) // every key of it lies in the future of every query of this wave (wave-uniform)
+        if (kb0 > q0 + 31 || !valid) // every key of it lies in the future of every query of this wave (wave-uniform)
             continue;
         const char* Ks = lds + (t & 1) * STAGE;
         const char* Vs = Ks + K_BYTES;
-        f32x16_t sacc;
+        // two accumulators (even / odd k-steps): eight MFMAs into one are a chain of eight result latencies, and once the light
+        // waves have dropped out (PAIR) or the sibling sits at the barrier nothing else runs on this SIMD
+        f32x16_t sacc, sacc1;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            sacc[r] = 0.f;
+            sacc[r] = 0.f, sacc1[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KST; ++s)
         {
@@ -743,8 +785,14 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
             f16x8_t ak, bq;
             __builtin_memcpy(&ak, &kk, 16);
             __builtin_memcpy(&bq, &qf[s], 16);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ak, bq, sacc, 0, 0, 0);
+            if (s & 1)
+                sacc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ak, bq, sacc1, 0, 0, 0);
+            else
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ak, bq, sacc, 0, 0, 0);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            sacc[r] += sacc1[r];
         if (kb0 + 31 > q0) // wave-uniform: the half-block crosses the diagonal for some query of this wave
         {
 #pragma unroll
@@ -811,7 +859,7 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
                 slab[(2 + 16 * i + r) * 64 + lane] = oacc[i][r];
     }
     __syncthreads();
-    if (kh == 1)
+    if (kh == 1 || !valid)
         return;
     {
         const float m1 = slab[lane], l1 = slab[64 + lane];
@@ -902,10 +950,32 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
             {
                 // 64-query workgroups while 128-query ones would not fill the chip (TLLM_CTX_ATTN_NQ overrides: A/B switch)
                 static const int nq_env = getenv("TLLM_CTX_ATTN_NQ") ? atoi(getenv("TLLM_CTX_ATTN_NQ")) : 0;
-                const bool narrow = nq_env ? nq_env == 2 : (int64_t) ((p.seq + 127) / 128) * p.num_heads * p.batch < 256;
+                bool narrow = nq_env ? nq_env == 2 : (int64_t) ((p.seq + 127) / 128) * p.num_heads * p.batch < 256;
                 constexpr size_t stages = 2 * (size_t) (64 * DH * 2 + DH * 128), slab = (size_t) (2 + 16 * (DH / 32)) * 64 * 4;
+                // Paired 64-query blocks while the launch is at most ONE round of 128-query workgroups (32 heads, r02,
+                // profiles/r02_ctx_attn_pairing.txt: S = 1024, 256 workgroups on 256 CUs, 31.9 -> 26.8 us; S = 896 / 768 / 512 / 384 /
+                // 256, where the unpaired choice is the 64-query kernel, 28.0 -> 24.1, 24.5 -> 21.0, 18.5 -> 16.4, 15.8 -> 14.3,
+                // 12.5 -> 12.0): with more workgroups than CUs the dispatcher already back-fills the CUs of the short blocks and
+                // pairing only makes every workgroup long (S = 1536: 44 -> 58 us, S = 2048: 61.6 -> 72.4).
+                // TLLM_CTX_ATTN_UNPAIRED / TLLM_CTX_ATTN_PAIRED force either way (A/B, tests).
+                const bool unpaired = getenv("TLLM_CTX_ATTN_UNPAIRED") != nullptr, force_pair = getenv("TLLM_CTX_ATTN_PAIRED") != nullptr; // read per launch
+                static std::atomic<int> cus_cache{0};
+                int cus = cus_cache.load();
+                if (!cus)
+                {
+                    int dev = 0;
+                    (void) hipGetDevice(&dev);
+                    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                        cus = 256;
+                    cus_cache.store(cus);
+                }
+                const int64_t wg128 = (int64_t) ((p.seq + 127) / 128) * p.num_heads * p.batch;
+                const bool pair = !unpaired && !nq_env && (force_pair || (wg128 <= cus && 4 * wg128 >= cus));
+                if (pair)
+                    narrow = false;
                 const size_t smem = stages > (narrow ? 2 : 4) * slab ? stages : 4 * slab;
-                auto kfn = narrow ? context_attn_mfma_ks_kernel<DH, 2> : context_attn_mfma_ks_kernel<DH, 4>;
+                auto kfn = narrow ? context_attn_mfma_ks_kernel<DH, 2>
+                                  : (pair ? context_attn_mfma_ks_kernel<DH, 4, true> : context_attn_mfma_ks_kernel<DH, 4>);
                 if (!attr_done)
                 {
                     if (stages > 64 * 1024 || 4 * slab > 64 * 1024)
@@ -914,10 +984,13 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                         (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                     }
                     attr_done = true;
                 }
                 const int qbw = narrow ? 64 : 128;
+                // paired: ceil(nblk64 / 2) workgroups per head - the same count as 128-query blocks
                 hipLaunchKernelGGL(kfn, dim3(p.num_heads, (p.seq + qbw - 1) / qbw, p.batch), dim3(narrow ? 256 : 512), smem, stream, p, spad);
             }
         }
