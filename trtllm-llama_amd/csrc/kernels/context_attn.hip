@@ -652,7 +652,12 @@ __global__ __launch_bounds__(512) void context_attn_mfma_kernel(const ContextAtt
 // paired, every workgroup runs nblk + 1 half-blocks of work.  The light slices fall out of the loop body through the causal
 // skip that was there already (they still arrive at the barriers), and the waves are dealt so that every SIMD hosts one
 // heavy and one light wave: wave kh * 4 + s takes slice s (kh = 0) or slice (s + 2) % 4 (kh = 1).
-template <int DH, int NQ, bool PAIR = false>
+//
+// RING: three operand stages instead of two - block t + 2 is requested at step t, so TWO blocks are in flight and the wait in
+// front of the barrier is a counted one (the pieces this wave issued for block t + 1 stay outstanding).  With two stages the
+// launch could not be shorter than its chain of request -> landing latencies: the paired kernel with its arithmetic removed
+// (DMA, waits and barriers only) still took 22 of its 27 us at S = 1024 (profiles/r02_ctx_attn_pairing.txt, box D).
+template <int DH, int NQ, bool PAIR = false, bool RING = false>
 __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const ContextAttnParams p, int spad)
 {
     static_assert(!PAIR || NQ == 4, "pairing deals four query slices");
@@ -719,9 +724,14 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
     // heavy waves are alone on their SIMDs with nothing to cover it
     const bool is_light = PAIR && qs >= 2;
     const int li = (qs - 2) * 2 + kh; // 0 .. 3 among the light waves
+    constexpr int AHEAD = RING ? 2 : 1; // block t is requested at step t - AHEAD
+    auto stage_of = [&](int t) { return RING ? t % 3 : (t & 1); };
+    auto handed_at = [&](int t) { return PAIR && (t - AHEAD > light || light == heavy); }; // workgroup-uniform
+    // LDS-DMA pieces THIS wave issues for block t
+    auto pieces_of = [&](int t) { return t >= nkb ? 0 : (handed_at(t) ? (is_light ? 2 * CPW : 0) : CPW); };
     auto issue = [&](int t) {
         const int kv0 = t * 64;
-        const bool handed = PAIR && (t - 1 > light || light == heavy); // block t is issued at step t - 1 (workgroup-uniform)
+        const bool handed = handed_at(t);
         if (handed && !is_light)
             return;
         constexpr int NI = PAIR ? 2 * CPW : CPW;
@@ -746,7 +756,7 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
                 const int col = (lane & 7) ^ ((d >> 1) & 7);
                 src = vt + ((int64_t) d * spad + kv0) * 2 + col * 16;
             }
-            glds16(src, lds_base + (t & 1) * STAGE + c * 1024);
+            glds16(src, lds_base + stage_of(t) * STAGE + c * 1024);
         }
     };
     f32x16_t oacc[DT];
@@ -759,18 +769,39 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
     const float c2 = p.inv_sqrt_dh * 1.4426950408889634f;
     const int krow = (ql & ~12) | ((ql & 4) << 1) | ((ql & 8) >> 1); // pi(ql): bits 2 and 3 swapped
 
+    // The Q fragments are consumed here, in front of the first LDS-DMA: hipcc does not see the hand-written vmcnt wait at the top of
+    // the loop, so it kept its own `s_waitcnt vmcnt(7) .. vmcnt(0)` for these eight loads in front of the eight QK MFMAs of EVERY
+    // iteration - where the only memory operations still in flight are this wave's LDS-DMA pieces of the NEXT block, which the
+    // last MFMA of the block then waited for (r02, found in the ISA: the DMA latency sat inside the compute chain of every step).
+#pragma unroll
+    for (int s = 0; s < KST; ++s)
+        asm volatile("" : "+v"(qf[s].x), "+v"(qf[s].y), "+v"(qf[s].z), "+v"(qf[s].w));
     issue(0);
+    if (RING && nkb > 1)
+        issue(1);
     for (int t = 0; t < nkb; ++t)
     {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's pieces of block t (and, the first time, its Q fragments)
+        // this wave's pieces of block t have landed (RING: those of block t + 1 may still be on their way - loads retire in order)
+        if constexpr (RING)
+        {
+            const int keep = pieces_of(t + 1); // wave-uniform
+            if (keep == 0)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (keep == CPW)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CPW) : "memory");
+        }
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads(); // block t is in LDS for everybody; everybody is done with block t - 1
-        const bool more = t + 1 < nkb; // block t + 1 goes into the stage block t - 1 occupied
+        const bool more = t + AHEAD < nkb; // block t + AHEAD goes into the stage block t - 1 occupied
         const int kb0 = t * 64 + 32 * kh; // first key of this wave's half-block
         if (more)
-            issue(t + 1); // right behind the barrier: between the MFMAs (+4.5 us), behind them (+2.8) or inside the softmax (+1) all lost
+            issue(t + AHEAD); // right behind the barrier: between the MFMAs (+4.5 us), behind them (+2.8) or inside the softmax (+1) all lost
         if (kb0 > q0 + 31 || !valid) // every key of it lies in the future of every query of this wave (wave-uniform)
             continue;
-        const char* Ks = lds + (t & 1) * STAGE;
+        const char* Ks = lds + stage_of(t) * STAGE;
         const char* Vs = Ks + K_BYTES;
         // two accumulators (even / odd k-steps): eight MFMAs into one are a chain of eight result latencies, and once the light
         // waves have dropped out (PAIR) or the sibling sits at the barrier nothing else runs on this SIMD
@@ -778,18 +809,31 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             sacc[r] = 0.f, sacc1[r] = 0.f;
+        // all K fragments requested before the first MFMA (left alone hipcc reused one register quad: read, wait, MFMA, eight times)
+        uint4 kfr[KST];
+#pragma unroll
+        for (int s = 0; s < KST; ++s)
+            kfr[s] = *reinterpret_cast<const uint4*>(Ks + (s >> 2) * (64 * 128) + swz128(kh * 32 + krow, (2 * s + hf) & 7));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < KST; ++s)
         {
-            const uint4 kk = *reinterpret_cast<const uint4*>(Ks + (s >> 2) * (64 * 128) + swz128(kh * 32 + krow, (2 * s + hf) & 7));
             f16x8_t ak, bq;
-            __builtin_memcpy(&ak, &kk, 16);
+            __builtin_memcpy(&ak, &kfr[s], 16);
             __builtin_memcpy(&bq, &qf[s], 16);
             if (s & 1)
                 sacc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ak, bq, sacc1, 0, 0, 0);
             else
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ak, bq, sacc, 0, 0, 0);
         }
+        // the V^T fragments of both key octets are requested now, under the softmax arithmetic
+        uint4 vfr[2][DT];
+#pragma unroll
+        for (int s2l = 0; s2l < 2; ++s2l)
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+                vfr[s2l][i] = *reinterpret_cast<const uint4*>(Vs + swz128(i * 32 + ql, 2 * (2 * kh + s2l) + hf));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             sacc[r] += sacc1[r];
@@ -837,9 +881,8 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
 #pragma unroll
             for (int i = 0; i < DT; ++i)
             {
-                const uint4 vv = *reinterpret_cast<const uint4*>(Vs + swz128(i * 32 + ql, 2 * (2 * kh + s2l) + hf));
                 f16x8_t av;
-                __builtin_memcpy(&av, &vv, 16);
+                __builtin_memcpy(&av, &vfr[s2l][i], 16);
                 oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bp, oacc[i], 0, 0, 0);
             }
         }
@@ -973,9 +1016,15 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
                 const bool pair = !unpaired && !nq_env && (force_pair || (wg128 <= cus && 4 * wg128 >= cus));
                 if (pair)
                     narrow = false;
-                const size_t smem = stages > (narrow ? 2 : 4) * slab ? stages : 4 * slab;
-                auto kfn = narrow ? context_attn_mfma_ks_kernel<DH, 2>
-                                  : (pair ? context_attn_mfma_ks_kernel<DH, 4, true> : context_attn_mfma_ks_kernel<DH, 4>);
+                // three operand stages only under the paired kernel (S = 1024: 28.1 -> 27.4 us; one block per workgroup loses with
+                // them: 30.4 -> 31.2 at S = 1024, 61.6 -> 63.0 at 2048 - the operand stream is bound by its rate, not by the latency
+                // of one block in flight).  TLLM_CTX_ATTN_NORING / TLLM_CTX_ATTN_RING force either way (A/B, read per launch).
+                const bool ring = getenv("TLLM_CTX_ATTN_RING") ? true : (getenv("TLLM_CTX_ATTN_NORING") ? false : pair);
+                const size_t stg = ring ? stages / 2 * 3 : stages;
+                const size_t smem = stg > (narrow ? 2 : 4) * slab ? stg : 4 * slab;
+                auto kfn = narrow ? (ring ? context_attn_mfma_ks_kernel<DH, 2, false, true> : context_attn_mfma_ks_kernel<DH, 2>)
+                    : (pair ? (ring ? context_attn_mfma_ks_kernel<DH, 4, true, true> : context_attn_mfma_ks_kernel<DH, 4, true>)
+                            : (ring ? context_attn_mfma_ks_kernel<DH, 4, false, true> : context_attn_mfma_ks_kernel<DH, 4>));
                 if (!attr_done)
                 {
                     if (stages > 64 * 1024 || 4 * slab > 64 * 1024)
@@ -985,6 +1034,12 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
                         (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                         (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 2, false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4, false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                     }
                     attr_done = true;
