@@ -523,13 +523,18 @@ def test_context_attention_vs_oracle(int8_kv, H, Dh, S):
 
 
 @pytest.mark.parametrize('int8_kv', [0, 1])
-@pytest.mark.parametrize('H,Dh,S,paired', [(4, 128, 200, 0), (2, 64, 70, 0), (2, 32, 40, 0), (32, 128, 1000, 0), (32, 128, 1000, 1),
-                                           (4, 128, 200, 1), (4, 64, 333, 1)])
-def test_packed_context_attention_equals_padded(int8_kv, H, Dh, S, paired, monkeypatch):
-    if paired:  # the paired-block kernel whatever the workgroup count (by default only when the launch is one round)
-        monkeypatch.setenv('TLLM_CTX_ATTN_PAIRED', '1')
+@pytest.mark.parametrize('H,Dh,S,env', [(4, 128, 200, ''), (2, 64, 70, ''), (2, 32, 40, ''), (32, 128, 1000, ''),
+                                        # kernel variants the launcher picks by workgroup count, forced here on small shapes:
+                                        # paired 64-query blocks (three stages), paired with two stages, one block per
+                                        # workgroup with three stages
+                                        (32, 128, 1000, 'PAIRED'), (4, 128, 200, 'PAIRED'), (4, 64, 333, 'PAIRED'),
+                                        (4, 128, 333, 'PAIRED NORING'), (4, 128, 333, 'RING'), (32, 128, 1000, 'UNPAIRED RING')])
+def test_packed_context_attention_equals_padded(int8_kv, H, Dh, S, env, monkeypatch):
     """remove_input_padding (gptAttentionPlugin.cpp:344-356): the tokens of all sequences back to back in [1, T, 3 D];
-    the plugin must produce, for every real token, what the padded run produces, and the same KV cache."""
+    the plugin must produce, for every real token, what the padded run produces, and the same KV cache.  A forced kernel
+    variant is also held against the oracle (the padded run; 5e-3 as in test_context_attention_vs_oracle)."""
+    for k in env.split():
+        monkeypatch.setenv('TLLM_CTX_ATTN_' + k, '1')
     r = rng(300 + S)
     B, smax = 3, S + 8
     in_len = [S, S // 3, max(S // 2, 1)]
@@ -540,6 +545,10 @@ def test_packed_context_attention_equals_padded(int8_kv, H, Dh, S, paired, monke
     cache_pad = torch.zeros((B, 2, H, smax, Dh), dtype=dt, device='cuda')
     out_pad = run_attention(attention_plugin(H, Dh, int8_kv), qkv.clone(), cache_pad, [S] * B, 0, True, masked, in_len, S, smax,
                             scales)
+    if env:
+        ref_cache = np.zeros((B, 2, H, smax, Dh), dtype=np.int8 if int8_kv else np.float16)
+        ref, _ = O.context_attention(as_f32(qkv), ref_cache, in_len, H, Dh, Dh, True, 1.0, scales[0] if scales else None)
+        np.testing.assert_allclose(as_f32(out_pad), ref, atol=5e-3, rtol=0)
     packed = torch.cat([qkv[b, :in_len[b]] for b in range(B)], dim=0)[None].contiguous()  # [1, T, 3 D]
     cache_pk = torch.zeros((B, 2, H, smax, Dh), dtype=dt, device='cuda')
     p = attention_plugin(H, Dh, int8_kv, packed=1)
