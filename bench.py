@@ -44,7 +44,8 @@ def parse():
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
     ap.add_argument('--no-parity', dest='parity', action='store_false',
                     help='skip the 7B accuracy report (GPU engines vs HF fp32 on the host CPU on identical weights)')
-    ap.add_argument('--parity-new-tokens', type=int, default=16)
+    ap.add_argument('--parity-new-tokens', type=int, default=128, help='new tokens per prompt of the accuracy report (SURVEY 8d: 128)')
+    ap.add_argument('--parity-prompts', type=int, default=8, help='seeded prompts of the accuracy report')
     ap.add_argument('--cpu-tokens', type=int, default=0, help='CPU-baseline decode steps (0 = sized to ~20 s)')
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--cpu-sweep', default='', help='debug: comma list of thread counts to try (stderr)')
@@ -440,7 +441,8 @@ def main():
         try:
             import bench_parity
             parity, cpu_model, cpu_info = bench_parity.run(
-                torch, dev, layers=args.layers, new_tokens=args.parity_new_tokens, cpu_threads=args.cpu_threads or _default_cpu_threads(),
+                torch, dev, layers=args.layers, new_tokens=args.parity_new_tokens, n_prompts=args.parity_prompts,
+                cpu_threads=args.cpu_threads or _default_cpu_threads(), cpu_leg=not args.no_cpu_baseline,
                 log=lambda m: print(f'[bench parity] {m}', file=sys.stderr, flush=True))
         except Exception as e:  # the decode metric must not depend on the side report
             import traceback

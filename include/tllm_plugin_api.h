@@ -182,6 +182,24 @@ int32_t tllm_comm_p2p_attach(const void* handles);
 void tllm_comm_p2p_enable(int32_t on);
 int32_t tllm_comm_p2p_all_reduce(void* buf, int64_t count, tllm_stream_t stream);
 int32_t tllm_comm_p2p_error(void);
+/* The tensor-parallel layer seam in ONE launch: all-reduce + residual add + the next RMSNorm (+ SmoothQuant activation quantiser).
+ * Reference seam, three to four graph nodes per rank: allreduce plugin (P/ncclPlugin/allreducePlugin.cpp:80-96, inserted by
+ * PY/quantization/layer.py:215,377 / PY/layers/linear.py:127-139) -> `hidden = residual + ...` (Q/llama_model.py:107-108,
+ * :117-118) -> rms_norm (PY/functional.py:3195-3219) [-> quantize, PY/quantization/layer.py:223-265].
+ *   partial  : this rank's [rows, cols] fp16 partial sum (read only);
+ *   x        : [rows, cols] fp16 residual stream, in place: x <- fp16(x + sum_r partial_r)  (fp32 sum in rank order, one rounding,
+ *              bit-identical on every rank);
+ *   norm_out : [rows, cols]  fp16(fp16(x * rsqrt(mean(x^2) + eps)) * gamma)          (quant 0)
+ *              int8 sat(rni(that * quant_scale[0]))                                   (quant 1, static)
+ *              int8 per token, amax / 127 to dyn_scale_out[rows]                      (quant 2; K/quantization.cu:94-118).
+ * rows * cols * 2 bytes must fit the inbox slot (tllm_comm_p2p_create max_bytes). */
+int32_t tllm_comm_p2p_all_reduce_residual_norm(const void* partial, void* x, const void* gamma, float eps, int32_t rows, int32_t cols,
+    void* norm_out, int32_t quant, const float* quant_scale, float* dyn_scale_out, tllm_stream_t stream);
+/* Test knob: how many polls a flag wait may take before it gives up (0 = default, about a second). */
+void tllm_comm_p2p_set_max_spins(int32_t n);
+/* What the RCCL communicator registered for `group` reports about itself (ncclCommCount / ncclCommUserRank): the number of ranks
+ * it spans and this process's index in it; returns non-zero when no communicator exists for the group. */
+int32_t tllm_comm_group_info(const int32_t* group, int32_t groupSize, int32_t* nranks, int32_t* my_index);
 
 /* ------------------------------------------------------------------------------------------------
  * Weight pre-processing for the weight-only plugins.  Replaces the torch ops of

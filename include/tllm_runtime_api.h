@@ -138,6 +138,14 @@ int32_t tllm_session_force_tokens(tllm_session_t s, const int32_t* ids, tllm_str
  * per-token flavour).  This is the tensor the reference's attention tests compare at atol 2e-3
  * (T/tests/attention/test_gpt_attention.py:828-831).  HOST buffer of exactly that many bytes. */
 int32_t tllm_session_get_tap(tllm_session_t s, int32_t layer, void* host, size_t nbytes, tllm_stream_t stream);
+/* The same for every GEMM input of the layer, i.e. all four quantisers of the SmoothQuant block
+ * (PY/quantization/layer.py:223-265 norm + quant, :385-439 MLP, :596-852 attention; K/quantization.cu:31-118):
+ *   which 0  QKV input        [B, hidden]     behind input_layernorm (+ its quantiser)
+ *         1  O-projection in  [B, H/tp * Dh]  (= tllm_session_get_tap)
+ *         2  fc | gate input  [B, hidden]     behind post_layernorm (+ its quantiser)
+ *         3  proj input       [B, inter/tp]   SwiGLU output (+ its quantiser)
+ * fp16, or int8 with SmoothQuant - parity tests compare these against the oracle in LSBs.  HOST buffer of exactly that size. */
+int32_t tllm_session_get_tap_ex(tllm_session_t s, int32_t layer, int32_t which, void* host, size_t nbytes, tllm_stream_t stream);
 /* Bytes a generation step must move from HBM at context length L (weights + KV read + KV write): the
  * algorithmic-bytes model of SURVEY.md §8(d), evaluated for this session's configuration. */
 int64_t tllm_session_step_bytes(tllm_session_t s, int32_t context_len);

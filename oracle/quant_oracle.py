@@ -67,8 +67,10 @@ class _Linear:
 def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, reference_rounding=False):
     """Context step + n_new-1 generation steps.  Returns ([logits per step], greedy ids [B, n_new]).
     `taps` (a dict) receives 'caches' (the per-layer KV caches, live objects: their state after the last step),
-    'caches_after_context' (copies) and 'attn_ctx' = [step][layer] attention output [B, H*Dh] of every generation step
-    (the O-projection's input before its quantiser).  `reference_rounding`: see llama_oracle.mmha_decode / woq_matmul."""
+    'caches_after_context' (copies), 'attn_ctx' = [step][layer] attention output [B, H*Dh] of every generation step
+    (the O-projection's input before its quantiser) and 'gemm_in' = [step][layer] dict(qkv_in, o_in, mlp_in, proj_in): the
+    operand of each of the layer's four GEMMs in that generation step - int8 behind its quantiser for SmoothQuant
+    (K/quantization.cu:31-118), the fp16 activation otherwise.  `reference_rounding`: see llama_oracle.mmha_decode / woq_matmul."""
     cfg = model['cfg']
     B, S = ids.shape
     H, D = cfg['num_heads'], cfg['hidden_size']
@@ -98,29 +100,37 @@ def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, re
             return O.quantize_per_token(x16)
         return O.quantize_tensor(x16, static_scale), None
 
-    def layer(li, x16, rows_valid, attn_fn):
+    def layer(li, x16, rows_valid, attn_fn, gemm_in=None):
         lw = model['layers'][li]
         M = x16.shape[0]
+        rec = {}
+
+        def operand(name, x_f16, q):  # what the GEMM consumes: the quantiser's int8, or the fp16 activation
+            rec[name] = (q[0] if q is not None else x_f16).copy()
+            return q
+
         h = O.rmsnorm(x16, lw['ln1'], eps)
         cap(f'{li}.attention.qkv', x=h[rows_valid])
-        qkv = lw['attention.qkv'](h, quant_in(h, lw.get('ln1_scale')))
+        qkv = lw['attention.qkv'](h, operand('qkv_in', h, quant_in(h, lw.get('ln1_scale'))))
         cap(f'{li}.attention.qkv', y=qkv[rows_valid])
         ctx = attn_fn(qkv, caches[li], lw)
         cap(f'{li}.attention.dense', x=ctx[rows_valid])
-        attn = lw['attention.dense'](ctx, quant_in(ctx, lw.get('attn_qscale')))
+        attn = lw['attention.dense'](ctx, operand('o_in', ctx, quant_in(ctx, lw.get('attn_qscale'))))
         cap(f'{li}.attention.dense', y=attn[rows_valid])
         x1 = O.f16(x16 + attn)
         h2 = O.rmsnorm(x1, lw['ln2'], eps)
         cap(f'{li}.mlp.fc', x=h2[rows_valid])
-        qi = quant_in(h2, lw.get('ln2_scale'))
+        qi = operand('mlp_in', h2, quant_in(h2, lw.get('ln2_scale')))
         g = lw['mlp.fc'](h2, qi)
         u = lw['mlp.gate'](h2, qi)
         cap(f'{li}.mlp.fc', y=g[rows_valid])
         cap(f'{li}.mlp.gate', y=u[rows_valid])
         inter = O.swiglu(g, u)
         cap(f'{li}.mlp.proj', x=inter[rows_valid])
-        m = lw['mlp.proj'](inter, quant_in(inter, lw.get('mlp_qscale')))
+        m = lw['mlp.proj'](inter, operand('proj_in', inter, quant_in(inter, lw.get('mlp_qscale'))))
         cap(f'{li}.mlp.proj', y=m[rows_valid])
+        if gemm_in is not None:
+            gemm_in.append(rec)
         return O.f16(x1 + m)
 
     # ---- context
@@ -137,6 +147,7 @@ def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, re
         taps['caches'] = caches
         taps['caches_after_context'] = [c.copy() for c in caches]
         taps['attn_ctx'] = []
+        taps['gemm_in'] = []
     x = x.reshape(B, S, D)
     last = np.stack([x[b, int(lens[b]) - 1] for b in range(B)])
     logits = [(O.rmsnorm(last, model['lnf'], eps) @ model['head'].T).astype(F32)]
@@ -152,6 +163,7 @@ def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, re
 
         if taps is not None:
             taps['attn_ctx'].append([])
+            taps['gemm_in'].append([])
 
         def dec_attn(qkv, cache, lw):
             c = O.mmha_decode(qkv, cache, [tl] * B, lens, S, tl, H, Dh, Dh, True, 1.0, masked, lw.get('kv_oq'),
@@ -161,7 +173,7 @@ def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, re
             return c
 
         for li in range(L):
-            xs = layer(li, xs, np.ones(B, bool), dec_attn)
+            xs = layer(li, xs, np.ones(B, bool), dec_attn, taps['gemm_in'][-1] if taps is not None else None)
         logits.append((O.rmsnorm(xs, model['lnf'], eps) @ model['head'].T).astype(F32))
         gen.append(logits[-1].argmax(-1))
     return logits, np.stack(gen, 1)

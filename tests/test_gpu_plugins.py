@@ -250,6 +250,34 @@ def test_weight_only_quant_matmul(bits, m, n, k):
         np.testing.assert_allclose(as_f32(out), deq, atol=max(deq.max(), 0) * rs * 1.5)
 
 
+@pytest.mark.parametrize('bits', [8, 4])
+@pytest.mark.parametrize('m,n,k', [(1, 4096, 11008), (2, 4096, 11008), (1, 12288, 4096), (4, 4096, 4096)])
+def test_weight_only_gemv_with_a_dc_offset_in_the_activations(bits, m, n, k):
+    """the weight-only GEMV runs its dot products on the raw byte / nibble splices (1152 + q, 1024 + n,
+    1024 + 16 n) and takes the splice bias times sum(x) off afterwards.  With zero-mean activations that bias term is small; with
+    a DC offset (x = 3 + N(0, 1): SwiGLU outputs into mlp.proj, attention outputs) it is 16x (int8) to 220x (int4) the signal and
+    fp32 rounding must still cancel.  Checked against the exact result (float64 sum of exact products, one rounding), in units of
+    the fp16 spacing at the largest output of the row."""
+    r = np.random.default_rng(3)
+    w = (r.uniform(-1, 1, (k, n))).astype(np.float16)
+    x = (3.0 + r.standard_normal((m, k))).astype(np.float16)
+    processed, scales, _ = capi.symmetric_quantize_last_axis(w, bits)
+    q_ref, s_ref = O.woq_quantize(w.astype(np.float32), bits)
+    p = make_plugin('WeightOnlyQuantMatmul', [('type_id', i32([capi.HALF])), ('weight_type_id', i32(1 if bits == 8 else 2))])
+    wt = torch.from_numpy(processed).cuda().view(torch.float32).reshape(k, -1)
+    out = torch.empty((m, n), dtype=torch.float16, device='cuda')
+    run_plugin(p, [torch.from_numpy(x).cuda(), wt, torch.from_numpy(scales).cuda()], [out])
+    exact = (x.astype(np.float64) @ q_ref.astype(np.float64)) * s_ref.astype(np.float64)[None, :]
+    got = as_f32(out).astype(np.float64)
+    top = np.abs(exact).max()
+    ulp = 2.0 ** (np.floor(np.log2(top)) - 10)  # fp16 spacing at the largest output
+    err = np.abs(got - exact)
+    print(f'[woq{bits} m={m} n={n} k={k}] max |err| = {err.max() / ulp:.2f} fp16 ulp(max |y|), rms = {np.sqrt((err ** 2).mean()) / ulp:.3f}, '
+          f'|sum x| = {np.abs(x.astype(np.float64).sum(1)).max():.0f}, max |y| = {top:.1f}')
+    # one rounding of the exact value is <= 0.5 ulp; fp32 accumulation of the splices must not add more than another 0.5
+    assert err.max() <= 1.0 * ulp, err.max() / ulp
+
+
 @pytest.mark.parametrize('m,n,k', [(1, 4096, 4096), (2, 32000, 4096), (1, 4096, 11008), (19, 192, 64), (8, 24, 64),
                                    (1, 1003, 5120), (1, 13, 12288), (1, 520, 2056)])  # K-split kernel, ragged rows / chunks
 def test_gemm_fp16(m, n, k):

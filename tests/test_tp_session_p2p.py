@@ -172,3 +172,103 @@ def test_tp2_sessions_on_one_gpu_match_the_unsharded_session():
     # and they follow the un-sharded greedy path except where a re-ordered fp16 sum flips a near-tie
     agree = np.mean(res[0][3][:, S:] == ref_out[:, S:])
     assert agree > 0.9, agree
+
+
+def _p2p_up(lib, capi, torch, dist, ctypes, world, rank):
+    h = (ctypes.c_char * 64)()
+    assert lib.tllm_comm_p2p_create(world, rank, 64 * 1024, h) == 0, capi.last_error()
+    allh = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(allh, torch.frombuffer(bytearray(h.raw), dtype=torch.uint8))
+    blob = b''.join(bytes(x.numpy().tobytes()) for x in allh)
+    assert lib.tllm_comm_p2p_attach(ctypes.create_string_buffer(blob, len(blob))) == 0, capi.last_error()
+    lib.tllm_comm_p2p_enable(1)
+
+
+def _timeout_rank(rank, world, port, q):
+    import ctypes
+    import time
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, 'trtllm-llama_amd'))
+    from tensorrt_llm.plugin import capi
+    from tensorrt_llm.runtime.native import NativeSession
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        lib = capi.load_library()
+        lib.tllm_comm_p2p_create.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]
+        lib.tllm_comm_p2p_attach.argtypes = [ctypes.c_void_p]
+        lib.tllm_comm_p2p_enable.argtypes = [ctypes.c_int32]
+        lib.tllm_comm_p2p_enable.restype = None
+        lib.tllm_comm_p2p_set_max_spins.argtypes = [ctypes.c_int32]
+        lib.tllm_comm_p2p_set_max_spins.restype = None
+        _p2p_up(lib, capi, torch, dist, ctypes, world, rank)
+        lib.tllm_comm_p2p_set_max_spins(20000)  # a few milliseconds
+        CFG, t, ids, lens = model()
+        B, S = ids.shape
+
+        def session():
+            s = NativeSession(dict(CFG, quant_mode=0, tp_size=world, tp_rank=rank))
+            for k, v in shard(t, world, rank).items():
+                s.set_tensor(k, v)
+            s.finalize()
+            s.setup(B, S, 8)
+            return s
+
+        s = session()
+        msgs = []
+        if rank == 1:
+            time.sleep(1.5)  # rank 0's first all-reduce gives up long before this rank shows up
+        for attempt in range(2):
+            try:
+                s.context(ids, lens)
+                s.step(2)
+                s.logits()
+                msgs.append('ok')
+            except RuntimeError as e:
+                msgs.append(str(e))
+        s.close()
+        dist.barrier()
+        # a fresh transport (destroy + create + attach + enable) serves a fresh session
+        lib.tllm_comm_destroy_all()
+        _p2p_up(lib, capi, torch, dist, ctypes, world, rank)
+        s = session()
+        out = s.generate(ids, lens, 8, end_id=-1)
+        s.close()
+        q.put((rank, msgs, out, int(lib.tllm_comm_p2p_error())))
+        dist.barrier()
+        lib.tllm_comm_destroy_all()
+    except BaseException as e:
+        q.put((rank, repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_session_call_after_a_timeout_is_not_failed_by_the_sticky_flag():
+    """ADVICE r2 (medium), session level.  Rank 1 is late; rank 0's first peer-to-peer all-reduce gives up.  The call fails on
+    BOTH ranks with the time-out error (rank 1 learns of it through the poison word), both take the transport out of service,
+    and the NEXT call is no longer failed by the recorded time-out: it goes to the fall-back transport (RCCL; none exists on this
+    one-GPU rig, so it fails with 'no communicator', not with the time-out).  A re-created transport then serves a new session."""
+    import torch.multiprocessing as mp
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timeout_rank, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(len(r) == 4 for r in res), res
+    res = sorted(res, key=lambda r: r[0])
+    for rank, msgs, out, err in res:
+        assert 'timed out' in msgs[0], (rank, msgs)
+        assert ('on this rank' in msgs[0]) == (rank == 0) and ('reported by a peer' in msgs[0]) == (rank == 1), (rank, msgs)
+        assert 'timed out' not in msgs[1] and 'communicator' in msgs[1], (rank, msgs)
+        assert err == 0, (rank, err)
+    np.testing.assert_array_equal(res[0][2], res[1][2])

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void gemm_glds_kernel(con
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform, and the compiler knows it (LDS-DMA base)
-    // clock evidence for the microbench (tllm_gemm_set_clock_probe; the field is unused by SmoothQuant / fp16 otherwise)
-    void* const clk_probe = SQ ? p.scratch : nullptr;
+    // clock evidence for the microbench (tllm_gemm_set_clock_probe; GemmParams::clock_probe, set by the launcher only)
+    void* const clk_probe = SQ ? p.clock_probe : nullptr;
     const uint64_t clk0 = clk_probe ? __builtin_readcyclecounter() : 0, rt0 = clk_probe ? __builtin_amdgcn_s_memrealtime() : 0;
     const bool loader = LW > 0 && wid >= NWC;     // wave-uniform
     const int iw = LW > 0 ? (wid >= NWC ? wid - NWC : 0) : wid; // index among the issuing waves
@@ -594,7 +594,7 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
     if (sq && gemm_clock_probe)
     {
         GemmParams q = p;
-        q.scratch = gemm_clock_probe;
+        q.clock_probe = gemm_clock_probe;
         return launch_wt<W_INT8_SQ>(q, cfg, stream);
     }
     return sq ? launch_wt<W_INT8_SQ>(p, cfg, stream) : launch_wt<W_FP16>(p, cfg, stream);

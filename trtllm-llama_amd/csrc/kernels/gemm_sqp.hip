@@ -80,9 +80,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // clock evidence (microbench only: GemmParams::scratch is unused by SmoothQuant): shader cycles (s_memtime) against the
+    // clock evidence (microbench only: GemmParams::clock_probe, set by the launchers): shader cycles (s_memtime) against the
     // constant 100 MHz counter (s_memrealtime) over this workgroup's lifetime -> the clock the chip actually held
-    const uint64_t clk0 = p.scratch ? __builtin_readcyclecounter() : 0, rt0 = p.scratch ? __builtin_amdgcn_s_memrealtime() : 0;
+    const uint64_t clk0 = p.clock_probe ? __builtin_readcyclecounter() : 0, rt0 = p.clock_probe ? __builtin_amdgcn_s_memrealtime() : 0;
     const int wr = wid / WC, wc = wid % WC;
     const int grp = wid >= NW / 2 ? 1 : 0; // the second-dispatched half: its DMA sits elsewhere in the phase
     const int nwg = gridDim.x;
@@ -369,9 +369,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     // ---- epilogue.  acc[i][j][m][n][r]: row i*AH + (wr*MTH + m)*16 + (lane & 15),
     //                                    col j*BH + (wc*NTH + n)*16 + 4*(lane >> 4) + r      (inside the tile)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); // scales landed (ntile == 1 aside, they have long ago)
-    if (p.scratch && tid == 0)
+    if (p.clock_probe && tid == 0)
     {
-        uint64_t* dbg = reinterpret_cast<uint64_t*>(p.scratch) + 2 * blockIdx.x;
+        uint64_t* dbg = reinterpret_cast<uint64_t*>(p.clock_probe) + 2 * blockIdx.x;
         dbg[0] = __builtin_readcyclecounter() - clk0;
         dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
@@ -593,7 +593,7 @@ void* gemm_clock_probe = nullptr;
 int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
 {
     GemmParams p = pin;
-    p.scratch = gemm_clock_probe;
+    p.clock_probe = gemm_clock_probe;
     if (p.wtype != W_INT8_SQ)
         return 1;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (p.lda & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) || (p.ldw & 15)

@@ -254,6 +254,8 @@ struct GemmParams
     // weight-only types at M >= 32: scratch of gemm_woq_scratch_bytes(N, K) bytes lets the GEMM expand the integers to
     // fp16 once (exact) and run the LDS-DMA staged fp16 kernel with the per-channel scale in its epilogue
     void* scratch = nullptr;
+    // microbench hook (tllm_gemm_set_clock_probe), set by the launchers only: 2 x uint64 per workgroup {shader cycles, 100 MHz ticks}
+    void* clock_probe = nullptr;
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 // fc and gate projections of the SmoothQuant MLP in one kernel with SwiGLU + static int8 quantisation in its epilogue
@@ -272,9 +274,23 @@ struct P2PParams
     void* gather_out = nullptr; // non-null: all-gather instead of sum, out = [world][n16 * 16 bytes]
     int32_t n16 = 0;
     uint32_t* epoch = nullptr; // device counter, advanced by the kernel
-    uint32_t* error = nullptr; // device flag: non-zero after a spin timed out
+    uint32_t* error = nullptr; // device flag: non-zero after a spin timed out (bit 31: a PEER reported the time-out)
     int32_t max_spins = 4000000;
+    // optional fused tail of the sum (never with gather_out):
+    //   residual != null           : the sum starts from residual[v]                       (hidden = residual + all_reduce(...))
+    //   x_out    != null           : the fp16 result goes there instead of back into x     (may alias residual)
+    //   norm_out != null           : + RMSNorm over rows of `cols` elements: norm_out = fp16(fp16(x_out * inv) * gamma), or its
+    //                                int8 quantisation (quant 1: static scale quant_scale[0]; 2: per token, scales to dyn_scale_out)
+    const void* residual = nullptr;
+    void* x_out = nullptr;
+    void* norm_out = nullptr;
+    const void* gamma = nullptr;
+    float eps = 1e-6f;
+    int32_t rows = 0, cols = 0, quant = 0;
+    const float* quant_scale = nullptr;
+    float* dyn_scale_out = nullptr;
 };
+constexpr size_t P2P_POISON_OFFSET = 2048; // byte offset behind flag_offset of the "a peer gave up" word in every region
 int launch_p2p_allreduce(const P2PParams& p, hipStream_t stream);
 
 // Greedy sampler: argmax over fp32 logits [B, V] -> ids; ties -> lowest index.

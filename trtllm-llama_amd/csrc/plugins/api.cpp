@@ -336,6 +336,47 @@ int32_t tllm_comm_p2p_all_reduce(void* buf, int64_t count, tllm_stream_t stream)
     return comm::p2p::all_reduce_f16(buf, count, reinterpret_cast<hipStream_t>(stream)) ? 1 : 0;
 }
 
+int32_t tllm_comm_p2p_all_reduce_residual_norm(const void* partial, void* x, const void* gamma, float eps, int32_t rows, int32_t cols,
+    void* norm_out, int32_t quant, const float* quant_scale, float* dyn_scale_out, tllm_stream_t stream)
+{
+    if (!partial || !x || !gamma || !norm_out)
+    {
+        set_error("tllm_comm_p2p_all_reduce_residual_norm: null argument");
+        return 1;
+    }
+    comm::p2p::FusedTail t;
+    t.x = x;
+    t.gamma = gamma;
+    t.eps = eps;
+    t.norm_out = norm_out;
+    t.quant = quant;
+    t.quant_scale = quant_scale;
+    t.dyn_scale_out = dyn_scale_out;
+    return comm::p2p::all_reduce_residual_norm(const_cast<void*>(partial), rows, cols, t, reinterpret_cast<hipStream_t>(stream)) ? 1 : 0;
+}
+
+void tllm_comm_p2p_set_max_spins(int32_t n)
+{
+    comm::p2p::set_max_spins(n);
+}
+
+int32_t tllm_comm_group_info(const int32_t* group, int32_t groupSize, int32_t* nranks, int32_t* my_index)
+{
+    if (!group || groupSize < 1)
+    {
+        set_error("tllm_comm_group_info: bad arguments");
+        return 1;
+    }
+    int n = 0, idx = -1;
+    if (comm::group_info(std::vector<int32_t>(group, group + groupSize), &n, &idx))
+        return 1;
+    if (nranks)
+        *nranks = n;
+    if (my_index)
+        *my_index = idx;
+    return 0;
+}
+
 int32_t tllm_comm_p2p_error(void)
 {
     uint32_t e = 0;

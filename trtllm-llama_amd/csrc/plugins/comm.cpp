@@ -20,6 +20,8 @@ struct Api
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -55,6 +57,8 @@ bool load_api()
     SYM(AllReduce, "ncclAllReduce")
     SYM(AllGather, "ncclAllGather")
     SYM(CommDestroy, "ncclCommDestroy")
+    SYM(CommCount, "ncclCommCount")
+    SYM(CommUserRank, "ncclCommUserRank")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     return true;
@@ -134,6 +138,23 @@ bool has_comm(const std::vector<int32_t>& group)
 {
     std::lock_guard<std::mutex> lk(g_mu);
     return g_comms.count(group) != 0;
+}
+
+int group_info(const std::vector<int32_t>& group, int* nranks, int* my_index)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ncclComm_t c = find(group);
+    if (!c)
+        return -1;
+    ncclResult_t r = g_api.CommCount(c, nranks);
+    if (r == ncclSuccess)
+        r = g_api.CommUserRank(c, my_index);
+    if (r != ncclSuccess)
+    {
+        set_error("comm: ncclCommCount / ncclCommUserRank: %s", g_api.GetErrorString(r));
+        return -1;
+    }
+    return 0;
 }
 
 int all_reduce_sum(const std::vector<int32_t>& group, const void* in, void* out, int64_t count, int32_t dtype,

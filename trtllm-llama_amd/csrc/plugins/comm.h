@@ -18,6 +18,7 @@ int all_gather(const std::vector<int32_t>& group, const void* in, void* out, int
     hipStream_t stream);
 int destroy_all();
 bool has_comm(const std::vector<int32_t>& group);
+int group_info(const std::vector<int32_t>& group, int* nranks, int* my_index); // ncclCommCount / ncclCommUserRank
 
 // One-shot peer-to-peer all-reduce for small fp16 vectors (kernels/p2p_allreduce.hip, plugins/p2p.cpp)
 namespace p2p
@@ -28,7 +29,25 @@ void enable(bool on);
 bool attached();
 bool usable(int world, int64_t bytes);
 int64_t slot_capacity(int world); // bytes one exchange can carry when the path is enabled for this world size, else 0
+bool enabled();
+// after a time-out: takes the transport out of service and clears the error / poison words, so that the sticky flag does not
+// fail later calls that no longer use this transport (destroy + create + attach brings it back)
+void disable_after_error();
+void set_max_spins(int n); // tests: how long a flag wait may spin before it gives up (0 = default)
 int all_reduce_f16(void* buf, int64_t count, hipStream_t stream);
+// the tensor-parallel layer seam in one launch (kernels/p2p_allreduce.hip): x <- fp16(x + sum_r partial_r), then
+// norm_out <- RMSNorm(x) * gamma as fp16 (quant 0) or int8 (1: static scale, 2: per token -> dyn_scale_out[rows])
+struct FusedTail
+{
+    void* x = nullptr;            // [rows, cols] fp16 residual stream, updated in place
+    const void* gamma = nullptr;  // [cols] fp16
+    float eps = 1e-6f;
+    void* norm_out = nullptr;     // [rows, cols] fp16 | int8
+    int quant = 0;
+    const float* quant_scale = nullptr;
+    float* dyn_scale_out = nullptr;
+};
+int all_reduce_residual_norm(void* partial, int rows, int cols, const FusedTail& t, hipStream_t stream);
 int all_gather(const void* in, void* out, int64_t bytes_per_rank, hipStream_t stream);
 int error_flag(uint32_t* out);
 int destroy();

@@ -22,6 +22,7 @@ struct State
     void* peer[8] = {};             // every rank's region as mapped here (peer[rank] == local)
     uint32_t* counters = nullptr;   // [0] epoch, [1] error  (ordinary device memory)
     bool attached = false, enabled = false;
+    int max_spins = 0;
 };
 std::mutex g_mu;
 State g;
@@ -129,6 +130,68 @@ bool attached()
     return g.attached;
 }
 
+bool enabled()
+{
+    return g.enabled;
+}
+
+void set_max_spins(int n)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g.max_spins = n;
+}
+
+void disable_after_error()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g.enabled = false;
+    if (g.counters)
+        (void) hipMemset(g.counters + 1, 0, 4);
+    if (g.local)
+        (void) hipMemset(static_cast<char*>(g.local) + g.flag_offset + kernels::P2P_POISON_OFFSET, 0, 4);
+}
+
+namespace
+{
+void fill_common(kernels::P2PParams& p)
+{
+    for (int r = 0; r < g.world; ++r)
+        p.peer[r] = g.peer[r];
+    p.world = g.world;
+    p.rank = g.rank;
+    p.slot_bytes = g.slot_bytes;
+    p.flag_offset = g.flag_offset;
+    p.epoch = g.counters;
+    p.error = g.counters + 1;
+    if (g.max_spins > 0)
+        p.max_spins = g.max_spins;
+}
+} // namespace
+
+int all_reduce_residual_norm(void* partial, int rows, int cols, const FusedTail& t, hipStream_t stream)
+{
+    if (!g.attached || rows < 1 || cols < 8 || (cols % 8))
+    {
+        set_error("p2p: fused all-reduce needs attached peers and rows of a multiple of 8 halfs");
+        return -1;
+    }
+    kernels::P2PParams p;
+    fill_common(p);
+    p.x = partial;
+    p.n16 = (int32_t) ((int64_t) rows * cols / 8);
+    p.residual = t.x;
+    p.x_out = t.x;
+    p.norm_out = t.norm_out;
+    p.gamma = t.gamma;
+    p.eps = t.eps;
+    p.rows = rows;
+    p.cols = cols;
+    p.quant = t.quant;
+    p.quant_scale = t.quant_scale;
+    p.dyn_scale_out = t.dyn_scale_out;
+    return kernels::launch_p2p_allreduce(p, stream);
+}
+
 int all_reduce_f16(void* buf, int64_t count, hipStream_t stream)
 {
     if (!g.attached || (count % 8))
@@ -137,16 +200,9 @@ int all_reduce_f16(void* buf, int64_t count, hipStream_t stream)
         return -1;
     }
     kernels::P2PParams p;
-    for (int r = 0; r < g.world; ++r)
-        p.peer[r] = g.peer[r];
-    p.world = g.world;
-    p.rank = g.rank;
-    p.slot_bytes = g.slot_bytes;
-    p.flag_offset = g.flag_offset;
+    fill_common(p);
     p.x = buf;
     p.n16 = (int32_t) (count / 8);
-    p.epoch = g.counters;
-    p.error = g.counters + 1;
     return kernels::launch_p2p_allreduce(p, stream);
 }
 
@@ -158,28 +214,28 @@ int all_gather(const void* in, void* out, int64_t bytes, hipStream_t stream)
         return -1;
     }
     kernels::P2PParams p;
-    for (int r = 0; r < g.world; ++r)
-        p.peer[r] = g.peer[r];
-    p.world = g.world;
-    p.rank = g.rank;
-    p.slot_bytes = g.slot_bytes;
-    p.flag_offset = g.flag_offset;
+    fill_common(p);
     p.x = const_cast<void*>(in);
     p.gather_out = out;
     p.n16 = (int32_t) (bytes / 16);
-    p.epoch = g.counters;
-    p.error = g.counters + 1;
     return kernels::launch_p2p_allreduce(p, stream);
 }
 
 int error_flag(uint32_t* out)
 {
+    *out = 0;
     if (!g.counters)
-    {
-        *out = 0;
         return 0;
-    }
-    return hipMemcpy(out, g.counters + 1, 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+    // this rank's own time-out, or the word a peer that gave up wrote into this rank's region (a rank that has not launched
+    // since then learns of it here: the decision to leave the transport is collective)
+    uint32_t own = 0, poison = 0;
+    if (hipMemcpy(&own, g.counters + 1, 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    if (g.local
+        && hipMemcpy(&poison, static_cast<char*>(g.local) + g.flag_offset + kernels::P2P_POISON_OFFSET, 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    *out = own ? own : (poison ? (poison | 0x80000000u) : 0);
+    return 0;
 }
 
 int destroy()

@@ -315,6 +315,12 @@ int verify_network(const std::string& network_json, const ScheduleDesc& d, std::
     const JVal* jout = root.get("outputs");
     const JVal* jnodes = root.get("nodes");
     const JVal* jconst = root.get("constants");
+    if (jin && jout && jnodes && !jconst)
+    {
+        // engines written before the builder recorded the traced constants (same TLLMENG1 container): say what to do
+        err = "network_json has no 'constants' map: this engine was built by an older builder - rebuild it (build.py) with the current one";
+        return 1;
+    }
     if (!jin || jin->type != JVal::ARR || !jout || jout->type != JVal::ARR || !jnodes || jnodes->type != JVal::ARR || !jconst
         || jconst->type != JVal::OBJ)
     {
@@ -441,7 +447,7 @@ int verify_network(const std::string& network_json, const ScheduleDesc& d, std::
         if (d.paged)
             ain.push_back(in("kv_cache_block_pointers_" + std::to_string(i)));
         const Fields af = {{"num_heads", {(double) d.heads_per_rank}}, {"head_size", {(double) d.head_size}}, {"unidirectional", {1}},
-            {"q_scaling", {1}}, {"rotary_embedding_dim", {(double) d.head_size}}, {"neox_rotary_style", {1}},
+            {"q_scaling", {1}}, {"rotary_embedding_dim", {(double) d.head_size}}, {"neox_rotary_style", {d.neox ? 1.0 : 0.0}},
             {"context_fmha_type", {0}}, {"multi_block_mode", {0}}, {"multi_query_mode", {0}},
             {"int8_kv_cache", {d.int8_kv ? 1.0 : 0.0}}, {"fp8_kv_cache", {0}}, {"remove_input_padding", {d.packed ? 1.0 : 0.0}},
             {"mask_type", {1}}, {"paged_kv_cache", {d.paged ? 1.0 : 0.0}}, {"type_id", {HALF}}, {"in_flight_batching", {0}}};

@@ -18,6 +18,7 @@ struct ScheduleDesc
     int num_layers = 0, heads_per_rank = 0, head_size = 0, tp = 1;
     float eps = 1e-6f;
     bool sq = false, per_token = false, woq = false, int4 = false, int8_kv = false, paged = false, packed = false;
+    bool neox = true; // GPTAttention neox_rotary_style (the session's config key of the same name)
     // SmoothQuant: has_per_channel_scaling of each GEMM as the loaded scale tensors imply it (order: qkv, dense, fc, gate, proj)
     std::vector<int> per_channel;
 };

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -163,9 +164,14 @@ struct tllm_session
     int tokens_per_block = 64, max_blocks = 0;
     size_t kv_elems = 0; // elements of one layer's cache / pool
     bool force_comm = false; // tests: run the TP collectives on a 1-rank communicator too (RCCL inside the captured graph)
-    bool debug_taps = false; // tests: keep every layer's O-projection input of the last generation step (tllm_session_get_tap)
-    char* tap_attn = nullptr; // [num_layers][B][Dr] fp16, or s8 when the O-projection's prologue quantises (SmoothQuant)
-    int tap_layer = -1;       // layer whose K4 launch is being issued (gemv() routes x_pro_out there)
+    bool debug_taps = false; // tests: keep every layer's GEMV inputs of the last generation step (tllm_session_get_tap[_ex])
+    // tap w of layer li: the activation exactly as GEMV w consumes it, behind its prologue (RMSNorm / split merge / quantiser):
+    //   0 QKV input [B, D]   1 O-projection input [B, Dr]   2 gate|up input [B, D]   3 down-projection input [B, Ir]
+    // fp16, or s8 where the path quantises (SmoothQuant) - the four quantisers of the SmoothQuant layer
+    char* tap_buf[4] = {nullptr, nullptr, nullptr, nullptr}; // each [num_layers][B][width] x 2 bytes
+    char* tap_dst = nullptr; // where the launch being issued leaves its prologue's result (gemv() routes x_pro_out there)
+    int tap_width(int which) const { return which == 1 ? Dr : (which == 3 ? Ir : hidden); }
+    char* tap_ptr(int which, int li) const { return tap_buf[which] + (size_t) li * B * tap_width(which) * 2; }
 
     // ---- runtime state (setup)
     int B = 0, max_in = 0, max_new = 0, Smax = 0;
@@ -182,6 +188,11 @@ struct tllm_session
     float* logits_local = nullptr;
     void* last_hidden = nullptr;
     void* woq_scratch = nullptr;
+    // tensor-parallel decode with the fused peer-to-peer seam (kernels/p2p_allreduce.hip): this rank's partial projection
+    // output, the normalised (+ quantised) row the next GEMV consumes, its per-token scales
+    void* ar_partial = nullptr; // [B, D] fp16
+    void* ar_norm = nullptr;    // [B, D] fp16 | s8
+    float* ar_scale = nullptr;  // [B]
     void* mmha_ws = nullptr;
     void* ctx_ws = nullptr; // V^T scratch of the MFMA context attention
     int32_t *ids_in = nullptr, *cur_ids = nullptr, *out_ids = nullptr, *seq_len = nullptr, *in_len = nullptr,
@@ -383,7 +394,7 @@ struct tllm_session
     // decode: fused skinny GEMM
     int gemv(const Linear& L, int M, int pro, int epi, const void* xin, int64_t ldx, const void* gamma,
         const float* in_qscale, const void* residual, const float* epi_scale, void* y, int64_t ldy, int out_dtype,
-        const Linear* up, hipStream_t st)
+        const Linear* up, hipStream_t st, const float* row_scales = nullptr)
     {
         GemvParams p;
         p.wtype = L.wtype;
@@ -401,6 +412,11 @@ struct tllm_session
         p.scale_row = L.act_scale;
         p.per_channel = L.per_channel;
         p.per_token = 0;
+        if (row_scales) // activations quantised per token upstream (the fused all-reduce tail): one dequantisation scale per row
+        {
+            p.scale_row = row_scales;
+            p.per_token = 1;
+        }
         p.gamma = gamma;
         p.eps = eps;
         p.act_scale = in_qscale;
@@ -418,8 +434,8 @@ struct tllm_session
             p.attn_tchunk = attn_tchunk;
             p.attn_nsmax = attn_ns;
         }
-        if (tap_layer >= 0 && tap_attn)
-            p.x_pro_out = tap_attn + (size_t) tap_layer * B * Dr * (sq ? 1 : 2);
+        if (tap_dst)
+            p.x_pro_out = tap_dst;
         if (up)
         {
             p.w_up = up->w;
@@ -466,12 +482,23 @@ struct tllm_session
         // step's 8 KB vectors, a ring is the better transport for the prefill's megabytes)
         const int64_t cap = comm::p2p::slot_capacity(tp) / 2 / 8 * 8; // fp16 elements per exchange, whole 16-byte vectors
         if (cap > 0 && n % 8 == 0 && !comm::has_comm(group))
+        {
+            static bool warned = false;
+            if (!warned && n > 8 * cap)
+            {
+                warned = true;
+                fprintf(stderr, "[tllm] warning: a %lld-element all-reduce goes through the peer-to-peer inbox in %lld pieces of %lld "
+                                "(no RCCL communicator is registered for this group): register one (tllm_comm_init_rank) or size the inbox "
+                                "(tllm_comm_p2p_create max_bytes) for the prefill\n",
+                    (long long) n, (long long) ((n + cap - 1) / cap), (long long) cap);
+            }
             return timed(PC_COMM, st, [&] {
                 for (int64_t off = 0; off < n; off += cap)
                     if (comm::p2p::all_reduce_f16(static_cast<char*>(buf) + off * 2, n - off < cap ? n - off : cap, st))
                         return 1;
                 return 0;
             });
+        }
         return timed(PC_COMM, st, [&] { return comm::all_reduce_sum(group, buf, buf, n, TLLM_HALF, st) ? 1 : 0; });
     }
 
@@ -655,12 +682,12 @@ struct tllm_session
         return 0;
     }
 
-    int run_head(const void* h, int rows, hipStream_t st)
+    int run_head(const void* h, int rows, hipStream_t st, bool normalised = false)
     {
         logit_rows = rows;
         gemv_cls = PC_GEMV_HEAD;
-        const int head_rc = gemv(head, rows, PRO_RMSNORM, EPI_NONE, h, hidden, lnf, nullptr, nullptr, nullptr, logits_local, Vr, DT_FLOAT,
-            nullptr, st);
+        const int head_rc = gemv(head, rows, normalised ? PRO_NONE : PRO_RMSNORM, EPI_NONE, h, hidden, lnf, nullptr, nullptr, nullptr,
+            logits_local, Vr, DT_FLOAT, nullptr, st);
         gemv_cls = PC_GEMV_LAYER;
         RUN(head_rc);
         if (tp > 1 || force_comm)
@@ -750,15 +777,53 @@ struct tllm_session
         if (ok < 0 && (beam > 1 || D % 8 != 0)) // greedy: the sampler gathered the row already
             RUN(timed(PC_OTHER, st, [&] { return launch_embedding(x, cur_ids, emb, B, D, vocab, st); }));
         const bool r0 = rank == 0;
+        // Tensor parallel over the peer-to-peer transport: the layer seam  all-reduce -> residual add -> next RMSNorm (-> quantiser)
+        // is ONE launch (kernels/p2p_allreduce.hip fused tail; reference seam: PY/quantization/layer.py:215,377 allreduce,
+        // Q/llama_model.py:107-118 adds, PY/layers/normalization.py:33-54).  The row-parallel GEMVs then write their bare partial
+        // sums, every rank adds the residual itself (no rank is special), and the consuming GEMV starts from its operand type.
+        // RCCL (or TLLM_NO_FUSED_ALLREDUCE=1) keeps the three-stage path: rank 0 carries the residual, the consumers normalise.
+        static const bool fused_off = getenv("TLLM_NO_FUSED_ALLREDUCE") != nullptr;
+        const bool fused_ar = tp > 1 && !fused_off && D % 8 == 0 && comm::p2p::usable(tp, (int64_t) B * D * 2);
+        const int ar_quant = !sq ? 0 : (per_token ? 2 : 1);
+        const float* ar_rows = (sq && per_token) ? ar_scale : nullptr; // per-token scales behind the fused quantiser
+        auto fused_seam = [&](const void* gamma, const float* qscale, int quant) {
+            comm::p2p::FusedTail t;
+            t.x = x;
+            t.gamma = gamma;
+            t.eps = eps;
+            t.norm_out = ar_norm;
+            t.quant = quant;
+            t.quant_scale = qscale;
+            t.dyn_scale_out = ar_scale;
+            return timed(PC_COMM, st, [&] { return comm::p2p::all_reduce_residual_norm(ar_partial, B, D, t, st) ? 1 : 0; });
+        };
         for (int li = 0; li < num_layers; ++li)
         {
             Layer& L = layers[li];
             const int pro_norm = !sq ? PRO_RMSNORM : (per_token ? PRO_RMSNORM_QDYN : PRO_RMSNORM_QSTATIC);
             const int pro_q = !sq ? PRO_NONE : (per_token ? PRO_QDYN : PRO_QSTATIC);
             // K1
+            const bool taps = debug_taps && ok < 0;
             if (ok < 0 || ok == 1)
-            RUN(gemv(L.qkv, B, pro_norm, EPI_NONE, x, D, L.ln1, L.ln1_scale, nullptr, nullptr, qkv, 3 * Dr, DT_HALF,
-                nullptr, st));
+            {
+                int rc1;
+                if (fused_ar && li > 0)
+                {
+                    // the previous layer's seam left input_layernorm's output (quantised for SmoothQuant) in ar_norm
+                    if (taps)
+                        HIP_OK(hipMemcpyAsync(tap_ptr(0, li), ar_norm, (size_t) B * D * (sq ? 1 : 2), hipMemcpyDeviceToDevice, st));
+                    rc1 = gemv(L.qkv, B, PRO_NONE, EPI_NONE, ar_norm, D, nullptr, nullptr, nullptr, nullptr, qkv, 3 * Dr, DT_HALF,
+                        nullptr, st, ar_rows);
+                }
+                else
+                {
+                    tap_dst = taps ? tap_ptr(0, li) : nullptr;
+                    rc1 = gemv(L.qkv, B, pro_norm, EPI_NONE, x, D, L.ln1, L.ln1_scale, nullptr, nullptr, qkv, 3 * Dr, DT_HALF,
+                        nullptr, st);
+                    tap_dst = nullptr;
+                }
+                RUN(rc1);
+            }
             // K2/K3
             MmhaParams m;
             m.batch = B;
@@ -796,36 +861,84 @@ struct tllm_session
             const int pro_o = !attn_fused ? pro_q : (!sq ? PRO_ATTN : (per_token ? PRO_ATTN_QDYN : PRO_ATTN_QSTATIC));
             if (ok < 0 || ok == 4)
             {
-                if (debug_taps && ok < 0)
+                if (taps)
                 {
                     if (pro_o == PRO_NONE) // nothing is transformed in the prologue: the input itself is the tap
-                        HIP_OK(hipMemcpyAsync(tap_attn + (size_t) li * B * Dr * 2, ctx, (size_t) B * Dr * 2, hipMemcpyDeviceToDevice, st));
+                        HIP_OK(hipMemcpyAsync(tap_ptr(1, li), ctx, (size_t) B * Dr * 2, hipMemcpyDeviceToDevice, st));
                     else
-                        tap_layer = li;
+                        tap_dst = tap_ptr(1, li);
                 }
-                const int rc4 = gemv(L.dense, B, pro_o, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE, ctx, Dr, nullptr, L.attn_qscale, x,
-                    nullptr, x, D, DT_HALF, nullptr, st);
-                tap_layer = -1;
+                const int rc4 = fused_ar
+                    ? gemv(L.dense, B, pro_o, EPI_NONE, ctx, Dr, nullptr, L.attn_qscale, nullptr, nullptr, ar_partial, D, DT_HALF, nullptr, st)
+                    : gemv(L.dense, B, pro_o, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE, ctx, Dr, nullptr, L.attn_qscale, x, nullptr, x, D,
+                          DT_HALF, nullptr, st);
+                tap_dst = nullptr;
                 RUN(rc4);
             }
             if (ok < 0)
-                RUN(allreduce(x, (int64_t) B * D, st));
+            {
+                if (fused_ar) // x <- x + sum_r O_r(ctx_r);  ar_norm <- post_layernorm(x) [-> int8]
+                    RUN(fused_seam(L.ln2, L.ln2_scale, ar_quant));
+                else
+                    RUN(allreduce(x, (int64_t) B * D, st));
+            }
             // K5
             const bool q_inter = sq && !per_token;
             if (ok < 0 || ok == 5)
-            RUN(gemv(L.fc, B, pro_norm, q_inter ? EPI_SWIGLU_QSTATIC : EPI_SWIGLU, x, D, L.ln2, L.ln2_scale, nullptr,
-                L.mlp_qscale, q_inter ? (void*) q8 : inter_buf, Ir, q_inter ? DT_INT8 : DT_HALF, &L.gate, st));
+            {
+                int rc5;
+                if (fused_ar)
+                {
+                    if (taps)
+                        HIP_OK(hipMemcpyAsync(tap_ptr(2, li), ar_norm, (size_t) B * D * (sq ? 1 : 2), hipMemcpyDeviceToDevice, st));
+                    rc5 = gemv(L.fc, B, PRO_NONE, q_inter ? EPI_SWIGLU_QSTATIC : EPI_SWIGLU, ar_norm, D, nullptr, nullptr, nullptr,
+                        L.mlp_qscale, q_inter ? (void*) q8 : inter_buf, Ir, q_inter ? DT_INT8 : DT_HALF, &L.gate, st, ar_rows);
+                }
+                else
+                {
+                    tap_dst = taps ? tap_ptr(2, li) : nullptr;
+                    rc5 = gemv(L.fc, B, pro_norm, q_inter ? EPI_SWIGLU_QSTATIC : EPI_SWIGLU, x, D, L.ln2, L.ln2_scale, nullptr,
+                        L.mlp_qscale, q_inter ? (void*) q8 : inter_buf, Ir, q_inter ? DT_INT8 : DT_HALF, &L.gate, st);
+                    tap_dst = nullptr;
+                }
+                RUN(rc5);
+            }
             // K6
             if (ok < 0 || ok == 6)
-            RUN(gemv(L.proj, B, q_inter ? PRO_NONE : pro_q, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE,
-                q_inter ? (const void*) q8 : inter_buf, Ir, nullptr, L.mlp_qscale, x, nullptr, x, D, DT_HALF, nullptr,
-                st));
+            {
+                const int pro6 = q_inter ? PRO_NONE : pro_q;
+                if (taps)
+                {
+                    if (pro6 == PRO_NONE) // the SwiGLU epilogue left the operand (s8 behind the static quantiser, fp16 otherwise)
+                        HIP_OK(hipMemcpyAsync(tap_ptr(3, li), q_inter ? (const void*) q8 : inter_buf, (size_t) B * Ir * (q_inter ? 1 : 2),
+                            hipMemcpyDeviceToDevice, st));
+                    else
+                        tap_dst = tap_ptr(3, li);
+                }
+                const int rc6 = fused_ar
+                    ? gemv(L.proj, B, pro6, EPI_NONE, q_inter ? (const void*) q8 : inter_buf, Ir, nullptr, L.mlp_qscale, nullptr, nullptr,
+                          ar_partial, D, DT_HALF, nullptr, st)
+                    : gemv(L.proj, B, pro6, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE, q_inter ? (const void*) q8 : inter_buf, Ir, nullptr,
+                          L.mlp_qscale, x, nullptr, x, D, DT_HALF, nullptr, st);
+                tap_dst = nullptr;
+                RUN(rc6);
+            }
             if (ok < 0)
-                RUN(allreduce(x, (int64_t) B * D, st));
+            {
+                if (fused_ar)
+                {
+                    // x <- x + sum_r proj_r(...);  ar_norm <- the NEXT layer's input_layernorm(x) [-> int8], or ln_f(x) for the head
+                    const bool last = li + 1 == num_layers;
+                    RUN(fused_seam(last ? lnf : layers[li + 1].ln1, last ? nullptr : layers[li + 1].ln1_scale, last ? 0 : ar_quant));
+                }
+                else
+                    RUN(allreduce(x, (int64_t) B * D, st));
+            }
         }
         if (ok >= 0)
             return 0;
-        RUN(run_head(x, B, st));
+        const bool head_normed = tp > 1 && !getenv("TLLM_NO_FUSED_ALLREDUCE") && D % 8 == 0 && comm::p2p::usable(tp, (int64_t) B * D * 2);
+        RUN(run_head(head_normed ? ar_norm : x, B, st, head_normed));
         RUN(run_sampler(1, st));
         return 0;
     }
@@ -1085,6 +1198,7 @@ int verify_engine_network(tllm_session_t s, const std::vector<EngineEntry>& ents
     d.int8_kv = s->int8_kv;
     d.paged = s->paged_kv;
     d.packed = s->packed;
+    d.neox = s->neox != 0;
     // has_per_channel_scaling of every SmoothQuant GEMM = what the scale tensor the engine carries implies (a "per tensor"
     // QKV scale is stored as one factor per channel: examples/llama_quant/weight.py)
     for (const char* n : {"attention.qkv", "attention.dense", "mlp.fc", "mlp.gate", "mlp.proj"})
@@ -1248,11 +1362,18 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
                 mx = std::max(mx, gemm_woq_scratch_bytes(l->N, l->K));
         RUN(s->dalloc(&s->woq_scratch, mx));
     }
-    s->tap_attn = nullptr;
-    if (s->debug_taps)
+    RUN(s->dalloc(&s->ar_partial, (size_t) B * D * 2));
+    RUN(s->dalloc(&s->ar_norm, (size_t) B * D * 2));
+    RUN(s->dalloc(&s->ar_scale, (size_t) B * 4));
+    for (int w = 0; w < 4; ++w)
     {
-        RUN(s->dalloc(&s->tap_attn, (size_t) s->num_layers * B * s->Dr * 2));
-        HIP_OK(hipMemset(s->tap_attn, 0, (size_t) s->num_layers * B * s->Dr * 2));
+        s->tap_buf[w] = nullptr;
+        if (s->debug_taps)
+        {
+            const size_t nb = (size_t) s->num_layers * B * s->tap_width(w) * 2;
+            RUN(s->dalloc(&s->tap_buf[w], nb));
+            HIP_OK(hipMemset(s->tap_buf[w], 0, nb));
+        }
     }
     RUN(s->dalloc(&s->cu_dev, (size_t) (Bc + 1) * 4));
     RUN(s->dalloc(&s->last_rows, (size_t) Bc * 4));
@@ -1317,7 +1438,9 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
 // service, so that later sessions of this process fall back to RCCL.
 static int check_comm(tllm_session_t s)
 {
-    if ((s->tp == 1 && !s->force_comm) || !comm::p2p::attached())
+    // only while the transport is IN SERVICE: once a time-out has taken it out (below), later calls run over RCCL and the
+    // words that recorded the failure must not fail them (disable_after_error clears them as well)
+    if ((s->tp == 1 && !s->force_comm) || !comm::p2p::enabled())
         return 0;
     uint32_t e = 0;
     if (comm::p2p::error_flag(&e) != 0)
@@ -1327,14 +1450,15 @@ static int check_comm(tllm_session_t s)
     }
     if (e)
     {
-        comm::p2p::enable(false);
+        comm::p2p::disable_after_error();
         if (s->graph) // the captured step holds the peer-to-peer launches
         {
             (void) hipGraphExecDestroy(s->graph);
             s->graph = nullptr;
         }
-        set_error("session: a peer-to-peer all-reduce timed out waiting for a rank (epoch %u); the results of this call are "
-                  "invalid and the peer-to-peer transport is disabled for this process", e);
+        set_error("session: a peer-to-peer all-reduce timed out waiting for a rank (%s, epoch %u); the results of this call are "
+                  "invalid and the peer-to-peer transport is out of service on every rank of the group (later calls use RCCL)",
+            (e & 0x80000000u) ? "reported by a peer" : "on this rank", e & 0x7fffffffu);
         return 1;
     }
     return 0;
@@ -1718,28 +1842,33 @@ int32_t tllm_session_force_tokens(tllm_session_t s, const int32_t* ids, tllm_str
     return 0;
 }
 
-int32_t tllm_session_get_tap(tllm_session_t s, int32_t layer, void* host, size_t nbytes, tllm_stream_t stream)
+int32_t tllm_session_get_tap_ex(tllm_session_t s, int32_t layer, int32_t which, void* host, size_t nbytes, tllm_stream_t stream)
 {
-    if (!s || !s->B || !host || layer < 0 || layer >= s->num_layers)
+    if (!s || !s->B || !host || layer < 0 || layer >= s->num_layers || which < 0 || which > 3)
     {
         set_error("tllm_session_get_tap: bad arguments / setup not called");
         return 1;
     }
-    if (!s->tap_attn)
+    if (!s->tap_buf[which])
     {
         set_error("tllm_session_get_tap: the session was not created with debug_taps=1");
         return 1;
     }
-    const size_t row = (size_t) s->B * s->Dr * (s->sq ? 1 : 2);
+    const size_t row = (size_t) s->B * s->tap_width(which) * (s->sq ? 1 : 2);
     if (nbytes != row)
     {
         set_error("tllm_session_get_tap: buffer of %zu bytes, the tap holds %zu", nbytes, row);
         return 1;
     }
     hipStream_t st = s->pick(stream);
-    HIP_OK(hipMemcpyAsync(host, s->tap_attn + (size_t) layer * row, row, hipMemcpyDeviceToHost, st));
+    HIP_OK(hipMemcpyAsync(host, s->tap_ptr(which, layer), row, hipMemcpyDeviceToHost, st));
     HIP_OK(hipStreamSynchronize(st));
     return 0;
+}
+
+int32_t tllm_session_get_tap(tllm_session_t s, int32_t layer, void* host, size_t nbytes, tllm_stream_t stream)
+{
+    return tllm_session_get_tap_ex(s, layer, 1, host, nbytes, stream);
 }
 
 void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer)

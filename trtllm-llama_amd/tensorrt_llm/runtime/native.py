@@ -60,6 +60,8 @@ def _lib():
     lib.tllm_session_get_step_state.restype = c.c_int32
     lib.tllm_session_get_tap.argtypes = [c.c_void_p, c.c_int32, c.c_void_p, c.c_size_t, c.c_void_p]
     lib.tllm_session_get_tap.restype = c.c_int32
+    lib.tllm_session_get_tap_ex.argtypes = [c.c_void_p, c.c_int32, c.c_int32, c.c_void_p, c.c_size_t, c.c_void_p]
+    lib.tllm_session_get_tap_ex.restype = c.c_int32
     lib.tllm_session_force_tokens.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p]
     lib.tllm_session_force_tokens.restype = c.c_int32
     lib.tllm_session_step_bytes.argtypes = [c.c_void_p, c.c_int32]
@@ -220,6 +222,15 @@ class NativeSession:
         """O-projection input of the last generation step (debug_taps=1): [batch * beam, H/tp * Dh] fp16, int8 for SmoothQuant."""
         out = np.empty((self.batch * self.beam, heads_x_dh), np.int8 if quantised else np.float16)
         _check(_lib().tllm_session_get_tap(self._h, layer, out.ctypes.data, out.nbytes, stream), 'get_tap')
+        return out
+
+    TAPS = {'qkv_in': 0, 'o_in': 1, 'mlp_in': 2, 'proj_in': 3}
+
+    def tap(self, layer: int, which: str, width: int, quantised: bool, stream: int = 0) -> np.ndarray:
+        """Input of one of the layer's four GEMMs in the last generation step, behind its prologue (debug_taps=1):
+        [batch * beam, width] fp16, int8 for SmoothQuant (the output of that GEMM's activation quantiser)."""
+        out = np.empty((self.batch * self.beam, width), np.int8 if quantised else np.float16)
+        _check(_lib().tllm_session_get_tap_ex(self._h, layer, self.TAPS[which], out.ctypes.data, out.nbytes, stream), 'get_tap_ex')
         return out
 
     def step_bytes(self, context_len: int) -> int:
