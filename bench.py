@@ -231,6 +231,26 @@ def sq_gemm_mfma_report(torch, dev, M=1024):
         sr = torch.full((M, ), 1e-2, dtype=torch.float32, device=dev)
         c = torch.empty((M, N), dtype=torch.float16, device=dev)
         q = GemmParams(3, 1, M, N, K, a.data_ptr(), K, w.data_ptr(), K, sc.data_ptr(), sr.data_ptr(), 1, 1, c.data_ptr(), N)
+        # the kernel is the one the on-device tactic profile finds fastest for this shape on THIS box (what a session does at
+        # setup, tllm_gemm_profile; reference: int8_gemm_template.h:372-457) - the static rule's pick is reported beside it
+        lib.tllm_gemm_tactics_clear()
+        static_us = None
+        try:
+            for _ in range(3):
+                lib.tllm_gemm(ctypes.byref(q), stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                lib.tllm_gemm(ctypes.byref(q), stream)
+            e1.record()
+            torch.cuda.synchronize()
+            static_us = e0.elapsed_time(e1) * 1e3 / 10
+        except Exception:
+            pass
+        tactic, tactic_us = ctypes.c_int32(0), ctypes.c_float(0)
+        lib.tllm_gemm_profile.argtypes = [ctypes.c_int32] * 4 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        if lib.tllm_gemm_profile(3, M, N, K, ctypes.byref(tactic), ctypes.byref(tactic_us), stream):
+            raise RuntimeError(capi.last_error())
         for _ in range(3):
             if lib.tllm_gemm(ctypes.byref(q), stream):
                 raise RuntimeError(capi.last_error())
@@ -245,7 +265,8 @@ def sq_gemm_mfma_report(torch, dev, M=1024):
             reps.append(e0.elapsed_time(e1) * 1e3 / iters)
         us, us_med = min(reps), sorted(reps)[len(reps) // 2]
         tops = 2.0 * M * N * K / us / 1e6
-        out[name] = {'M': M, 'N': N, 'K': K, 'us': us, 'us_median': us_med, 'TOP/s': tops, 'frac_of_5POPs': tops / 5000.0}
+        out[name] = {'M': M, 'N': N, 'K': K, 'us': us, 'us_median': us_med, 'TOP/s': tops, 'frac_of_5POPs': tops / 5000.0,
+                     'tactic': int(tactic.value), 'tactic_profile_us': float(tactic_us.value), 'static_rule_us': static_us}
         # the clock the chip held under this kernel (it clocks to its power budget: dense random-operand int8 MFMA work next to
         # the LDS / L2 traffic that feeds it runs well below 2.4 GHz): every workgroup reports its shader cycles against the
         # constant 100 MHz counter (tllm_gemm_set_clock_probe); 5 POP/s is the nominal peak AT 2.4 GHz
@@ -371,11 +392,26 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher - one process per GPU under torch.distributed.run
+        # (the reference's model is the same, one process per GPU under mpirun: PY/_utils.py:181-190, Q/run.py:83-93)
+        shared = os.environ.get('TLLM_TEST_SHARED_GPU') == '1'
+        if torch.cuda.device_count() < args.gpus and not shared:
+            raise SystemExit(f'bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible')
+        import socket
+        sock = socket.socket()
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL / hipIpc between the rank processes need it
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print('[bench] re-launching as: ' + ' '.join(cmd), file=sys.stderr, flush=True)
+        os.execv(sys.executable, cmd)
+    if world != args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus} inside a launcher of WORLD_SIZE {world}: start it with --nproc-per-node {args.gpus}')
     if os.environ.get('TLLM_TEST_SHARED_GPU') == '1':
         local = 0
     torch.cuda.set_device(local)
@@ -397,8 +433,19 @@ def main():
         mapping = Mapping(world, rank)
         ensure_tp_communicator(mapping)
         allreduce_path = 'p2p' if enable_p2p_allreduce(mapping) else 'rccl'
+        if allreduce_path == 'p2p' and not os.environ.get('TLLM_NO_FUSED_ALLREDUCE'):
+            allreduce_path = 'p2p, fused with the residual add and the next RMSNorm / quantiser (one launch per layer seam)'
+        # what the RCCL communicator itself says about the group (None on the shared-GPU test rig, which has none)
+        import ctypes
+        from tensorrt_llm.plugin import capi
+        lib = capi.load_library()
+        grp = (ctypes.c_int32 * world)(*mapping.tp_group)
+        nr, me = ctypes.c_int32(0), ctypes.c_int32(-1)
+        lib.tllm_comm_group_info.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+        rccl_ranks = int(nr.value) if lib.tllm_comm_group_info(grp, world, ctypes.byref(nr), ctypes.byref(me)) == 0 else None
     else:
         allreduce_path = None
+        rccl_ranks = None
 
     # Everything runs on a torch stream of its own, not on the legacy default stream: handed the NULL stream, the session
     # replays its graph on a private stream, and a timing event recorded on the NULL stream next to those replays (round 1's
@@ -480,6 +527,9 @@ def main():
         'config': {'workload': f'LLaMA-7B ({args.layers} layers) {names[args.config]}, batch 1, context {args.context} '
                                f'(synthetic KV), greedy decode, TP={world}', 'global_batch': 1,
                    'seq_len': args.context, 'parallelism': f'tp{world}', 'allreduce': allreduce_path,
+                   'rccl_communicator_ranks': rccl_ranks,
+                   'comm_us_per_step': (prof['comm'][0] * 1e3 / prof_steps) if world > 1 else 0.0,
+                   'comm_launches_per_step': (prof['comm'][1] / prof_steps) if world > 1 else 0,
                    'step_launch': 'hipGraph replay' if res.get('graph', True) else 'eager (graph capture failed)'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,

@@ -34,7 +34,8 @@ typedef struct tllm_session* tllm_session_t;
  *   paged_kv_cache (0; 1: every layer's cache is a pool of [Hr, tokens_per_block, Dh] blocks reached through a per-sequence
  *   table of block pointers - K/kvCacheUtils.h:34-112, PY/runtime/kv_cache_manager.py; the table is filled at setup),
  *   tokens_per_block (64; a power of two),
- *   debug_taps (0; 1: keep per-layer intermediates of the generation step for tllm_session_get_tap).
+ *   debug_taps (0; 1: keep per-layer intermediates of the generation step for tllm_session_get_tap),
+ *   gemm_tactics (optional; the table tllm_gemm_tactics_export wrote, as the builder stores it in the engine).
  * Returns NULL on error (tllm_last_error()). */
 tllm_session_t tllm_session_create(const char* config_text);
 
@@ -144,7 +145,9 @@ int32_t tllm_session_get_tap(tllm_session_t s, int32_t layer, void* host, size_t
  *         1  O-projection in  [B, H/tp * Dh]  (= tllm_session_get_tap)
  *         2  fc | gate input  [B, hidden]     behind post_layernorm (+ its quantiser)
  *         3  proj input       [B, inter/tp]   SwiGLU output (+ its quantiser)
- * fp16, or int8 with SmoothQuant - parity tests compare these against the oracle in LSBs.  HOST buffer of exactly that size. */
+ *         4  the layer's input row of the residual stream [B, hidden], always fp16
+ * 0..3: fp16, or int8 with SmoothQuant - parity tests compare these against the oracle in LSBs, and check every stage of the layer
+ * as a function of the engine's OWN previous tap (no compounding across stages).  HOST buffer of exactly that size. */
 int32_t tllm_session_get_tap_ex(tllm_session_t s, int32_t layer, int32_t which, void* host, size_t nbytes, tllm_stream_t stream);
 /* Bytes a generation step must move from HBM at context length L (weights + KV read + KV write): the
  * algorithmic-bytes model of SURVEY.md §8(d), evaluated for this session's configuration. */
@@ -228,6 +231,24 @@ int32_t tllm_gemm(const tllm_gemm_params_t* p, tllm_stream_t stream);
  * prefill.  p->w / p->scale_col: the matrix that goes through SiLU; p->c: int8 output. */
 int32_t tllm_gemm_swiglu_quant(const tllm_gemm_params_t* p, const void* w_up, const void* scale_col_up, const float* quant_scale,
     tllm_stream_t stream);
+/* On-device tactic selection for the prefill GEMMs (M >= 32; SmoothQuant int8 = wtype 3, fp16 = wtype 0 - also what the weight-only
+ * prefill runs on its expanded weights).  Takes the place of the profile the reference's SmoothQuant GEMM plugin runs when an
+ * engine is built - every CUTLASS tile configuration timed on the device per M bucket
+ * (K/cutlass_kernels/int8_gemm/int8_gemm_template.h:372-457), the winners kept in the plugin's serialisation
+ * (P/smoothQuantGemmPlugin/smoothQuantGemmPlugin.cpp:253-282):
+ *   profile : times every candidate kernel (tile shape x lock-step / phased pipeline) for C[M, N] = A[M, K] W[N, K]^T on random
+ *             operands of its own and records the fastest in the process-wide table; best_cfg = its id (as tllm_gemm_set_tile_cfg
+ *             takes them), 0 when no MFMA kernel serves the shape.  A session does this for its own four GEMM shapes at
+ *             tllm_session_setup (unless the engine brought the table, or TLLM_GEMM_TACTICS=off);
+ *   export  : the table as text "wtype:M:N:K:cfg:us;..." - returns the bytes needed including the terminator; the builder stores
+ *             it in the engine file (header line `gemm_tactics=`), tllm_session_load_engine / tllm_session_create import it;
+ *   lookup  : the kernel id tllm_gemm will use for the shape (exact M, else the nearest profiled M of the same power-of-two
+ *             bucket), 0 = the static "fewest workgroup rounds" rule. */
+int32_t tllm_gemm_profile(int32_t wtype, int32_t M, int32_t N, int32_t K, int32_t* best_cfg, float* best_us, tllm_stream_t stream);
+int64_t tllm_gemm_tactics_export(char* buf, int64_t capacity);
+int32_t tllm_gemm_tactics_import(const char* text);
+void tllm_gemm_tactics_clear(void);
+int32_t tllm_gemm_tactic_lookup(int32_t wtype, int32_t M, int32_t N, int32_t K);
 /* Microbenchmark hook: while set (non-NULL), every workgroup of the phased SmoothQuant GEMM writes {shader cycles, ticks of
  * the constant 100 MHz counter} over its lifetime to device_buffer[2 * workgroup] (uint64) - the clock the chip held. */
 void tllm_gemm_set_clock_probe(void* device_buffer);

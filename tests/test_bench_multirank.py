@@ -14,21 +14,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('world,layers', [(2, 4), (4, 2)])
-def test_bench_ranks_sharing_one_gpu(world, layers):
+@pytest.mark.parametrize('world,layers,launcher', [(2, 4, 'torchrun'), (4, 2, 'torchrun'), (2, 2, 'self')])
+def test_bench_ranks_sharing_one_gpu(world, layers, launcher):
+    """launcher 'torchrun': the driver's command line.  'self': plain `python bench.py --gpus N` - bench.py becomes its own launcher
+    (re-executes itself under torch.distributed.run) instead of exiting (missing #2)."""
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, TLLM_TEST_SHARED_GPU='1')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr',
-                        '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', '8',
-                        '--warmup', '2', '--layers', str(layers), '--no-prefill', '--no-fp16-ref', '--no-cpu-baseline'],
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    head = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+            '--master-port', str(port)] if launcher == 'torchrun' else [sys.executable]
+    r = subprocess.run(head + [os.path.join(ROOT, 'bench.py'), '--gpus', str(world), '--steps', '8', '--warmup', '2', '--layers', str(layers),
+                               '--no-prefill', '--no-fp16-ref', '--no-cpu-baseline'],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 only
     d = json.loads(lines[0])
-    assert d['n_gpus'] == world and d['config']['parallelism'] == f'tp{world}' and d['config']['allreduce'] == 'p2p'
+    assert d['n_gpus'] == world and d['config']['parallelism'] == f'tp{world}' and d['config']['allreduce'].startswith('p2p, fused')
+    assert d['config']['rccl_communicator_ranks'] is None  # the shared-GPU rig has no RCCL communicator
     assert d['step']['outputs_finite'] and d['value'] > 0 and d['steps'] == 8
-    assert d['step']['launches_per_step']['comm'] == 2 * layers + 0  # two all-reduces per layer (the gather is in the head)
+    # one launch per layer seam: two per layer (the logits' gather is in the head) - all-reduce, residual add, next RMSNorm and
+    # the SmoothQuant quantiser of each seam in that one launch
+    assert d['step']['launches_per_step']['comm'] == 2 * layers
+    assert d['config']['comm_launches_per_step'] == 2 * layers and d['config']['comm_us_per_step'] > 0

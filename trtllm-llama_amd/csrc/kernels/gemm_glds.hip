@@ -534,21 +534,50 @@ int launch_wt(const GemmParams& p, int cfg, hipStream_t stream)
 
 } // namespace
 
+static bool glds_serves(const GemmParams& p)
+{
+    const bool sq = p.wtype == W_INT8_SQ;
+    if (!sq && p.wtype != W_FP16)
+        return false;
+    const int es = sq ? 1 : 2;
+    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || ((p.lda * es) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)
+        || (p.ldw & 15) || ((p.K * es) % 128) || p.K <= 0 || p.M < 32)
+        return false;
+    if (!sq && p.out_dtype == DT_INT32)
+        return false;
+    if (p.residual && (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)))
+        return false; // the fused residual lives in the vector epilogue
+    return true;
+}
+
+// exactly kernel `cfg`, no fall-back: 0 launched, -1 launch error, 1 this kernel does not serve the problem (the tactic profiler)
+int launch_gemm_cfg(const GemmParams& p, int cfg, hipStream_t stream)
+{
+    if (!glds_serves(p))
+        return 1;
+    const bool sq = p.wtype == W_INT8_SQ;
+    if ((cfg >= 1 && cfg <= kNumCfg) || cfg == 36 || cfg == 37)
+    {
+        // a tile far larger than the problem only burns time in the sweep
+        return sq ? launch_wt<W_INT8_SQ>(p, cfg, stream) : launch_wt<W_FP16>(p, cfg, stream);
+    }
+    return sq ? launch_gemm_sqp(p, cfg, stream) : 1;
+}
+
 // returns 0 on success, -1 on a launch error, 1 when the shape / type is not served by this kernel
 int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
 {
     const bool sq = p.wtype == W_INT8_SQ;
-    if (!sq && p.wtype != W_FP16)
+    if (!glds_serves(p))
         return 1;
-    const int es = sq ? 1 : 2;
-    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || ((p.lda * es) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15)
-        || (p.ldw & 15) || ((p.K * es) % 128) || p.K <= 0 || p.M < 32)
-        return 1;
-    if (!sq && p.out_dtype == DT_INT32)
-        return 1;
-    if (p.residual && (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)))
-        return 1; // the fused residual lives in the vector epilogue
     int cfg = gemm_tune_cfg;
+    bool from_table = false;
+    if (cfg <= 0)
+    {
+        // the kernel the on-device profile found fastest for this shape (gemm_tactics.hip), else the static rule below
+        cfg = gemm_tactic_lookup(p.wtype, p.M, p.N, p.K);
+        from_table = cfg > 0;
+    }
     const bool glds_id = (cfg >= 1 && cfg <= kNumCfg) || cfg == 36 || cfg == 37; // ids served by this file's table
     if (sq && cfg > kNumCfg && !glds_id)
     {
@@ -583,7 +612,7 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
             }
         }
     }
-    if (sq && cfg == 6 && gemm_tune_cfg <= 0)
+    if (sq && cfg == 6 && gemm_tune_cfg <= 0 && !from_table)
     {
         // the 256 x 192 SmoothQuant tile has a phased sibling (gemm_sqp.hip) that measures 2-5 % faster at the 7B prefill
         // shapes; exact either way

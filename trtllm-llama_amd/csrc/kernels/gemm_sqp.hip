@@ -61,9 +61,12 @@ __device__ __forceinline__ int swz_g(int row)
     return ((j & 1) << 1) | (j & 4);
 }
 
-template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRIO, int ABL, int RSP, bool DUAL = false>
+// SCL: the tile's scales are staged in LDS ahead of the operand stream (the epilogue issues no global load).  false: the epilogue
+// reads them from global / L2 instead - 1.25 KB of LDS less, which is what lets TWO 128 x 192 workgroups (2 x 80 KB) share a CU.
+template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRIO, int ABL, int RSP, bool DUAL = false, bool SCL = true>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams p)
 {
+    static_assert(SCL || !DUAL, "the fused SwiGLU epilogue reads its scales from LDS");
     constexpr int NW = WR * WC;
     constexpr int AH = WR * MTH * 16, BH = WC * NTH * 16; // rows of an X-half / W-half unit
     constexpr int BM = 2 * AH, BN = 2 * BH;
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     // ---- the tile's scales go to LDS by 4-byte LDS-DMA, ahead of the operand stream (older in the vmcnt order): the
     // epilogue then needs no global load at all.  s_col -> [0, BN) floats, s_row -> [BN, BN + BM) floats behind the buffers
     constexpr int SC_OFF = 2 * BUF;
+    if constexpr (SCL)
     {
         constexpr int CCH = (BN + 63) / 64, RCH = (BM + 63) / 64;
         const char* scb = reinterpret_cast<const char*>(p.scale_col);
@@ -377,6 +381,34 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     }
     const float* sc_l = reinterpret_cast<const float*>(lds + SC_OFF);
     const float* sr_l = sc_l + BN;
+    // the four column scales of output columns [cl, cl + 4) / the row scale of tile row rl
+    auto col_scales = [&](int cl) -> float4 {
+        if constexpr (SCL)
+            return *reinterpret_cast<const float4*>(sc_l + cl);
+        else
+        {
+            const float* g = reinterpret_cast<const float*>(p.scale_col);
+            if (!p.per_channel)
+                return make_float4(g[0], g[0], g[0], g[0]);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const int col = n0 + cl + r;
+                v[r] = g[col < N ? col : N - 1];
+            }
+            return make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto row_scale = [&](int rl) -> float {
+        if constexpr (SCL)
+            return sr_l[rl];
+        else
+        {
+            const int row = m0 + rl;
+            return p.scale_row[p.per_token ? (row < M ? row : M - 1) : 0];
+        }
+    };
     const bool vec16 = p.out_dtype == DT_HALF && !(p.ldc & 7) && !(N & 7) && !(reinterpret_cast<uintptr_t>(p.c) & 15)
         && !(reinterpret_cast<uintptr_t>(p.residual) & 15);
     if (ABL & 8)
@@ -466,14 +498,14 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
             for (int n = 0; n < NTH; ++n)
             {
                 const int cl = j * BH + (wc * NTH + n) * 16 + 4 * (lane >> 4);
-                const float4 sc = *reinterpret_cast<const float4*>(sc_l + cl);
+                const float4 sc = col_scales(cl);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int m = 0; m < MTH; ++m)
                     {
                         const int rl = i * AH + (wr * MTH + m) * 16 + (lane & 15);
-                        const float sr = sr_l[rl];
+                        const float sr = row_scale(rl);
                         const i32x4 a = acc[i][j][m][n];
                         const uint32_t lo = (uint32_t) f2h((float) a[0] * (sc.x * sr)) | ((uint32_t) f2h((float) a[1] * (sc.y * sr)) << 16);
                         const uint32_t hi = (uint32_t) f2h((float) a[2] * (sc.z * sr)) | ((uint32_t) f2h((float) a[3] * (sc.w * sr)) << 16);
@@ -530,7 +562,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                     const int row = m0 + rl;
                     if (row >= M)
                         continue;
-                    const float sr = sr_l[rl];
+                    const float sr = row_scale(rl);
+                    const float4 sc4 = col_scales(cl);
+                    const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
                     const i32x4 a = acc[i][j][m][n];
                     const int64_t o = (int64_t) row * p.ldc + col;
 #pragma unroll
@@ -542,7 +576,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                             reinterpret_cast<int32_t*>(p.c)[o + r] = a[r];
                         else
                         {
-                            const float v = (float) a[r] * (sc_l[cl + r] * sr);
+                            const float v = (float) a[r] * (scv[r] * sr);
                             if (p.out_dtype == DT_FLOAT)
                                 reinterpret_cast<float*>(p.c)[o + r] = v;
                             else
@@ -558,13 +592,13 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         }
 }
 
-template <int WR, int WC, int MTH, int NTH, int DP0, int DP1, bool PRIO, int ABL = 0, int RSP = 0, bool DUAL = false>
+template <int WR, int WC, int MTH, int NTH, int DP0, int DP1, bool PRIO, int ABL = 0, int RSP = 0, bool DUAL = false, bool SCL = true>
 int launch_sqp(const GemmParams& p, hipStream_t stream)
 {
     constexpr int BM = 2 * WR * MTH * 16, BN = 2 * WC * NTH * 16;
-    constexpr size_t smem = (size_t) 2 * (BM + BN) * 128 + (BM + BN) * 4; // operand buffers + the tile's scales
+    constexpr size_t smem = (size_t) 2 * (BM + BN) * 128 + (SCL ? (BM + BN) * 4 : 0); // operand buffers + the tile's scales
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP, DUAL>;
+    auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP, DUAL, SCL>;
     static std::atomic<bool> attr_done{false};
     if (!attr_done)
     {
@@ -617,6 +651,10 @@ int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
     case 29: return launch_sqp<4, 2, 2, 3, -1, 0, false, 16>(p, stream); // every wave its own DMA slot in the phase
     case 30: return launch_sqp<4, 2, 2, 3, 10, 10, false, 0, 1>(p, stream);
     case 18: return launch_sqp<4, 2, 1, 2, 1, 3, true>(p, stream);  // 128 x 128 on 8 waves
+    // 128 x 192 on 4 waves (the 64 x 96 wave tile of the 256 x 192 shape), 80 KB: TWO independent workgroups per CU - one's
+    // prologue / epilogue under the other's main loop, at the price of 43 % more LDS-DMA bytes per MFMA
+    case 40: return launch_sqp<2, 2, 2, 3, 1, 7, false, 16, 0, false, false>(p, stream);
+    case 41: return launch_sqp<2, 2, 2, 3, 2, 8, true, 16, 0, false, false>(p, stream);
     // ablations of the 256 x 192 shape (wrong results on purpose; microbench only)
     case 21: return launch_sqp<4, 2, 2, 3, 2, 8, false, 1>(p, stream); // no DMA in the loop
     case 22: return launch_sqp<4, 2, 2, 3, 2, 8, false, 2>(p, stream); // no MFMA

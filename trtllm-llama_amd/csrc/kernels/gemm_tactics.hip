@@ -1,0 +1,265 @@
+// On-device tactic selection for the prefill GEMMs (SmoothQuant int8 and fp16 MFMA kernels of gemm_glds.hip / gemm_sqp.hip).
+//
+// Reference: the SmoothQuant GEMM plugin times every CUTLASS tile configuration ON THE DEVICE for each M bucket when the engine
+// is built (K/cutlass_kernels/int8_gemm/int8_gemm_template.h:372-457 `profileGemm`: run each candidate, cudaEvent timing, keep
+// the fastest) and stores the winners in its serialisation (P/smoothQuantGemmPlugin/smoothQuantGemmPlugin.cpp:253-282
+// `mMNKProfileMap`), so the engine carries the choice.  Same thing here: a table (weight type, M, N, K) -> kernel id, filled by
+// timing the candidate kernels on random operands (constant operands clock ~20 % higher and flatter the ranking), exported /
+// imported as text so that Builder.build_engine can put it into the engine file (`gemm_tactics=` header line) and
+// tllm_session_load_engine can take it from there.  A static rule ("fewest workgroup rounds", gemm_glds.hip) remains the
+// fall-back for shapes nobody profiled; with the 10 - 15 % box-to-box spread of these kernels it is not always the best pick.
+#include "dev_utils.h"
+#include "kernels.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace tllm
+{
+namespace kernels
+{
+
+int launch_gemm_cfg(const GemmParams& p, int cfg, hipStream_t stream); // gemm_glds.hip: exactly this kernel id, 1 = not served
+
+namespace
+{
+using Key = std::tuple<int, int, int, int>; // wtype, M, N, K
+struct Entry
+{
+    int cfg;
+    float us;
+};
+std::mutex g_mu;
+std::map<Key, Entry> g_table;
+
+// candidates, the static rule's own picks first (a candidate must beat the first served one by > 2 % to replace it)
+const int kSqCandidates[] = {20, 8, 13, 6, 40, 41, 15, 18, 1, 3, 2, 4};
+const int kFp16Candidates[] = {6, 8, 1, 3, 2, 4, 5, 7};
+
+__global__ void fill_random_kernel(uint32_t* p, size_t n_words, uint32_t seed, int fp16)
+{
+    for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t) gridDim.x * blockDim.x)
+    {
+        uint32_t x = (uint32_t) i * 2654435761u + seed;
+        x ^= x >> 16;
+        x *= 0x7feb352du;
+        x ^= x >> 15;
+        x *= 0x846ca68bu;
+        x ^= x >> 16;
+        if (fp16) // two halfs in [-1, 1): sign + exponent 0x3800..0x3bff region (0.5 .. 1) with random mantissa
+            x = (x & 0x83ff83ffu) | 0x38003800u;
+        p[i] = x;
+    }
+}
+
+int bucket_of(int M)
+{
+    int b = 32;
+    while (b < M)
+        b <<= 1;
+    return b;
+}
+} // namespace
+
+int gemm_tactic_lookup(int wtype, int M, int N, int K)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_table.find(Key(wtype, M, N, K));
+    if (it != g_table.end())
+        return it->second.cfg;
+    // the nearest profiled M of the same (N, K) inside the same power-of-two bucket (the reference profiles one M per bucket)
+    const int b = bucket_of(M);
+    int best = 0, dist = 1 << 30;
+    for (auto& kv : g_table)
+        if (std::get<0>(kv.first) == wtype && std::get<2>(kv.first) == N && std::get<3>(kv.first) == K
+            && bucket_of(std::get<1>(kv.first)) == b && std::abs(std::get<1>(kv.first) - M) < dist)
+        {
+            dist = std::abs(std::get<1>(kv.first) - M);
+            best = kv.second.cfg;
+        }
+    return best;
+}
+
+bool gemm_tactic_known(int wtype, int M, int N, int K)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_table.count(Key(wtype, M, N, K)) != 0;
+}
+
+void gemm_tactics_clear()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_table.clear();
+}
+
+std::string gemm_tactics_export()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::ostringstream o;
+    for (auto& kv : g_table)
+    {
+        char line[96];
+        snprintf(line, sizeof(line), "%d:%d:%d:%d:%d:%.2f;", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first),
+            std::get<3>(kv.first), kv.second.cfg, kv.second.us);
+        o << line;
+    }
+    return o.str();
+}
+
+int gemm_tactics_import(const char* text)
+{
+    if (!text)
+        return 0;
+    int n = 0;
+    const char* p = text;
+    std::lock_guard<std::mutex> lk(g_mu);
+    while (*p)
+    {
+        int wt, M, N, K, cfg;
+        float us = 0.f;
+        int used = 0;
+        if (sscanf(p, "%d:%d:%d:%d:%d:%f;%n", &wt, &M, &N, &K, &cfg, &us, &used) < 6 || used <= 0)
+        {
+            set_error("gemm tactics: cannot parse '%.40s'", p);
+            return -1;
+        }
+        if (cfg > 0 && M > 0 && N > 0 && K > 0)
+        {
+            g_table[Key(wt, M, N, K)] = Entry{cfg, us};
+            ++n;
+        }
+        p += used;
+    }
+    return n;
+}
+
+// Times every candidate kernel for C[M, N] = A[M, K] W[N, K]^T (fp16 output, per-channel x per-token scales for SmoothQuant) on
+// operands of its own and records the winner.  Returns 0 (winner in *best_cfg / *best_us, 0 when no MFMA kernel serves the shape),
+// -1 on a HIP error.
+int gemm_profile(int wtype, int M, int N, int K, int* best_cfg, float* best_us, hipStream_t stream)
+{
+    if (best_cfg)
+        *best_cfg = 0;
+    if (best_us)
+        *best_us = 0.f;
+    const bool sq = wtype == W_INT8_SQ;
+    if ((!sq && wtype != W_FP16) || M < 32 || N <= 0 || K <= 0)
+        return 0;
+    const int es = sq ? 1 : 2;
+    const size_t a_bytes = (size_t) M * K * es, w_bytes = (size_t) N * K * es, c_bytes = (size_t) M * N * 2;
+    char *a = nullptr, *w = nullptr, *c = nullptr;
+    float *sc = nullptr, *sr = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = -1;
+    auto cleanup = [&]() {
+        if (e0)
+            (void) hipEventDestroy(e0);
+        if (e1)
+            (void) hipEventDestroy(e1);
+        for (void* p : {(void*) a, (void*) w, (void*) c, (void*) sc, (void*) sr})
+            if (p)
+                (void) hipFree(p);
+    };
+    do
+    {
+        if (hipMalloc(reinterpret_cast<void**>(&a), a_bytes + 16) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&w), w_bytes + 16) != hipSuccess
+            || hipMalloc(reinterpret_cast<void**>(&c), c_bytes + 16) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&sc), (size_t) N * 4) != hipSuccess
+            || hipMalloc(reinterpret_cast<void**>(&sr), (size_t) M * 4) != hipSuccess)
+        {
+            set_error("gemm profile: hipMalloc failed (%d x %d x %d)", M, N, K);
+            break;
+        }
+        hipLaunchKernelGGL(fill_random_kernel, dim3(1024), dim3(256), 0, stream, reinterpret_cast<uint32_t*>(a), a_bytes / 4, 17u, sq ? 0 : 1);
+        hipLaunchKernelGGL(fill_random_kernel, dim3(1024), dim3(256), 0, stream, reinterpret_cast<uint32_t*>(w), w_bytes / 4, 29u, sq ? 0 : 1);
+        std::vector<float> ones((size_t) std::max(M, N), 1e-3f);
+        if (hipMemcpyAsync(sc, ones.data(), (size_t) N * 4, hipMemcpyHostToDevice, stream) != hipSuccess
+            || hipMemcpyAsync(sr, ones.data(), (size_t) M * 4, hipMemcpyHostToDevice, stream) != hipSuccess
+            || hipStreamSynchronize(stream) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+        {
+            set_error("gemm profile: set-up failed");
+            break;
+        }
+        GemmParams p;
+        p.wtype = wtype;
+        p.out_dtype = DT_HALF;
+        p.M = M;
+        p.N = N;
+        p.K = K;
+        p.a = a;
+        p.lda = K;
+        p.w = w;
+        p.ldw = (int64_t) K * es;
+        p.scale_col = sq ? (const void*) sc : nullptr;
+        p.scale_row = sq ? sr : nullptr;
+        p.per_channel = sq ? 1 : 0;
+        p.per_token = sq ? 1 : 0;
+        p.c = c;
+        p.ldc = N;
+        const int* cand = sq ? kSqCandidates : kFp16Candidates;
+        const int ncand = sq ? (int) (sizeof(kSqCandidates) / sizeof(int)) : (int) (sizeof(kFp16Candidates) / sizeof(int));
+        int win = 0;
+        float win_us = 0.f;
+        bool hip_bad = false;
+        for (int ci = 0; ci < ncand && !hip_bad; ++ci)
+        {
+            const int cfg = cand[ci];
+            int r = launch_gemm_cfg(p, cfg, stream); // warm-up (first use of a kernel sets its LDS attribute, loads its code)
+            if (r > 0)
+                continue; // this kernel does not serve the shape
+            if (r < 0 || launch_gemm_cfg(p, cfg, stream) < 0)
+            {
+                hip_bad = true;
+                break;
+            }
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep)
+            {
+                constexpr int kLaunches = 4;
+                (void) hipEventRecord(e0, stream);
+                for (int i = 0; i < kLaunches; ++i)
+                    (void) launch_gemm_cfg(p, cfg, stream);
+                (void) hipEventRecord(e1, stream);
+                float ms = 0.f;
+                if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess)
+                {
+                    hip_bad = true;
+                    break;
+                }
+                best = std::min(best, ms * 1000.f / kLaunches);
+            }
+            if (hip_bad)
+                break;
+            if (!win || best < win_us * 0.98f)
+            {
+                win = cfg;
+                win_us = best;
+            }
+        }
+        if (hip_bad)
+        {
+            set_error("gemm profile: a HIP call failed while timing the candidates (%d x %d x %d)", M, N, K);
+            break;
+        }
+        if (win)
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            g_table[Key(wtype, M, N, K)] = Entry{win, win_us};
+        }
+        if (best_cfg)
+            *best_cfg = win;
+        if (best_us)
+            *best_us = win_us;
+        rc = 0;
+    } while (false);
+    cleanup();
+    return rc;
+}
+
+} // namespace kernels
+} // namespace tllm

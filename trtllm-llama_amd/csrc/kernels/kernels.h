@@ -3,6 +3,7 @@
 // cannot run.  SURVEY.md §8a row ids (A2, A5, ...) are cited per kernel.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <string>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -262,6 +263,14 @@ int launch_gemm(const GemmParams& p, hipStream_t stream);
 // (gemm_sqp.hip); returns 1 when the problem is not served (caller runs the two GEMMs + launch_swiglu_quant instead)
 int launch_gemm_swiglu(const GemmParams& p, hipStream_t stream);
 size_t gemm_woq_scratch_bytes(int32_t N, int32_t K);
+// On-device tactic selection for the prefill GEMMs (gemm_tactics.hip; reference: int8_gemm_template.h:372-457 profileGemm +
+// smoothQuantGemmPlugin.cpp:253-282 mMNKProfileMap).  lookup: kernel id for the shape, 0 = nothing profiled (static rule).
+int gemm_tactic_lookup(int wtype, int M, int N, int K);
+bool gemm_tactic_known(int wtype, int M, int N, int K);
+int gemm_profile(int wtype, int M, int N, int K, int* best_cfg, float* best_us, hipStream_t stream);
+void gemm_tactics_clear();
+int gemm_tactics_import(const char* text); // entries taken, -1 on a parse error
+std::string gemm_tactics_export();       // "wtype:M:N:K:cfg:us;..."
 
 // One-shot peer-to-peer sum all-reduce of an fp16 vector, in place (kernels/p2p_allreduce.hip; plugins/p2p.cpp owns the
 // inboxes).  peer[r]: base of rank r's region as mapped in THIS process: [2 gens][world][slot_bytes] data, then flags.

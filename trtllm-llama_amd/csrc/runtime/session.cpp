@@ -167,8 +167,11 @@ struct tllm_session
     bool debug_taps = false; // tests: keep every layer's GEMV inputs of the last generation step (tllm_session_get_tap[_ex])
     // tap w of layer li: the activation exactly as GEMV w consumes it, behind its prologue (RMSNorm / split merge / quantiser):
     //   0 QKV input [B, D]   1 O-projection input [B, Dr]   2 gate|up input [B, D]   3 down-projection input [B, Ir]
-    // fp16, or s8 where the path quantises (SmoothQuant) - the four quantisers of the SmoothQuant layer
-    char* tap_buf[4] = {nullptr, nullptr, nullptr, nullptr}; // each [num_layers][B][width] x 2 bytes
+    // fp16, or s8 where the path quantises (SmoothQuant) - the four quantisers of the SmoothQuant layer;
+    //   4 the layer's input row of the residual stream [B, D], always fp16 (tap 4 of layer num_layers - 1 + 1 does not exist:
+    //     the last layer's output is what the head consumes)
+    static constexpr int kTaps = 5;
+    char* tap_buf[kTaps] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // each [num_layers][B][width] x 2 bytes
     char* tap_dst = nullptr; // where the launch being issued leaves its prologue's result (gemv() routes x_pro_out there)
     int tap_width(int which) const { return which == 1 ? Dr : (which == 3 ? Ir : hidden); }
     char* tap_ptr(int which, int li) const { return tap_buf[which] + (size_t) li * B * tap_width(which) * 2; }
@@ -468,6 +471,33 @@ struct tllm_session
         g.c = c;
         g.ldc = L.N;
         return launch_gemm(g, st) ? 1 : 0;
+    }
+
+    // On-device tactic selection (kernels/gemm_tactics.hip; reference: int8_gemm_template.h:372-457, stored per M bucket in the
+    // plugin, smoothQuantGemmPlugin.cpp:253-282): the MFMA kernel of each prefill GEMM shape of this model at M rows is the one
+    // that measured fastest on THIS device - timed once per process and shape unless the engine file brought the choice along.
+    // TLLM_GEMM_TACTICS=off keeps the static rule.
+    int profile_prefill_gemms(int M)
+    {
+        static const bool off = [] {
+            const char* e = getenv("TLLM_GEMM_TACTICS");
+            return e && (!strcmp(e, "off") || !strcmp(e, "0"));
+        }();
+        if (off || layers.empty() || packed) // packed inputs: M varies with the prompt batch, the nearest bucket entry serves
+            return 0;
+        const Layer& L = layers[0];
+        for (const Linear* l : {&L.qkv, &L.dense, &L.fc, &L.proj})
+        {
+            // weight-only prefill GEMMs run the fp16 kernel on the expanded weights
+            const int wt = l->wtype == W_INT8_SQ ? W_INT8_SQ : W_FP16;
+            if (gemm_tactic_known(wt, M, l->N, l->K))
+                continue;
+            int cfg = 0;
+            float us = 0.f;
+            if (gemm_profile(wt, M, l->N, l->K, &cfg, &us, nullptr))
+                return 1;
+        }
+        return 0;
     }
 
     int allreduce(void* buf, int64_t n, hipStream_t st)
@@ -804,6 +834,8 @@ struct tllm_session
             const int pro_q = !sq ? PRO_NONE : (per_token ? PRO_QDYN : PRO_QSTATIC);
             // K1
             const bool taps = debug_taps && ok < 0;
+            if (taps)
+                HIP_OK(hipMemcpyAsync(tap_ptr(4, li), x, (size_t) B * D * 2, hipMemcpyDeviceToDevice, st));
             if (ok < 0 || ok == 1)
             {
                 int rc1;
@@ -985,6 +1017,12 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->neox = geti("neox_rotary_style", 1);
     s->force_comm = geti("force_comm", 0) != 0;
     s->debug_taps = geti("debug_taps", 0) != 0;
+    if (kv.count("gemm_tactics") && !kv["gemm_tactics"].empty())
+    {
+        // the prefill GEMM kernels the builder's on-device profile chose (engine header; Builder.build_engine)
+        if (gemm_tactics_import(kv["gemm_tactics"].c_str()) < 0)
+            return nullptr;
+    }
     s->packed = geti("remove_input_padding", 0) != 0;
     s->paged_kv = geti("paged_kv_cache", 0) != 0;
     s->tokens_per_block = geti("tokens_per_block", 64);
@@ -1362,10 +1400,12 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
                 mx = std::max(mx, gemm_woq_scratch_bytes(l->N, l->K));
         RUN(s->dalloc(&s->woq_scratch, mx));
     }
+    if ((size_t) Bc * S >= 32)
+        RUN(s->profile_prefill_gemms(Bc * S));
     RUN(s->dalloc(&s->ar_partial, (size_t) B * D * 2));
     RUN(s->dalloc(&s->ar_norm, (size_t) B * D * 2));
     RUN(s->dalloc(&s->ar_scale, (size_t) B * 4));
-    for (int w = 0; w < 4; ++w)
+    for (int w = 0; w < tllm_session::kTaps; ++w)
     {
         s->tap_buf[w] = nullptr;
         if (s->debug_taps)
@@ -1844,7 +1884,7 @@ int32_t tllm_session_force_tokens(tllm_session_t s, const int32_t* ids, tllm_str
 
 int32_t tllm_session_get_tap_ex(tllm_session_t s, int32_t layer, int32_t which, void* host, size_t nbytes, tllm_stream_t stream)
 {
-    if (!s || !s->B || !host || layer < 0 || layer >= s->num_layers || which < 0 || which > 3)
+    if (!s || !s->B || !host || layer < 0 || layer >= s->num_layers || which < 0 || which >= tllm_session::kTaps)
     {
         set_error("tllm_session_get_tap: bad arguments / setup not called");
         return 1;
@@ -1854,7 +1894,7 @@ int32_t tllm_session_get_tap_ex(tllm_session_t s, int32_t layer, int32_t which, 
         set_error("tllm_session_get_tap: the session was not created with debug_taps=1");
         return 1;
     }
-    const size_t row = (size_t) s->B * s->tap_width(which) * (s->sq ? 1 : 2);
+    const size_t row = (size_t) s->B * s->tap_width(which) * ((s->sq && which != 4) ? 1 : 2);
     if (nbytes != row)
     {
         set_error("tllm_session_get_tap: buffer of %zu bytes, the tap holds %zu", nbytes, row);
@@ -2025,6 +2065,46 @@ int32_t tllm_gemm(const tllm_gemm_params_t* q, tllm_stream_t stream)
     g.c = q->c;
     g.ldc = q->ldc;
     return launch_gemm(g, reinterpret_cast<hipStream_t>(stream)) ? 1 : 0;
+}
+
+int32_t tllm_gemm_profile(int32_t wtype, int32_t M, int32_t N, int32_t K, int32_t* best_cfg, float* best_us, tllm_stream_t stream)
+{
+    int cfg = 0;
+    float us = 0.f;
+    if (gemm_profile(wtype, M, N, K, &cfg, &us, reinterpret_cast<hipStream_t>(stream)))
+        return 1;
+    if (best_cfg)
+        *best_cfg = cfg;
+    if (best_us)
+        *best_us = us;
+    return 0;
+}
+
+int64_t tllm_gemm_tactics_export(char* buf, int64_t capacity)
+{
+    const std::string t = gemm_tactics_export();
+    if (buf && capacity > 0)
+    {
+        const size_t n = std::min((size_t) capacity - 1, t.size());
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t) t.size() + 1;
+}
+
+int32_t tllm_gemm_tactics_import(const char* text)
+{
+    return gemm_tactics_import(text) < 0 ? 1 : 0;
+}
+
+void tllm_gemm_tactics_clear(void)
+{
+    gemm_tactics_clear();
+}
+
+int32_t tllm_gemm_tactic_lookup(int32_t wtype, int32_t M, int32_t N, int32_t K)
+{
+    return gemm_tactic_lookup(wtype, M, N, K);
 }
 
 void tllm_gemv_set_blocks_per_cu(int32_t n)

@@ -95,6 +95,9 @@ class Builder():
             'tokens_per_block': int(getattr(network.plugin_config, 'tokens_per_block', 64)),
             'network_ops': ','.join(ops[:0]),  # the node list itself goes below as one JSON line
         }
+        tactics = self._profile_gemm_tactics(cfg, inter_size)
+        if tactics:
+            header['gemm_tactics'] = tactics
         text = '\n'.join(f'{k}={v}' for k, v in header.items())
         # which Parameter (module path) every constant tensor of the graph is: lets the runtime check that each plugin port
         # is fed by the weight its schedule reads there
@@ -130,8 +133,49 @@ class Builder():
         return bytes(blob)
 
     @staticmethod
+    def _profile_gemm_tactics(cfg: dict, inter_size: int) -> str:
+        """The reference's SmoothQuant GEMM plugin profiles its tile configurations on the device for every M bucket while the
+        engine is built and keeps the winners in the engine (int8_gemm_template.h:372-457, smoothQuantGemmPlugin.cpp:253-282).
+        Same here when a GPU is visible at build time: the four GEMM shapes of a layer at every power-of-two M up to
+        max_batch_size * max_input_len (and at that M itself) are timed by `tllm_gemm_profile`; the table travels in the engine
+        header (`gemm_tactics=`).  Without a GPU (or with TLLM_GEMM_TACTICS=off) the session profiles at set-up instead."""
+        if os.environ.get('TLLM_GEMM_TACTICS', '').lower() in ('off', '0'):
+            return ''
+        try:
+            import ctypes
+
+            import torch
+            if not torch.cuda.is_available():
+                return ''
+            from .plugin import capi
+            lib = capi.load_library()
+        except Exception:
+            return ''
+        lib.tllm_gemm_profile.argtypes = [ctypes.c_int32] * 4 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.tllm_gemm_tactics_export.argtypes = [ctypes.c_char_p, ctypes.c_int64]
+        lib.tllm_gemm_tactics_export.restype = ctypes.c_int64
+        tp = int(cfg.get('tensor_parallel', 1))
+        D, inter = int(cfg['hidden_size']), int(inter_size)
+        m_max = int(cfg.get('max_batch_size', 1)) * int(cfg.get('max_input_len', 0))
+        if m_max < 32:
+            return ''
+        wtype = 3 if int(cfg.get('quant_mode', 0)) & 4 else 0  # SmoothQuant int8, else fp16 (also the weight-only prefill)
+        shapes = {(3 * D // tp, D), (D, D // tp), (inter // tp, D), (D, inter // tp)}
+        ms = sorted({m_max} | {1 << i for i in range(5, 14) if (1 << i) < m_max})
+        for m in ms:
+            for n, k in shapes:
+                if lib.tllm_gemm_profile(wtype, m, n, k, None, None, None):
+                    logger.warning(f'gemm tactic profile failed for {m} x {n} x {k}: {capi.last_error()}')
+                    return ''
+        need = lib.tllm_gemm_tactics_export(None, 0)
+        buf = ctypes.create_string_buffer(int(need))
+        lib.tllm_gemm_tactics_export(buf, need)
+        return buf.value.decode()
+
+    @staticmethod
     def save_timing_cache(builder_config: BuilderConfig, out_path: str) -> bool:
-        """TensorRT's tactic timing cache has no equivalent: kernels are fixed; kept for build.py compatibility."""
+        """TensorRT's timing cache has one counterpart here, the prefill GEMM tactic table (`_profile_gemm_tactics`), and that
+        travels inside the engine; nothing to save separately.  Kept for build.py compatibility."""
         return True
 
     @staticmethod

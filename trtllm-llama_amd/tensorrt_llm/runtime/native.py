@@ -224,12 +224,12 @@ class NativeSession:
         _check(_lib().tllm_session_get_tap(self._h, layer, out.ctypes.data, out.nbytes, stream), 'get_tap')
         return out
 
-    TAPS = {'qkv_in': 0, 'o_in': 1, 'mlp_in': 2, 'proj_in': 3}
+    TAPS = {'qkv_in': 0, 'o_in': 1, 'mlp_in': 2, 'proj_in': 3, 'x_in': 4}
 
     def tap(self, layer: int, which: str, width: int, quantised: bool, stream: int = 0) -> np.ndarray:
         """Input of one of the layer's four GEMMs in the last generation step, behind its prologue (debug_taps=1):
         [batch * beam, width] fp16, int8 for SmoothQuant (the output of that GEMM's activation quantiser)."""
-        out = np.empty((self.batch * self.beam, width), np.int8 if quantised else np.float16)
+        out = np.empty((self.batch * self.beam, width), np.int8 if (quantised and which != 'x_in') else np.float16)
         _check(_lib().tllm_session_get_tap_ex(self._h, layer, self.TAPS[which], out.ctypes.data, out.nbytes, stream), 'get_tap_ex')
         return out
 
