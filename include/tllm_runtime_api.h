@@ -66,7 +66,8 @@ int32_t tllm_engine_verify(const void* engine, size_t nbytes);
 int32_t tllm_session_setup(tllm_session_t s, int32_t batch_size, int32_t max_input_len, int32_t max_new_tokens);
 
 /* The same with beam search (SamplingConfig.num_beams > 1, generation.py:365-411, 823-866): batch_size prompts, beam_width
- * hypotheses each (1 <= beam_width <= 8, batch_size * beam_width <= 8 for the generation kernels).  The KV cache holds
+ * hypotheses each (1 <= beam_width <= 8; batch_size * beam_width is not limited: the generation GEMVs take 8 rows per launch and
+ * run more sequences in slabs of 8, each slab streaming the weights again).  The KV cache holds
  * batch_size * beam_width sequences; the prompt's K/V is stored once per batch entry (in hypothesis 0's rows) and reached by
  * the others through the cache indirection [batch_size * beam_width, max_seq_len] (value = sibling hypothesis whose rows
  * hold that time step), which the device-side beam step re-parents every step - the reference's src/tgt

@@ -445,7 +445,40 @@ struct tllm_session
             p.scale_col_up = up->scale_col;
             p.scale_row_up = up->act_scale;
         }
-        return timed(gemv_cls, st, [&] { return launch_gemv(p, st) ? 1 : 0; });
+        if (M <= 8)
+            return timed(gemv_cls, st, [&] { return launch_gemv(p, st) ? 1 : 0; });
+        // more than 8 sequences (batch x beam width): the skinny kernel takes 8 rows per launch, so the rows go through it in
+        // slabs of 8 - every operand that is indexed by the row moves along.  Each slab streams the weights again: beyond 8
+        // sequences a step costs ceil(B / 8) weight passes (the throughput per sequence of B = 8), but nothing is refused -
+        // build.py's default --max_batch_size 8 with any beam width > 1 asks for exactly this (Q/build.py:73-76).
+        const int xes = (L.wtype == W_INT8_SQ && pro == PRO_NONE) ? 1 : 2; // raw s8 activations, else fp16
+        const int yes = out_dtype == DT_INT8 ? 1 : (out_dtype == DT_HALF ? 2 : 4);
+        const int tap_es = L.wtype == W_INT8_SQ ? 1 : 2;
+        return timed(gemv_cls, st, [&] {
+            for (int m0 = 0; m0 < M; m0 += 8)
+            {
+                GemvParams q = p;
+                q.M = M - m0 < 8 ? M - m0 : 8;
+                if (pro < PRO_ATTN)
+                    q.x = static_cast<const char*>(xin) + (int64_t) m0 * ldx * xes;
+                else
+                {
+                    q.attn_ml = static_cast<const char*>(p.attn_ml) + (int64_t) m0 * Hr * attn_ns * 8 /* (m, l) float pairs */;
+                    q.attn_o = p.attn_o + (int64_t) m0 * Hr * attn_ns * Dh;
+                    q.attn_seq_len = seq_len + m0;
+                }
+                q.y = static_cast<char*>(y) + (int64_t) m0 * ldy * yes;
+                if (residual)
+                    q.residual = static_cast<const char*>(residual) + (int64_t) m0 * ldy * 2;
+                if (p.per_token && p.scale_row)
+                    q.scale_row = p.scale_row + m0;
+                if (p.x_pro_out)
+                    q.x_pro_out = static_cast<char*>(p.x_pro_out) + (int64_t) m0 * L.K * tap_es;
+                if (launch_gemv(q, st))
+                    return 1;
+            }
+            return 0;
+        });
     }
 
     // context: plain GEMM on M rows (activation already in the operand type)
@@ -798,11 +831,6 @@ struct tllm_session
     int run_decode_step(hipStream_t st)
     {
         const int D = hidden;
-        if (B > 8)
-        {
-            set_error("session: generation step supports batch <= 8 (got %d)", B);
-            return 1;
-        }
         const int ok = only_kernel;
         if (ok < 0 && (beam > 1 || D % 8 != 0)) // greedy: the sampler gathered the row already
             RUN(timed(PC_OTHER, st, [&] { return launch_embedding(x, cur_ids, emb, B, D, vocab, st); }));

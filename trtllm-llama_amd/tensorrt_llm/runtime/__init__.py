@@ -1,4 +1,3 @@
 from .generation import GenerationSession, ModelConfig, SamplingConfig
-from .session import Session
 
-__all__ = ['GenerationSession', 'ModelConfig', 'SamplingConfig', 'Session']
+__all__ = ['GenerationSession', 'ModelConfig', 'SamplingConfig']

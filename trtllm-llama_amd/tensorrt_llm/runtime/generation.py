@@ -82,8 +82,10 @@ class GenerationSession(object):
         return self._model_config.hidden_size
 
     def setup(self, batch_size: int, max_input_length: int, max_new_tokens: int, beam_width: int = 1):
-        if not 1 <= beam_width <= 8 or batch_size * beam_width > 8:
-            raise ValueError(f'beam_width {beam_width} x batch {batch_size}: the generation kernels take at most 8 sequences')
+        if not 1 <= beam_width <= 8:
+            raise ValueError(f'beam_width {beam_width}: the device-side beam step takes 1 to 8 hypotheses per prompt')
+        # batch_size * beam_width sequences: any number; the generation GEMVs take 8 rows per launch, more go through in slabs of 8
+        # (each slab streams the weights again - build.py's default --max_batch_size 8 with beam search relies on this)
         self.batch_size, self.max_input_length, self.max_new_tokens = batch_size, max_input_length, max_new_tokens
         self.beam_width = beam_width
         self.runtime.setup(batch_size, max_input_length, max_new_tokens, beam_width)

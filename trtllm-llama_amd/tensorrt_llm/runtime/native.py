@@ -120,7 +120,7 @@ class NativeSession:
         _check(_lib().tllm_session_finalize(self._h), 'finalize')
 
     def setup(self, batch: int, max_input_len: int, max_new_tokens: int, beam_width: int = 1):
-        """batch prompts x beam_width hypotheses (beam search when > 1; batch * beam_width <= 8 in the generation phase)."""
+        """batch prompts x beam_width hypotheses (beam search when > 1, beam_width <= 8; beyond 8 sequences the generation GEMVs run in slabs of 8 rows)."""
         _check(_lib().tllm_session_setup_beam(self._h, batch, beam_width, max_input_len, max_new_tokens), 'setup')
         self.batch, self.max_in, self.max_new, self.beam = batch, max_input_len, max_new_tokens, beam_width
 
