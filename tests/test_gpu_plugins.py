@@ -8,6 +8,8 @@ Shapes/seeds follow the reference tests where they exist:
   T/tests/quantization/test_functional.py:48-50,146-155          (quantisers, exact)
   T/tests/attention/test_gpt_attention.py:30-73                   (llama attention: H=4, Dh in {32,64,128})
 """
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -248,6 +250,38 @@ def test_weight_only_quant_matmul(bits, m, n, k):
         assert np.all(np.abs(as_f32(out) - deq) <= atol[None, :] + 1e-7 * np.abs(deq) + 2e-3 * np.abs(deq).max())
     else:
         np.testing.assert_allclose(as_f32(out), deq, atol=max(deq.max(), 0) * rs * 1.5)
+
+
+@pytest.mark.parametrize('bits', [8, 4])
+@pytest.mark.parametrize('m,n,k', [(1024, 384, 4096), (300, 456, 1152), (33, 200, 64), (257, 4096, 704)])
+def test_woq_prefill_gemm_dequantises_in_the_main_loop(bits, m, n, k, lib):
+    """Weight-only prefill GEMM without the fp16 image of the weights (gemm_woq.hip; reference: the mixed-input CUTLASS GEMM,
+    K/cutlass_kernels/fpA_intB_gemm/fpA_intB_gemm_template.h:60-160): every tile shape against the oracle (exact integer weights,
+    fp32 accumulate, one fp16 scale, one rounding - only the fp32 summation order is the kernel's own), ragged M / N, a K of one
+    and of eleven stages; and the tile shapes against each other BIT FOR BIT (the k order of a sum does not depend on the tile)."""
+    lib.tllm_gemm_set_tile_cfg.argtypes = [ctypes.c_int32]
+    lib.tllm_gemm_set_tile_cfg.restype = None
+    r = np.random.default_rng(7 + bits)
+    w = r.uniform(-1, 1, (k, n)).astype(np.float16)
+    x = r.standard_normal((m, k)).astype(np.float16)
+    processed, scales, _ = capi.symmetric_quantize_last_axis(w, bits)
+    q_ref, s_ref = O.woq_quantize(w.astype(np.float32), bits)
+    ref = O.woq_matmul(x.astype(np.float32), q_ref, s_ref)
+    p = make_plugin('WeightOnlyQuantMatmul', [('type_id', i32([capi.HALF])), ('weight_type_id', i32(1 if bits == 8 else 2))])
+    wt = torch.from_numpy(processed).cuda().view(torch.float32).reshape(k, -1)
+    outs = []
+    try:
+        for cfg in (101, 102, 103, 104):
+            lib.tllm_gemm_set_tile_cfg(cfg)
+            out = torch.full((m, n), 7.0, dtype=torch.float16, device='cuda')
+            run_plugin(p, [torch.from_numpy(x).cuda(), wt, torch.from_numpy(scales).cuda()], [out])
+            got = as_f32(out)
+            np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max(), err_msg=f'cfg {cfg}')
+            outs.append(got)
+    finally:
+        lib.tllm_gemm_set_tile_cfg(0)
+    for g in outs[1:]:
+        np.testing.assert_array_equal(g, outs[0])
 
 
 @pytest.mark.parametrize('bits', [8, 4])

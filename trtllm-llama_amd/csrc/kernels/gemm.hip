@@ -3,6 +3,7 @@
 //   M  > 8  -> MFMA tiles: LDS-DMA staged (gemm_glds.hip: SQ / fp16, K-bytes % 128 == 0), else register staged with
 //              in-flight dequantisation (gemm_mfma.hip: weight-only types, odd K), else 8-row GEMV slabs.
 #include "dev_utils.h"
+#include <cstdlib>
 #include "kernels.h"
 #include "weight_layout.h"
 
@@ -12,6 +13,7 @@ namespace kernels
 {
 
 int launch_gemm_mfma(const GemmParams& p, hipStream_t stream); // gemm_mfma.hip; returns 1 when the shape is unsupported
+int launch_gemm_woq(const GemmParams& p, hipStream_t stream);  // gemm_woq.hip (weight-only, dequantisation in the main loop); same
 int launch_gemm_glds(const GemmParams& p, hipStream_t stream); // gemm_glds.hip (SQ / fp16, LDS-DMA staged); same convention
 
 namespace
@@ -108,6 +110,15 @@ int launch_gemm(const GemmParams& pin, hipStream_t stream)
     if (pin.M > 8)
     {
         const bool woq = pin.wtype == W_INT8_WOQ || pin.wtype == W_INT4_WOQ;
+        static const bool expand_only = getenv("TLLM_WOQ_EXPAND") != nullptr; // A/B switch: the r02 path (fp16 image in a scratch buffer)
+        if (woq && !expand_only)
+        {
+            // weight-only at prefill sizes: the u8 / nibble tile by LDS-DMA, dequantised between LDS and the MFMA fragments -
+            // no fp16 image of the weights, a third of the expanded path's HBM traffic
+            const int r = launch_gemm_woq(pin, stream);
+            if (r <= 0)
+                return r;
+        }
         if (woq && pin.scratch && pin.M >= 32 && pin.K % (pin.wtype == W_INT8_WOQ ? 16 : 32) == 0 && pin.K % 64 == 0
             && !(reinterpret_cast<uintptr_t>(pin.w) & 15) && !(pin.ldw & 15))
         {

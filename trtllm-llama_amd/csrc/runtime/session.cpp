@@ -41,6 +41,7 @@ namespace kernels
 {
 extern int gemv_tune_blocks_per_cu;
 extern int gemm_tune_cfg;
+extern int gemm_woq_tune_cfg;
 extern void* gemm_clock_probe;
 }
 } // namespace tllm
@@ -2180,6 +2181,12 @@ void tllm_gemm_set_clock_probe(void* device_buffer)
 
 void tllm_gemm_set_tile_cfg(int32_t cfg)
 {
+    // 0 resets both tables; 101.. select the tile shape of the weight-only main-loop-dequantising GEMM (gemm_woq.hip: 101 = 256 x 192,
+    // 102 = 128 x 128, 103 = 256 x 192 two stages ahead, 104 = 256 x 192 on 4 waves)
+    if (cfg == 0 || cfg > 100)
+        tllm::kernels::gemm_woq_tune_cfg = cfg > 100 ? cfg - 100 : 0;
+    if (cfg > 100)
+        return;
     tllm::kernels::gemm_tune_cfg = cfg;
 }
 
