@@ -35,7 +35,8 @@ def test_rouge_known_values():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('flags,min_match', [([], 0.9), (['--use_smooth_quant', '--per_channel', '--int8_kv_cache'], 0.3)])
+# observed (r03, deterministic kernels): fp16 1.000 / ROUGE-L 100, SmoothQuant + int8 KV 0.792 / 90.6 on this tiny two-layer model
+@pytest.mark.parametrize('flags,min_match', [([], 0.95), (['--use_smooth_quant', '--per_channel', '--int8_kv_cache'], 0.65)])
 def test_summarize_engine_vs_hf(tmp_path, flags, min_match):
     """hf_llama_convert -> build -> summarize.py --test_hf --test_trt_llm on seeded token prompts (ragged batch of 2):
     the fp16 engine reproduces HF's greedy continuation almost token for token; the SmoothQuant engine stays close."""
@@ -54,5 +55,6 @@ def test_summarize_engine_vs_hf(tmp_path, flags, min_match):
                     '--batch_size', '2', '--max_ite', '4', '--log_level', 'error', '--output_json', str(out)],
                    check=True, cwd=EX, timeout=900)
     r = json.load(open(out))
+    print(f"[summarize {' '.join(flags) or 'fp16'}] token_match_rate {r['token_match_rate']:.3f}, rougeL vs HF {r['tensorrt_llm_vs_hf']['rougeL']:.1f}")
     assert r['token_match_rate'] >= min_match, r
     assert r['tensorrt_llm_vs_hf']['rougeL'] >= 100 * min_match, r
