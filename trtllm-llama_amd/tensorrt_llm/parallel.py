@@ -89,8 +89,42 @@ def enable_p2p_allreduce(mapping, max_bytes: int = 64 * 1024, iters: int = 8, ve
                 ok, why = False, f'mismatch vs RCCL at iteration {it}: max |diff| {(got.float() - ref.float()).abs().max().item():.4g}'
         if ok and lib.tllm_comm_p2p_error() != 0:
             ok, why = False, 'a flag wait timed out'
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        # the fused layer seam (all-reduce + residual add + next RMSNorm + SmoothQuant quantiser in one launch,
+        # kernels/p2p_allreduce.hip) is validated the same way before the decode step may use it: x <- x + sum of the partials
+        # against RCCL's sum, the normalised row against torch.  A mismatch leaves the all-reduce peer-to-peer but keeps the
+        # three-stage seam (TLLM_NO_FUSED_ALLREDUCE, read by the session at its first generation step).
+        fused_ok, fused_why = ok, ''
+        if ok:
+            lib.tllm_comm_p2p_all_reduce_residual_norm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
+                                                                   ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+            gshared = torch.Generator(device='cpu').manual_seed(99)  # residual stream and gamma: identical on every rank
+            for rows, cols in ((1, 4096), (2, 1024)):
+                part = (torch.randn(rows, cols, generator=g) * 0.5).to(torch.float16).to(dev)
+                x0 = (torch.randn(rows, cols, generator=gshared) * 2).to(torch.float16).to(dev)
+                gamma = (1 + 0.1 * torch.randn(cols, generator=gshared)).to(torch.float16).to(dev)
+                total = part.clone()
+                dist.all_reduce(total)
+                x = x0.clone()
+                out = torch.empty_like(x)
+                if lib.tllm_comm_p2p_all_reduce_residual_norm(part.data_ptr(), x.data_ptr(), gamma.data_ptr(), 1e-6, rows, cols,
+                                                              out.data_ptr(), 0, None, None, stream):
+                    fused_ok, fused_why = False, capi.last_error()
+                torch.cuda.synchronize()
+                want_x = (x0.float() + total.float())
+                xf = x.float()
+                want_n = (xf * torch.rsqrt((xf * xf).mean(-1, keepdim=True) + 1e-6)).half().float() * gamma.float()
+                if fused_ok and not (torch.allclose(xf, want_x, rtol=4e-3, atol=4e-3 * world)
+                                     and torch.allclose(out.float(), want_n, rtol=4e-3, atol=4e-3)):
+                    fused_ok, fused_why = False, 'the fused residual + RMSNorm tail does not reproduce torch / RCCL'
+            if lib.tllm_comm_p2p_error() != 0:
+                ok, why = False, 'a flag wait timed out'
+        flag = torch.tensor([1 if ok else 0, 1 if fused_ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0].item()) == 1 and int(flag[1].item()) == 0:
+            os.environ['TLLM_NO_FUSED_ALLREDUCE'] = '1'
+            why = f'fused seam off: {fused_why}' if fused_why else 'fused seam off (a peer\'s validation failed)'
+        flag = flag[:1]
     use = int(flag.item()) == 1
     lib.tllm_comm_p2p_enable(1 if use else 0)
     if verbose and mapping.rank == mapping.tp_group[0]:
