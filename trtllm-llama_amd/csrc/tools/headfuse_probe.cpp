@@ -246,6 +246,93 @@ __global__ __launch_bounds__(512) void fused_kernel(FusedArgs a)
         a.part[(size_t) blockIdx.x * 130 + threadIdx.x] = m;
 }
 
+// ---- B4: the same on 4 waves per workgroup (the real GEMV's block size): 12 rows per wave as 6 double-buffered tiles; the KV range
+// split as today (192-token chunks: 6 of the 8 workgroups of a head hold one at a 1073-slot cache), 12 rows per lane group
+__global__ __launch_bounds__(256) void fused4_kernel(FusedArgs a)
+{
+    __shared__ uint32_t lds[16 + 256];
+    __shared__ float sm[16][20];
+    __shared__ uint32_t qkv_s[192];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int head = blockIdx.x & 31, member = blockIdx.x >> 5;
+    const bool has_kv = member < 6;
+    const size_t kv_per_wg = a.kvbytes / 192 / 16 * 16; // 32 heads x 6 splits
+    const char* kvb = a.kv + (size_t) (head * 6 + (has_kv ? member : 0)) * kv_per_wg;
+    constexpr int NV = 12; // 48 KB per workgroup = 192 B per thread
+    u4 kvr[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        kvr[i] = *reinterpret_cast<const u4*>(kvb + ((size_t) i * 256 + threadIdx.x) * 16 % kv_per_wg);
+    const size_t tiles_per_wg = a.wbytes / 8192 / 256;
+    const size_t t0 = (size_t) blockIdx.x * tiles_per_wg;
+    Tile s;
+    size_t t = wv;
+    if (t < tiles_per_wg)
+        s.request(a.w, t0 + t, lane);
+    const uint32_t ep = *a.epoch;
+    const uint32_t x = prologue(a.xin[threadIdx.x], lds, 4);
+    uint32_t acc = 0;
+    while (t < tiles_per_wg)
+    {
+        Tile nxt;
+        const size_t tn = t + 4;
+        if (tn < tiles_per_wg)
+            nxt.request(a.w, t0 + tn, lane);
+        acc += s.consume(x);
+        s = nxt;
+        t = tn;
+    }
+    for (int o = 32; o; o >>= 1)
+        acc += __shfl_xor(acc, o, 64);
+    gu64* gx = (gu64*) (a.xchg + (size_t) head * 192);
+    if (lane < 6)
+        __hip_atomic_store(gx + member * 24 + wv * 6 + lane, ((unsigned long long) ep << 32) | (acc & 0xffffffffu), __ATOMIC_RELAXED,
+            __HIP_MEMORY_SCOPE_AGENT);
+    if (!has_kv) // block-uniform: nothing to attend to
+        return;
+    if (wv == 0)
+    {
+        unsigned spins = 0;
+        for (;;)
+        {
+            bool ok = true;
+            uint32_t v[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+            {
+                const unsigned long long g = __hip_atomic_load(gx + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[k] = (uint32_t) g;
+                ok &= (uint32_t) (g >> 32) == ep;
+            }
+            if (__all(ok))
+            {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    qkv_s[k * 64 + lane] = v[k];
+                break;
+            }
+            if (++spins > 2000000u)
+            {
+                if (lane == 0)
+                    atomicExch(a.timeout, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    const float q = (float) qkv_s[threadIdx.x & 127];
+    const float o = attn_math(kvr, NV, 12, q);
+    const int gid = threadIdx.x >> 4;
+    sm[gid][threadIdx.x & 15] = o;
+    __syncthreads();
+    float m = 0.f;
+    for (int g = 0; g < 16; ++g)
+        m += sm[g][threadIdx.x & 15];
+    if (threadIdx.x < 130)
+        a.part[(size_t) blockIdx.x * 130 + threadIdx.x] = m;
+}
+
 __global__ void bump_kernel(uint32_t* epoch)
 {
     *epoch += 1;
@@ -285,8 +372,8 @@ int main(int argc, char** argv)
         hipLaunchKernelGGL(stream_kernel, dim3(918), dim3(256), lds, st, bufs[(size_t) l * 5 + 3], sizes[3], x0, x1);
         hipLaunchKernelGGL(stream_kernel, dim3(1024), dim3(256), lds, st, bufs[(size_t) l * 5 + 4], sizes[4], x1, x0);
     };
-    hipGraphExec_t gexec[3] = {nullptr, nullptr, nullptr};
-    for (int variant = 0; variant < 3; ++variant)
+    hipGraphExec_t gexec[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int variant = 0; variant < 4; ++variant)
     {
         hipGraph_t g;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -303,6 +390,12 @@ int main(int argc, char** argv)
                     xchg + (size_t) l * 32 * 192, epoch, part, timeout};
                 hipLaunchKernelGGL(fused_kernel, dim3(256), dim3(512), 0, st, a);
             }
+            else if (variant == 3)
+            {
+                FusedArgs a{bufs[(size_t) l * 5], sizes[0] / (8192 * 256) * (8192 * 256), bufs[(size_t) l * 5 + 1], sizes[1], x0,
+                    xchg + (size_t) l * 32 * 192, epoch, part, timeout};
+                hipLaunchKernelGGL(fused4_kernel, dim3(256), dim3(256), 0, st, a);
+            }
             else // the same two launches without anything behind the hand-off: QKV stream only (what the boundary alone costs)
                 hipLaunchKernelGGL(stream_kernel, dim3(1024), dim3(256), lds, st, bufs[(size_t) l * 5], sizes[0] / 8192 * 8192, x0, x1);
             rest(l);
@@ -315,10 +408,11 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
-    const char* names[3] = {"A: QKV launch + attention launch", "B: one launch per head group (fused)", "C: QKV launch only (no attention at all)"};
-    float best[3] = {1e30f, 1e30f, 1e30f};
+    const char* names[4] = {"A: QKV launch + attention launch", "B: one launch per head group (fused, 8 waves)", "C: QKV launch only (no attention at all)",
+        "B4: fused on 4 waves, 192-token splits"};
+    float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};
     for (int round = 0; round < 4; ++round) // interleaved rounds: one box, one clock state
-        for (int variant = 0; variant < 3; ++variant)
+        for (int variant = 0; variant < 4; ++variant)
         {
             for (int i = 0; i < 3; ++i)
                 CK(hipGraphLaunch(gexec[variant], st));
@@ -337,7 +431,7 @@ int main(int argc, char** argv)
     uint32_t to = 0;
     CK(hipMemcpy(&to, timeout, 4, hipMemcpyDeviceToHost));
     printf("\nbest of 4 rounds, per layer (5 / 4 / 4 launches):  A %.2f us   B %.2f us   C %.2f us   ->  B - A = %+.2f us,  A - C = %.2f us "
-           "(what the attention launch costs today)%s\n", best[0], best[1], best[2], best[1] - best[0], best[0] - best[2],
-        to ? "   [a granule sweep TIMED OUT]" : "");
+           "(what the attention launch costs today);  B4 %.2f us -> B4 - A = %+.2f us%s\n", best[0], best[1], best[2], best[1] - best[0], best[0] - best[2],
+        best[3], best[3] - best[0], to ? "   [a granule sweep TIMED OUT]" : "");
     return 0;
 }
