@@ -528,8 +528,10 @@ struct tllm_session
                 continue;
             int cfg = 0;
             float us = 0.f;
+            // best effort: a profile that cannot run (no memory left for its operands next to a large session) leaves the shape
+            // to the static rule - it must not fail the set-up
             if (gemm_profile(wt, M, l->N, l->K, &cfg, &us, nullptr))
-                return 1;
+                break;
         }
         return 0;
     }
