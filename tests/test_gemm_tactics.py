@@ -91,3 +91,37 @@ def test_profile_picks_a_kernel_and_the_gemm_stays_exact(wtype, m, n, k):
         ref = O.gemm_fp16(a.cpu().numpy().astype(np.float32), w.cpu().numpy().astype(np.float32))
         np.testing.assert_allclose(c.cpu().numpy().astype(np.float32), ref, rtol=2e-3, atol=2e-3)
     lib.tllm_gemm_tactics_clear()
+
+
+def test_a_session_config_carries_the_table():
+    """host only: the `gemm_tactics=` line of an engine header (Builder.build_engine writes it when a GPU is visible at build time)
+    reaches the table when the session is created; a malformed line fails the creation with the parser's message."""
+    from tensorrt_llm.runtime.native import NativeSession
+    lib = _lib()
+    lib.tllm_gemm_tactics_clear()
+    cfg = dict(num_layers=1, num_heads=2, hidden_size=64, inter_size=24, vocab_size=128, quant_mode=0)
+    s = NativeSession(dict(cfg, gemm_tactics='0:256:192:256:8:11.50;3:1024:12288:4096:20:45.10;'))
+    assert lib.tllm_gemm_tactic_lookup(0, 256, 192, 256) == 8 and lib.tllm_gemm_tactic_lookup(3, 1024, 12288, 4096) == 20
+    s.close()
+    with pytest.raises(RuntimeError, match='parse'):
+        NativeSession(dict(cfg, gemm_tactics='0:256:nonsense'))
+    lib.tllm_gemm_tactics_clear()
+
+
+@pytest.mark.gpu
+def test_builder_profiles_on_the_device_and_the_engine_brings_the_table():
+    """Builder._profile_gemm_tactics (what build_engine calls): the layer's four GEMM shapes at every power-of-two M up to
+    max_batch_size * max_input_len, on the device; the text is what a session imports from the engine header."""
+    from tensorrt_llm.builder import Builder
+    lib = _lib()
+    lib.tllm_gemm_tactics_clear()
+    text = Builder._profile_gemm_tactics(dict(hidden_size=256, tensor_parallel=1, max_batch_size=2, max_input_len=48, quant_mode=0), 512)
+    entries = [e.split(':') for e in text.split(';') if e]
+    shapes = {(int(e[2]), int(e[3])) for e in entries}
+    ms = {int(e[1]) for e in entries}
+    assert shapes == {(768, 256), (256, 256), (512, 256), (256, 512)} and ms == {32, 64, 96}, text
+    assert all(int(e[0]) == 0 and int(e[4]) > 0 and float(e[5]) > 0 for e in entries)
+    lib.tllm_gemm_tactics_clear()
+    assert lib.tllm_gemm_tactics_import(text.encode()) == 0
+    assert lib.tllm_gemm_tactic_lookup(0, 96, 768, 256) > 0 and lib.tllm_gemm_tactic_lookup(0, 80, 768, 256) > 0  # bucket (64, 128]
+    lib.tllm_gemm_tactics_clear()

@@ -201,5 +201,10 @@ def test_generation_session_num_beams():
     got = gs.decode(ids, lens, SamplingConfig(end_id=-1, pad_id=2, num_beams=W))
     np.testing.assert_array_equal(np.asarray(got), want)
     with pytest.raises(ValueError):
-        gs.setup(4, S, NEW, beam_width=4)
+        gs.setup(1, S, NEW, beam_width=9)  # the device-side beam step takes at most 8 hypotheses per prompt
+    # 4 prompts x 4 hypotheses = 16 sequences: more than the 8 rows a generation GEMV launch takes - runs in slabs of 8 since r03
+    gs.setup(4, S, NEW, beam_width=4)
+    ids4 = prompts(cfg, 4, S, np.array([8, 8, 8, 8], np.int32), 10)
+    out4 = gs.decode(ids4, np.array([8, 8, 8, 8], np.int32), SamplingConfig(end_id=-1, pad_id=2, num_beams=4))
+    assert np.asarray(out4).shape == (4, 4, S + NEW)
     s.close()
