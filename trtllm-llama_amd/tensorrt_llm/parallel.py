@@ -93,8 +93,12 @@ def enable_p2p_allreduce(mapping, max_bytes: int = 64 * 1024, iters: int = 8, ve
         # kernels/p2p_allreduce.hip) is validated the same way before the decode step may use it: x <- x + sum of the partials
         # against RCCL's sum, the normalised row against torch.  A mismatch leaves the all-reduce peer-to-peer but keeps the
         # three-stage seam (TLLM_NO_FUSED_ALLREDUCE, read by the session at its first generation step).
-        fused_ok, fused_why = ok, ''
-        if ok:
+        # (the verdict so far is made collective first: every rank must take the same path through the collectives below)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        all_ok = int(flag.item()) == 1
+        fused_ok, fused_why = all_ok, ''
+        if all_ok:
             lib.tllm_comm_p2p_all_reduce_residual_norm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
                                                                    ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -119,7 +123,7 @@ def enable_p2p_allreduce(mapping, max_bytes: int = 64 * 1024, iters: int = 8, ve
                     fused_ok, fused_why = False, 'the fused residual + RMSNorm tail does not reproduce torch / RCCL'
             if lib.tllm_comm_p2p_error() != 0:
                 ok, why = False, 'a flag wait timed out'
-        flag = torch.tensor([1 if ok else 0, 1 if fused_ok else 0], dtype=torch.int32, device=dev)
+        flag = torch.tensor([1 if (ok and all_ok) else 0, 1 if fused_ok else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0].item()) == 1 and int(flag[1].item()) == 0:
             os.environ['TLLM_NO_FUSED_ALLREDUCE'] = '1'
