@@ -300,6 +300,23 @@ def run(torch, dev, layers=32, prompt_len=128, new_tokens=128, n_prompts=8, cpu_
                        'sq_dyn': 'SmoothQuant per-channel weights, per-token dynamic activations, int8 KV (--per_token --per_channel)'}}
     # how decisive the reference's own choices are: a greedy token is only comparable where top-1 leads top-2 by more than
     # the logit error - a random-weight 32-layer model has very small margins (its logits barely depend on the prompt)
+    # the noise floor of the free-running comparison: HF itself in fp16 (what the reference's own run_hf.py / summarize.py baseline
+    # runs, Q/run_hf.py:55-57 `.half().cuda()`) against HF fp32 on the same weights - how far a mere change of precision moves a
+    # greedy continuation of this parent
+    try:
+        with torch.no_grad():
+            seq16, lg16 = run_hf.hf_generate(parent, prompts.to(dev), N, eos_token_id=None, pad_token_id=0, return_logits=True)
+        t16 = seq16[:, P:].cpu().numpy()
+        rl16 = [rouge_l_ids(t16[i], hf_tokens[i]) for i in range(n_prompts)]
+        with torch.no_grad():
+            tf16 = ref(seq16[:, :-1]).logits[:, P - 1:].float().cpu().numpy()
+        e16 = np.abs(lg16.permute(1, 0, 2).cpu().numpy() - tf16)
+        res['hf_fp16_vs_hf_fp32'] = {'what': 'HF LlamaForCausalLM in fp16 on the GPU (the reference\'s own baseline precision) against HF fp32, same weights',
+                                     'rougeL_mean': float(np.mean(rl16)), 'rougeL_per_prompt': [round(x, 2) for x in rl16],
+                                     'token_match_rate_free_running': float((t16 == hf_tokens).mean()),
+                                     'max_abs_logit_err_teacher_forced': float(e16.max()), 'mean_abs_logit_err': float(e16.mean())}
+    except Exception as e:  # side report
+        res['hf_fp16_vs_hf_fp32'] = {'error': repr(e)}
     top2 = np.sort(hf_logits, axis=-1)[..., -2:]
     margin = top2[..., 1] - top2[..., 0]
     res['hf_top1_top2_margin'] = {'min': float(margin.min()), 'median': float(np.median(margin)), 'max': float(margin.max()),
@@ -341,6 +358,10 @@ def run(torch, dev, layers=32, prompt_len=128, new_tokens=128, n_prompts=8, cpu_
         }
     for mode in MODES[1:]:
         res[mode]['rougeL_delta_vs_fp16_engine'] = res['fp16']['rougeL_vs_hf_mean'] - res[mode]['rougeL_vs_hf_mean']
+    base16 = res.get('hf_fp16_vs_hf_fp32', {}).get('rougeL_mean')
+    if base16 is not None:  # the reference's own comparison: engine vs the HF fp16 baseline, both scored against the same target
+        for mode in MODES:
+            res[mode]['rougeL_delta_vs_hf_fp16_baseline'] = base16 - res[mode]['rougeL_vs_hf_mean']
 
     # ---- attribution of the SmoothQuant engine's distance to HF: kernels or algorithm?
     t1 = time.perf_counter()
