@@ -21,8 +21,14 @@
 //     -> down projection (11 slots = 16 rows x 11 k-chunks of 1 KiB) + residual -> edge X2 (as X1) -> next layer.
 // Nothing of numerical interest is computed (integer dot products of whatever is in the buffers, a stand-in for the attention
 // arithmetic with the right instruction count and LDS traffic); every dependency, byte volume, hand-off and spin is the real one.
-//   build/engine_probe [layers=32] [replays=20] [mode=3]     mode bit 0: edges on (0 = nobody waits for anybody: the engine's
-//                                                             streaming ceiling), bit 1: attention arithmetic on
+//   build/engine_probe [layers=32] [replays=20] [mode]     mode bit 0: edges on (0 = nobody waits for anybody: the engine's
+//     streaming ceiling), bit 1: attention arithmetic on, bit 2: the loader keeps one fill in flight while its CU sweeps,
+//     bit 3: granule groups of 256 B spread 4 KiB apart (more memory channels per area).  Default: modes 0, 1, 7.
+// Measured (profiles/r03_engine_probe.txt): the stream alone runs at 33 - 34 us per layer (6.3 - 6.5 TB/s); with the six edges
+// 48.5 - 52, with the attention arithmetic 50 - 53 - against 49.3 us for today's five launches.  An all-to-all edge costs 4.5 - 7.5 us
+// here (publishes spread over ~1.3 us, then ~1.7 passes of ~1.5 us: a pass costs ~1 us per 8 KB swept, whatever its shape), the chain
+// QKV -> q -> attention -> partials -> merge -> O -> x is ~18 us long with 6 slots of weights in it, and the 8-slot ring covers 5 us:
+// the loader stands still for 12 - 13 us of every layer.  DESIGN.md s8 has the table and what was tried on top (register banks).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +48,7 @@
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(3))) void lds_void_t;
 
 constexpr int SLOT = 16384, NSLOT = 8;
 constexpr int S_QKV = 12, S_KV = 2, S_O = 4, S_GU = 22, S_DN = 11;
@@ -54,9 +61,10 @@ constexpr int N_H = 2816; // 11 granules x 256 CUs (the real edge: 2752)
 
 // LDS layout (bytes)
 constexpr int L_X = NSLOT * SLOT;      // activation vector, up to 11264 int8
-constexpr int L_Q = L_X + 11264;       // q (128 floats) + scores (128 floats)
-constexpr int L_RED = L_Q + 1024;      // cross-wave reduction scratch: 3 x 132 floats
-constexpr int L_FLAGS = L_RED + 2048;  // ready[8], freed[8], xflag, xack, cbar, dead
+constexpr int L_RAW = L_X + 11264;     // the fp16 row as it was swept (2048 words)
+constexpr int L_Q = L_RAW + 8192;      // q | k | v of the new token (3 x 64 floats), scores (128 floats)
+constexpr int L_RED = L_Q + 2048;      // cross-wave reduction scratch: 3 x 132 floats
+constexpr int L_FLAGS = L_RED + 6144;  // ready[8], freed[8], xflag, xack, cbar, dead
 constexpr int L_TOTAL = L_FLAGS + 256;
 
 enum
@@ -66,7 +74,9 @@ enum
     F_XFLAG = 16,
     F_XACK = 17,
     F_CBAR = 18,
-    F_DEAD = 19
+    F_DEAD = 19,
+    F_GATHER = 20, // the gatherer is sweeping: the loader keeps ONE fill in flight (its bursts queue ahead of the sweep's loads)
+    F_PASSES = 21
 };
 
 constexpr unsigned SPIN_LIMIT = 1u << 22;
@@ -76,47 +86,44 @@ __device__ __forceinline__ void glds16_nt(const void* gptr, uint32_t lds_byte)
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gptr), "s"(lds_byte) : "memory");
 }
 
+typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) const u4 lds_cu4;
+
+#define CFENCE() asm volatile("" ::: "memory")
+
 struct Ctx
 {
-    volatile uint32_t* fl; // LDS flags
+    lds_vu32* fl; // LDS flags
     gu32* err;
     int lane;
 };
 
-// wait until an LDS word equals `want` (bounded; once one wait of this CU gave up, none waits any more)
+__device__ __forceinline__ bool give_up(const Ctx& c, unsigned code)
+{
+    if (!c.fl[F_DEAD] && c.lane == 0)
+    {
+        c.fl[F_DEAD] = 1;
+        __hip_atomic_store(c.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return false;
+}
+
+// wait until an LDS word equals / reaches `want` (bounded; once one wait of this CU gave up, none waits any more)
+template <bool GE>
 __device__ __forceinline__ bool wait_lds(const Ctx& c, int word, uint32_t want, unsigned code)
 {
     for (unsigned spins = 0;; ++spins)
     {
-        if (c.fl[word] == want)
-            return true;
-        if (c.fl[F_DEAD] || spins > SPIN_LIMIT)
+        const uint32_t v = c.fl[word];
+        if (GE ? v >= want : v == want)
         {
-            if (!c.fl[F_DEAD] && c.lane == 0)
-            {
-                c.fl[F_DEAD] = 1;
-                __hip_atomic_store(c.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-__device__ __forceinline__ bool wait_lds_ge(const Ctx& c, int word, uint32_t want, unsigned code)
-{
-    for (unsigned spins = 0;; ++spins)
-    {
-        if (c.fl[word] >= want)
+            CFENCE();
             return true;
-        if (c.fl[F_DEAD] || spins > SPIN_LIMIT)
-        {
-            if (!c.fl[F_DEAD] && c.lane == 0)
-            {
-                c.fl[F_DEAD] = 1;
-                __hip_atomic_store(c.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return false;
         }
+        if (c.fl[F_DEAD] || spins > SPIN_LIMIT)
+            return give_up(c, code);
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -126,118 +133,180 @@ __device__ __forceinline__ void store_granule(gu64* g, unsigned epoch, unsigned 
     __hip_atomic_store(g, ((unsigned long long) epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ONE wave re-reads n granules (granule i of lane l = g[(c * 16 + k) * 64 + l]) in chunks of 16 loads per lane until every tag
-// carries the epoch; v receives the values (LDS staging is the caller's).  Bounded.
-template <int N>
-__device__ __forceinline__ bool sweep(const Ctx& c, gu64* g, int n_total, unsigned epoch, unsigned (&v)[N], unsigned code)
+// ONE wave re-reads granules [0, n_total) (granule k * 64 + lane in load k of a lane), ALL N loads of a lane in flight per pass (a pass
+// costs one loaded memory round trip, ~1.5 us, whatever its size), until every tag carries the epoch; stage(k, value) then receives
+// the values.  Bounded.
+template <int N, typename F>
+__device__ __forceinline__ bool sweep(const Ctx& c, gu64* gran, int area, int gs, int n_total, unsigned epoch, unsigned code, F&& stage, unsigned long long* pass_ts = nullptr)
 {
-#pragma unroll
-    for (int c0 = 0; c0 < N; c0 += 16)
+    if (c.lane == 0)
+        c.fl[F_GATHER] = 1;
+    int lo = c.lane;
+    asm volatile("" : "+v"(lo)); // the addresses are formed here, per sweep - not hoisted out of the layer loop into 2 x N registers
+    gu64* gl = gran + (size_t) ((area >> 5) + (lo >> 5)) * gs + (lo & 31); // granule i lives at (i / 32) * gs + i % 32
+    unsigned v[N];
+    for (unsigned spins = 0;; ++spins)
     {
-        for (unsigned spins = 0;; ++spins)
-        {
-            bool ok = true;
+        bool ok = true;
 #pragma unroll
-            for (int k = c0; k < (c0 + 16 < N ? c0 + 16 : N); ++k)
-            {
-                const int i = k * 64 + c.lane;
-                unsigned long long x = (unsigned long long) epoch << 32;
-                if (i < n_total)
-                    x = __hip_atomic_load(g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v[k] = (unsigned) x;
-                ok &= (unsigned) (x >> 32) == epoch;
-            }
-            if (__all(ok))
-                break;
-            if (c.fl[F_DEAD] || spins > (SPIN_LIMIT >> 4))
-            {
-                if (!c.fl[F_DEAD] && c.lane == 0)
-                {
-                    c.fl[F_DEAD] = 1;
-                    __hip_atomic_store(c.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                return false;
-            }
+        for (int k = 0; k < N; ++k)
+        {
+            // (the last load of a lane may lie behind the area: clamp the address, ignore the tag)
+            const bool in = lo + k * 64 < n_total;
+            const unsigned long long x = __hip_atomic_load(in ? gl + (size_t) k * 2 * gs : gl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[k] = (unsigned) x;
+            ok &= !in || (unsigned) (x >> 32) == epoch;
         }
+        if (c.lane == 0)
+            c.fl[F_PASSES] = c.fl[F_PASSES] + 1;
+        if (pass_ts && c.lane == 0 && spins < 7)
+        {
+            pass_ts[1 + spins] = __builtin_amdgcn_s_memrealtime();
+            pass_ts[0] = spins + 1;
+        }
+        if (__all(ok))
+            break;
+        if (c.fl[F_DEAD] || spins > (SPIN_LIMIT >> 4))
+            return give_up(c, code);
     }
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        stage(k, v[k]);
+    if (c.lane == 0)
+        c.fl[F_GATHER] = 0;
     return true;
 }
 
+// wave64 reductions on the DPP network (kernels/dev_utils.h): no LDS crossbar round trips
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int src, int old)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int o = 32; o; o >>= 1)
-        v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_i32<0xB1, 0xf>(v, 0);  // quad_perm [1,0,3,2]
+    v += dpp_i32<0x4E, 0xf>(v, 0);  // quad_perm [2,3,0,1]
+    v += dpp_i32<0x141, 0xf>(v, 0); // row_half_mirror
+    v += dpp_i32<0x140, 0xf>(v, 0); // row_mirror
+    v += dpp_i32<0x142, 0xa>(v, 0); // row_bcast:15 -> rows 1, 3
+    v += dpp_i32<0x143, 0xc>(v, 0); // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
 }
+#define DPP_F(v, ctrl, mask) __builtin_bit_cast(float, dpp_i32<ctrl, mask>(__builtin_bit_cast(int, v), 0))
 __device__ __forceinline__ float wave_sumf(float v)
 {
-#pragma unroll
-    for (int o = 32; o; o >>= 1)
-        v += __shfl_xor(v, o, 64);
-    return v;
+    v += DPP_F(v, 0xB1, 0xf);
+    v += DPP_F(v, 0x4E, 0xf);
+    v += DPP_F(v, 0x141, 0xf);
+    v += DPP_F(v, 0x140, 0xf);
+    v += DPP_F(v, 0x142, 0xa);
+    v += DPP_F(v, 0x143, 0xc);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_maxf(float v)
+{
+#define DPP_M(ctrl, mask) v = fmaxf(v, __builtin_bit_cast(float, dpp_i32<ctrl, mask>(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v))))
+    DPP_M(0xB1, 0xf);
+    DPP_M(0x4E, 0xf);
+    DPP_M(0x141, 0xf);
+    DPP_M(0x140, 0xf);
+    DPP_M(0x142, 0xa);
+    DPP_M(0x143, 0xc);
+#undef DPP_M
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // barrier among the three consumer waves (the loader never takes part): monotonic LDS counter
 __device__ __forceinline__ void cbar(const Ctx& c, uint32_t& gen)
 {
     gen += 3;
+    CFENCE();
     if (c.lane == 0)
-        __hip_atomic_fetch_add(const_cast<uint32_t*>(&c.fl[F_CBAR]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    wait_lds_ge(c, F_CBAR, gen, 0x700);
+        __hip_atomic_fetch_add((lds_u32*) (c.fl + F_CBAR), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    wait_lds<true>(c, F_CBAR, gen, 0x700);
 }
 
 __global__ __launch_bounds__(256) void engine_kernel(const char* __restrict__ wstream, size_t cu_stride, int layers, gu64* gran, gu32* err,
-    uint32_t* out, int mode)
+    uint32_t* out, int mode, unsigned long long* ts, unsigned long long* ts2)
 {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
+    extern __shared__ __attribute__((aligned(16))) char lds_generic[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* lds = (lds_char*) lds_generic;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cu = blockIdx.x;
-    volatile uint32_t* fl = reinterpret_cast<volatile uint32_t*>(lds + L_FLAGS);
+    lds_vu32* fl = (lds_vu32*) (lds + L_FLAGS);
     if (tid < 64)
         fl[tid] = 0;
     __syncthreads();
     Ctx c{fl, err, lane};
-    const bool edges = mode & 1, attn = mode & 2;
+    const bool edges = mode & 1, attn = mode & 2, thin = mode & 4;
+    const int gs = mode & 8 ? 544 : 32; // granule groups of 256 B spread 4 KiB + 256 B apart: more memory channels per area
+    auto G = [&](int area, int i) { return gran + (size_t) ((area >> 5) + (i >> 5)) * gs + (i & 31); };
     const int total = layers * S_LAYER;
 
     if (wave == 0)
     {
         // ------------------------------------------------------------------ loader
         const char* base = wstream + (size_t) cu * cu_stride + lane * 16;
-        const uint32_t ring = (uint32_t) (size_t) lds; // LDS byte address of the ring (dynamic LDS starts at 0: no statics)
+        const uint32_t ring = (uint32_t) (uintptr_t) lds; // LDS byte address of the ring
         int pub = 0;
+        unsigned long long stall = 0, t_begin = __builtin_amdgcn_s_memrealtime();
+        int nstall = 0;
+#pragma unroll 1
         for (int s = 0; s < total; ++s)
         {
             const int sl = s & 7;
             const uint32_t rnd = s >> 3;
             if (fl[F_FREED + sl] != rnd)
             {
+                // ring full: we are stalled anyway - drain, publish everything that has been requested, then wait for the slot
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0)
-                    for (; pub < s; ++pub)
-                        fl[F_READY + (pub & 7)] = (pub >> 3) + 1;
+                    for (int f = pub; f < s; ++f)
+                        fl[F_READY + (f & 7)] = (f >> 3) + 1;
                 pub = s;
-                if (!wait_lds(c, F_FREED + sl, rnd, 0x100))
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                if (!wait_lds<false>(c, F_FREED + sl, rnd, 0x100))
                     break;
+                stall += __builtin_amdgcn_s_memrealtime() - t0;
+                ++nstall;
             }
             const char* p = base + (size_t) s * SLOT;
             const uint32_t dst = ring + sl * SLOT;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 glds16_nt(p + i * 1024, dst + i * 1024);
-            asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); // fills <= s - 2 have landed
-            if (lane == 0)
-                for (int f = pub; f + 1 < s; ++f)
-                    fl[F_READY + (f & 7)] = (f >> 3) + 1;
-            if (pub + 1 < s)
-                pub = s - 1;
+            if (thin && fl[F_GATHER])
+            {
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); // fills <= s - 1 have landed
+                if (lane == 0)
+                    for (int f = pub; f < s; ++f)
+                        fl[F_READY + (f & 7)] = (f >> 3) + 1;
+                pub = s;
+            }
+            else
+            {
+                asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); // fills <= s - 2 have landed
+                if (lane == 0)
+                    for (int f = pub; f + 1 < s; ++f)
+                        fl[F_READY + (f & 7)] = (f >> 3) + 1;
+                if (pub + 1 < s)
+                    pub = s - 1;
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
-            for (; pub < total; ++pub)
-                fl[F_READY + (pub & 7)] = (pub >> 3) + 1;
+            for (int f = pub; f < total; ++f)
+                fl[F_READY + (f & 7)] = (f >> 3) + 1;
+        if (lane == 0 && (cu == 0 || cu == 100))
+        {
+            unsigned long long* t = ts + (cu ? 64 : 0) + 32;
+            t[0] = stall;
+            t[1] = nstall;
+            t[2] = __builtin_amdgcn_s_memrealtime() - t_begin;
+        }
         return;
     }
 
@@ -246,35 +315,39 @@ __global__ __launch_bounds__(256) void engine_kernel(const char* __restrict__ ws
     const int xcd = cu & 7, idx = cu >> 3, head = xcd * 4 + (idx >> 3), hj = idx & 7;
     uint32_t gen = 0, xack_want = 0;
     uint32_t sink = 0;
-    const u4* ring = reinterpret_cast<const u4*>(lds);
-    volatile uint32_t* xb32 = reinterpret_cast<volatile uint32_t*>(lds + L_X);
-    float* qb = reinterpret_cast<float*>(lds + L_Q);
-    float* red = reinterpret_cast<float*>(lds + L_RED);
+    lds_cu4* ring = (lds_cu4*) lds;
+    lds_cu4* xv = (lds_cu4*) (lds + L_X);
+    lds_u32* xb32 = (lds_u32*) (lds + L_X);
+    lds_u32* raw = (lds_u32*) (lds + L_RAW);
+    lds_f32* qb = (lds_f32*) (lds + L_Q);
+    lds_f32* red = (lds_f32*) (lds + L_RED);
 
-    auto take = [&](int s) { return wait_lds(c, F_READY + (s & 7), (s >> 3) + 1, 0x200); };
+    auto take = [&](int s) { return wait_lds<false>(c, F_READY + (s & 7), (s >> 3) + 1, 0x200); };
     auto release = [&](int s) {
+        CFENCE(); // LDS operations of one wave are performed in order: the flag lands behind this wave's reads of the slot
         if (lane == 0)
             fl[F_FREED + (s & 7)] = (s >> 3) + 1;
     };
-    // the gatherer stages a swept vector: granule i's value -> LDS word i (xbuf), after the other consumers have let go of xbuf
-    auto xbuf_free = [&]() { wait_lds_ge(c, F_XACK, xack_want, 0x300); };
+    // the gatherer overwrites xbuf only after the other two consumers have let go of the previous vector
+    auto xbuf_free = [&]() { wait_lds<true>(c, F_XACK, xack_want, 0x300); };
     auto raise = [&](uint32_t e) {
-        // LDS writes of one wave are performed in order: the flag lands behind the staged words
+        CFENCE();
         if (lane == 0)
             fl[F_XFLAG] = e;
     };
     auto wait_x = [&](uint32_t e) {
         if (edges)
-            wait_lds_ge(c, F_XFLAG, e, 0x400);
+            wait_lds<true>(c, F_XFLAG, e, 0x400);
     };
     auto ack = [&]() {
         xack_want += 2;
+        CFENCE();
         if (cw != 0 && lane == 0)
-            __hip_atomic_fetch_add(const_cast<uint32_t*>(&fl[F_XACK]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add((lds_u32*) (fl + F_XACK), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     // 4 rows of K = 4096 against the activation slice in registers: 16 ds_read_b128, 64 dot4, one 4-row reduction
     auto rows4 = [&](int s, const u4 (&xr)[4], int (&r)[4]) {
-        const u4* w = ring + (s & 7) * (SLOT / 16) + lane;
+        lds_cu4* w = ring + (s & 7) * (SLOT / 16) + lane;
 #pragma unroll
         for (int row = 0; row < 4; ++row)
         {
@@ -292,18 +365,45 @@ __global__ __launch_bounds__(256) void engine_kernel(const char* __restrict__ ws
         }
     };
     auto load_xr = [&](u4 (&xr)[4]) {
-        const u4* xv = reinterpret_cast<const u4*>(lds + L_X);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             xr[j] = xv[j * 64 + lane];
     };
+    // 2048 granules = 4096 fp16 -> raw copy in LDS + sum of squares -> normalise, quantise -> 4096 int8 in xbuf
+    auto gather_x = [&](int area, unsigned e, unsigned long long* pts = nullptr) -> bool {
+        float ss = 0.f;
+        if (!sweep<32>(c, gran, area, gs, 2048, e, 0x504, [&](int k, unsigned v) {
+                const float lo = (float) (v & 0xffff), hi = (float) (v >> 16);
+                ss += lo * lo + hi * hi;
+                raw[k * 64 + lane] = v;
+            }, pts))
+            return false;
+        ss = wave_sumf(ss);
+        const float inv = rsqrtf(ss * (1.f / 4096.f) + 1e-6f);
+        xbuf_free();
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k)
+        {
+            const uint32_t v0 = raw[(2 * k) * 64 + lane], v1 = raw[(2 * k + 1) * 64 + lane];
+            const int a = (int) ((float) (v0 & 0xffff) * inv), b = (int) ((float) (v0 >> 16) * inv);
+            const int c2 = (int) ((float) (v1 & 0xffff) * inv), d = (int) ((float) (v1 >> 16) * inv);
+            xb32[k * 64 + lane] = (a & 255) | ((b & 255) << 8) | ((c2 & 255) << 16) | (d << 24);
+        }
+        return true;
+    };
 
+    const bool stamp_cu = (cu == 0 || cu == 100) && cw == 0 && lane == 0;
+    unsigned long long* tsc = ts + (cu ? 64 : 0);
+#define STAMP(i)                                                                                                       \
+    if (stamp_cu && layer == layers / 2)                                                                               \
+    tsc[i] = __builtin_amdgcn_s_memrealtime()
+#pragma unroll 1
     for (int layer = 0; layer < layers; ++layer)
     {
         const int s0 = layer * S_LAYER;
-        const unsigned ep = layer * 8 + 1; // + edge index: 0 X2(prev) 1 Q 2 P 3 A 4 X1 5 H 6 X2
+        const unsigned ep = layer * 8 + 1; // tags: ep X2 of the previous layer, +1 Q, +2 P, +3 A, +4 X1, +5 H, +8 X2
         u4 xr[4];
-        int r[4];
+        int r[4] = {0, 0, 0, 0};
 
         // ---- QKV
         if (layer == 0 && cw == 0)
@@ -313,8 +413,10 @@ __global__ __launch_bounds__(256) void engine_kernel(const char* __restrict__ ws
             raise(ep);
         }
         wait_x(ep);
+        STAMP(0);
         load_xr(xr);
         ack();
+#pragma unroll 1
         for (int s = s0 + B_QKV + cw; s < s0 + B_KV; s += 3)
         {
             if (!take(s))
@@ -322,34 +424,32 @@ __global__ __launch_bounds__(256) void engine_kernel(const char* __restrict__ ws
             rows4(s, xr, r);
             release(s);
             if (lane < 2) // 4 rows -> 2 granules (fp16 pairs) of this head's q | k | v
-                store_granule(gran + G_Q + head * 192 + hj * 24 + ((s - s0) * 2 + lane), ep + 1, (unsigned) (r[lane * 2] ^ r[lane * 2 + 1]));
+                store_granule(G(G_Q + head * 192, hj * 24 + ((s - s0) * 2 + lane)), ep + 1, (unsigned) (r[lane * 2] ^ r[lane * 2 + 1]));
         }
+        STAMP(1);
         if (cw == 0 && edges)
         {
-            unsigned v[3];
-            if (!sweep<3>(c, gran + G_Q + head * 192, 192, ep + 1, v, 0x501))
+            if (!sweep<3>(c, gran, G_Q + head * 192, gs, 192, ep + 1, 0x501, [&](int k, unsigned v) { qb[k * 64 + lane] = (float) (v & 0xffff) * 1e-4f; }))
                 return;
-            xbuf_free();
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                qb[k * 64 + lane] = (float) (v[k] & 0xffff) * 1e-4f;
             raise(ep + 1);
         }
         wait_x(ep + 1);
+        STAMP(2);
 
         // ---- attention over this CU's eighth of the cache: K slot, V slot
         {
             const int sk = s0 + B_KV, sv = sk + 1;
             if (!take(sk))
                 return;
-            float part[2] = {0.f, 0.f};
+            float part0 = 0.f, part1 = 0.f;
+            lds_f32* sc = qb + 256;
             if (attn)
             {
                 float q[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     q[i] = qb[(lane & 7) * 16 + i];
-                float* sc = qb + 128;
+#pragma unroll 1
                 for (int line = cw; line < 16; line += 3)
                 {
                     const u4 kv = ring[(sk & 7) * (SLOT / 16) + line * 64 + lane];
@@ -358,35 +458,31 @@ __global__ __launch_bounds__(256) void engine_kernel(const char* __restrict__ ws
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
                         a += q[i] * (float) (int8_t) (w[i >> 2] >> ((i & 3) * 8));
-                    a += __shfl_xor(a, 1, 64);
-                    a += __shfl_xor(a, 2, 64);
-                    a += __shfl_xor(a, 4, 64);
+                    a += DPP_F(a, 0xB1, 0xf);
+                    a += DPP_F(a, 0x4E, 0xf);
+                    a += DPP_F(a, 0x141, 0xf);
                     if ((lane & 7) == 0)
                         sc[line * 8 + (lane >> 3)] = a * 1e-3f;
                 }
                 cbar(c, gen);
                 const float s0v = sc[lane], s1v = sc[64 + lane];
-                float m = fmaxf(s0v, s1v);
-#pragma unroll
-                for (int o = 32; o; o >>= 1)
-                    m = fmaxf(m, __shfl_xor(m, o, 64));
+                const float m = wave_maxf(fmaxf(s0v, s1v));
                 const float p0 = __expf(s0v - m), p1 = __expf(s1v - m);
-                const float l = wave_sumf(p0 + p1);
-                part[0] = m;
-                part[1] = l;
+                part0 = m;
+                part1 = wave_sumf(p0 + p1);
                 cbar(c, gen); // everybody has read the scores
                 sc[lane] = p0;
                 sc[64 + lane] = p1; // (each wave writes the same values)
             }
             if (!take(sv))
                 return;
-            float o[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                o[i] = 0.f;
             if (attn)
             {
-                const float* sc = qb + 128;
+                float o[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    o[i] = 0.f;
+#pragma unroll 1
                 for (int line = cw; line < 16; line += 3)
                 {
                     const u4 vv = ring[(sv & 7) * (SLOT / 16) + line * 64 + lane];
@@ -398,17 +494,14 @@ __global__ __launch_bounds__(256) void engine_kernel(const char* __restrict__ ws
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                {
-                    o[i] += __shfl_xor(o[i], 8, 64);
-                    o[i] += __shfl_xor(o[i], 16, 64);
-                    o[i] += __shfl_xor(o[i], 32, 64);
-                }
-                if (lane < 8)
+                    o[i] += DPP_F(o[i], 0x128, 0xf); // row_ror:8 - the two cache rows of a 16-lane row
+                if ((lane & 8) == 0) // 4 partial rows per wave: red[(cw * 4 + lane / 16)][128]
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
-                        red[cw * 132 + lane * 16 + i] = o[i];
+                        red[(cw * 4 + (lane >> 4)) * 128 + (lane & 7) * 16 + i] = o[i];
             }
             cbar(c, gen); // K and V slots are read, partial outputs are in LDS
+            STAMP(3);
             if (cw == 0)
             {
                 release(sk);
@@ -416,87 +509,69 @@ __global__ __launch_bounds__(256) void engine_kernel(const char* __restrict__ ws
                 if (edges)
                 {
                     // publish this CU's partial (m, l, o[128]) -> 130 granules, sweep the head's 8 partials, merge, publish 16 outputs
-                    gu64* pg = gran + G_P + (head * 8 + hj) * 132;
-                    float mine[3];
 #pragma unroll
                     for (int k = 0; k < 3; ++k)
                     {
                         const int i = k * 64 + lane;
-                        mine[k] = i < 128 ? red[i] + red[132 + i] + red[264 + i] : (i == 128 ? part[0] : part[1]);
-                        if (i < 130)
-                            store_granule(pg + i, ep + 2, __float_as_uint(mine[k]));
+                        float mine = i == 128 ? part0 : part1;
+                        if (i < 128)
+                        {
+                            mine = 0.f;
+#pragma unroll
+                            for (int pr = 0; pr < 12; ++pr)
+                                mine += red[pr * 128 + i];
+                        }
+                        if (i < 132)
+                            store_granule(G(G_P + head * 1056, hj * 132 + i), ep + 2, __float_as_uint(mine));
                     }
-                    unsigned v[17];
-                    if (!sweep<17>(c, gran + G_P + head * 8 * 132, 8 * 132, ep + 2, v, 0x502))
+                    float acc = 0.f; // merge stand-in
+                    if (!sweep<17>(c, gran, G_P + head * 1056, gs, 8 * 132, ep + 2, 0x502, [&](int k, unsigned v) { acc = acc * 0.5f + __uint_as_float(v); }))
                         return;
-                    // merge stand-in: 8 slots x 3 ops per output pair
-                    float acc = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 17; ++k)
-                        acc = acc * 0.5f + __uint_as_float(v[k]);
                     acc = wave_sumf(acc);
+                    STAMP(4);
                     if (lane < 4) // this CU's 16 of the head's 128 outputs, int8: 4 granules
-                        store_granule(gran + G_A + head * 32 + hj * 4 + lane, ep + 3, __float_as_uint(acc) + lane);
-                    unsigned a[16];
-                    if (!sweep<16>(c, gran + G_A, 1024, ep + 3, a, 0x503))
-                        return;
+                        store_granule(G(G_A, head * 32 + hj * 4 + lane), ep + 3, __float_as_uint(acc) + lane);
                     xbuf_free();
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        xb32[k * 64 + lane] = a[k];
+                    if (!sweep<16>(c, gran, G_A, gs, 1024, ep + 3, 0x503, [&](int k, unsigned v) { xb32[k * 64 + lane] = v; }))
+                        return;
                     raise(ep + 3);
                 }
             }
         }
         wait_x(ep + 3);
+        STAMP(5);
 
         // ---- O projection + residual
         load_xr(xr);
         ack();
+#pragma unroll 1
         for (int s = s0 + B_O + cw; s < s0 + B_GU; s += 3)
         {
             if (!take(s))
                 return;
             rows4(s, xr, r);
             release(s);
+            if (lane == 0 && layer == layers / 2)
+                ts2[cu * 16 + cw] = __builtin_amdgcn_s_memrealtime();
             if (lane < 2)
-                store_granule(gran + G_X1 + cu * 8 + (s - s0 - B_O) * 2 + lane, ep + 4, (unsigned) (r[lane * 2] + r[lane * 2 + 1]));
+                store_granule(G(G_X1, cu * 8 + (s - s0 - B_O) * 2 + lane), ep + 4, (unsigned) (r[lane * 2] + r[lane * 2 + 1]));
         }
-        auto gather_x = [&](gu64* area, unsigned e) -> bool {
-            // 2048 granules = 4096 fp16 -> sum of squares -> normalise, quantise -> 4096 int8 in xbuf
-            unsigned v[32];
-            if (!sweep<32>(c, area, 2048, e, v, 0x504))
-                return false;
-            float ss = 0.f;
-#pragma unroll
-            for (int k = 0; k < 32; ++k)
-            {
-                const float lo = (float) (v[k] & 0xffff), hi = (float) (v[k] >> 16);
-                ss += lo * lo + hi * hi;
-            }
-            ss = wave_sumf(ss);
-            const float inv = rsqrtf(ss * (1.f / 4096.f) + 1e-6f);
-            xbuf_free();
-#pragma unroll
-            for (int k = 0; k < 32; k += 2)
-            {
-                const int a = (int) ((float) (v[k] & 0xffff) * inv), b = (int) ((float) (v[k] >> 16) * inv);
-                const int c2 = (int) ((float) (v[k + 1] & 0xffff) * inv), d = (int) ((float) (v[k + 1] >> 16) * inv);
-                xb32[(k >> 1) * 64 + lane] = (a & 255) | ((b & 255) << 8) | ((c2 & 255) << 16) | (d << 24);
-            }
-            return true;
-        };
+        STAMP(6);
         if (cw == 0 && edges)
         {
-            if (!gather_x(gran + G_X1, ep + 4))
+            if (lane == 0 && layer == layers / 2)
+                ts2[cu * 16 + 4] = __builtin_amdgcn_s_memrealtime();
+            if (!gather_x(G_X1, ep + 4, layer == layers / 2 ? ts2 + cu * 16 + 5 : nullptr))
                 return;
             raise(ep + 4);
         }
         wait_x(ep + 4);
+        STAMP(7);
 
         // ---- gate | up + SwiGLU + quantise
         load_xr(xr);
         ack();
+#pragma unroll 1
         for (int s = s0 + B_GU + cw; s < s0 + B_DN; s += 3)
         {
             if (!take(s))
@@ -507,20 +582,18 @@ __global__ __launch_bounds__(256) void engine_kernel(const char* __restrict__ ws
             const float g0 = (float) r[0] * 1e-3f, g1 = (float) r[1] * 1e-3f;
             const unsigned act = (unsigned) (int) (g0 / (1.f + __expf(-g0)) * (float) r[2]) ^ (unsigned) (int) (g1 / (1.f + __expf(-g1)) * (float) r[3]);
             if (lane == 0 && (i & 1) == 0)
-                store_granule(gran + G_H + cu * 11 + (i >> 1), ep + 5, act);
+                store_granule(G(G_H, cu * 11 + (i >> 1)), ep + 5, act);
         }
+        STAMP(8);
         if (cw == 0 && edges)
         {
-            unsigned v[44];
-            if (!sweep<44>(c, gran + G_H, N_H, ep + 5, v, 0x505))
-                return;
             xbuf_free();
-#pragma unroll
-            for (int k = 0; k < 44; ++k)
-                xb32[k * 64 + lane] = v[k];
+            if (!sweep<44>(c, gran, G_H, gs, N_H, ep + 5, 0x505, [&](int k, unsigned v) { xb32[k * 64 + lane] = v; }))
+                return;
             raise(ep + 5);
         }
         wait_x(ep + 5);
+        STAMP(9);
 
         // ---- down projection: 11 slots of 16 rows x 1 KiB of k; per-lane partial sums, one reduction at the end
         {
@@ -528,13 +601,13 @@ __global__ __launch_bounds__(256) void engine_kernel(const char* __restrict__ ws
 #pragma unroll
             for (int i = 0; i < 16; ++i)
                 acc[i] = 0;
-            const u4* xv = reinterpret_cast<const u4*>(lds + L_X);
+#pragma unroll 1
             for (int s = s0 + B_DN + cw; s < s0 + S_LAYER; s += 3)
             {
                 if (!take(s))
                     return;
                 const u4 x = xv[(s - s0 - B_DN) * 64 + lane];
-                const u4* w = ring + (s & 7) * (SLOT / 16) + lane;
+                lds_cu4* w = ring + (s & 7) * (SLOT / 16) + lane;
 #pragma unroll
                 for (int row = 0; row < 16; ++row)
                 {
@@ -557,26 +630,32 @@ __global__ __launch_bounds__(256) void engine_kernel(const char* __restrict__ ws
                 if (lane == row)
                     mine = t;
             }
+            lds_u32* ri = (lds_u32*) red;
             if (lane < 16)
-                reinterpret_cast<int*>(red)[cw * 16 + lane] = mine;
+                ri[cw * 16 + lane] = (uint32_t) mine;
             cbar(c, gen);
+            STAMP(10);
             if (cw == 0)
             {
-                const int* ri = reinterpret_cast<const int*>(red);
                 if (lane < 8)
                 {
-                    const int a = ri[2 * lane] + ri[16 + 2 * lane] + ri[32 + 2 * lane], b = ri[2 * lane + 1] + ri[17 + 2 * lane] + ri[33 + 2 * lane];
-                    store_granule(gran + G_X2 + cu * 8 + lane, ep + 8, (unsigned) (a & 0xffff) | ((unsigned) b << 16));
+                    const int a = (int) (ri[2 * lane] + ri[16 + 2 * lane] + ri[32 + 2 * lane]), b = (int) (ri[2 * lane + 1] + ri[17 + 2 * lane] + ri[33 + 2 * lane]);
+                    store_granule(G(G_X2, cu * 8 + lane), ep + 8, (unsigned) (a & 0xffff) | ((unsigned) b << 16));
                     sink += a + b;
                 }
                 if (edges && layer + 1 < layers)
                 {
-                    if (!gather_x(gran + G_X2, ep + 8))
+                    if (!gather_x(G_X2, ep + 8))
                         return;
                     raise(ep + 8);
                 }
             }
             cbar(c, gen); // red[] may be rewritten
+            STAMP(11);
+            if (stamp_cu && layer == layers / 2)
+                tsc[12] = fl[F_PASSES];
+            if (stamp_cu && layer == layers / 2 - 1)
+                tsc[13] = fl[F_PASSES];
         }
         sink += r[0] + xr[0].x;
     }
@@ -598,13 +677,19 @@ int main(int argc, char** argv)
     const size_t cu_stride = (size_t) layers * S_LAYER * SLOT;
     const size_t bytes = cu_stride * 256;
     char* w;
-    gu64* gran;
-    gu32* err;
+    unsigned long long* gran;
+    unsigned* err;
     uint32_t* out;
+    unsigned long long* ts;
+    unsigned long long* ts2;
     CK(hipMalloc(reinterpret_cast<void**>(&w), bytes));
-    CK(hipMalloc(reinterpret_cast<void**>(&gran), (size_t) G_END * 8));
+    CK(hipMalloc(reinterpret_cast<void**>(&gran), (size_t) G_END * 8 * 17));
     CK(hipMalloc(reinterpret_cast<void**>(&err), 64));
     CK(hipMalloc(reinterpret_cast<void**>(&out), 256 * 3 * 4));
+    CK(hipMalloc(reinterpret_cast<void**>(&ts), 128 * 8));
+    CK(hipMemset(ts, 0, 128 * 8));
+    CK(hipMalloc(reinterpret_cast<void**>(&ts2), 256 * 16 * 8));
+    CK(hipMemset(ts2, 0, 256 * 16 * 8));
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, 0, reinterpret_cast<uint32_t*>(w), bytes / 4);
     CK(hipDeviceSynchronize());
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(engine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL));
@@ -615,23 +700,23 @@ int main(int argc, char** argv)
     CK(hipEventCreate(&e1));
     printf("engine probe: %d layers, %d slots of 16 KiB per CU and layer = %.1f MB per layer on the chip, LDS %d bytes\n", layers, S_LAYER,
         S_LAYER * SLOT * 256 / 1e6, L_TOTAL);
-    const int modes[] = {0, 1, 3};
+    const int modes[] = {0, 1, 7};
     for (int mi = 0; mi < 3; ++mi)
     {
         const int mode = mode_arg >= 0 ? mode_arg : modes[mi];
         hipGraph_t graph;
         hipGraphExec_t exec;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
-        CK(hipMemsetAsync(reinterpret_cast<void*>(gran), 0, (size_t) G_END * 8, st));
-        CK(hipMemsetAsync(reinterpret_cast<void*>(err), 0, 64, st));
-        hipLaunchKernelGGL(engine_kernel, dim3(256), dim3(256), L_TOTAL, st, w, cu_stride, layers, gran, err, out, mode);
+        CK(hipMemsetAsync(gran, 0, (size_t) G_END * 8 * (mode & 8 ? 17 : 1), st));
+        CK(hipMemsetAsync(err, 0, 64, st));
+        hipLaunchKernelGGL(engine_kernel, dim3(256), dim3(256), L_TOTAL, st, w, cu_stride, layers, (gu64*) gran, (gu32*) err, out, mode, ts, ts2);
         CK(hipStreamEndCapture(st, &graph));
         CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         for (int i = 0; i < 3; ++i)
             CK(hipGraphLaunch(exec, st));
         CK(hipStreamSynchronize(st));
         unsigned herr = 0;
-        CK(hipMemcpy(&herr, reinterpret_cast<void*>(err), 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
         CK(hipEventRecord(e0, st));
         for (int i = 0; i < replays; ++i)
             CK(hipGraphLaunch(exec, st));
@@ -640,11 +725,58 @@ int main(int argc, char** argv)
         float ms = 0.f;
         CK(hipEventElapsedTime(&ms, e0, e1));
         const double us = ms * 1000.0 / replays;
-        printf("mode %d (%s%s): %.1f us per step of %d layers = %.2f us per layer, %.2f TB/s%s\n", mode, mode & 1 ? "edges" : "no edges",
+        printf("mode %d%s (%s%s): %.1f us per step of %d layers = %.2f us per layer, %.2f TB/s%s\n", mode, mode & 8 ? " thinned loader, spread granules" : (mode & 4 ? " thinned loader" : ""), mode & 1 ? "edges" : "no edges",
             mode & 2 ? " + attention arithmetic" : "", us, layers, us / layers, (double) bytes / us * 1e-6,
             herr ? "   ** a wait gave up **" : "");
         if (herr)
             printf("   give-up code 0x%x\n", herr);
+        {
+            unsigned long long h[128];
+            CK(hipMemcpy(h, ts, sizeof(h), hipMemcpyDeviceToHost));
+            static const char* names[] = {"x ready", "QKV done", "Q swept", "attention done", "P swept + merged", "A swept", "O done", "X1 gathered", "gate|up done",
+                "H gathered", "down done", "X2 gathered"};
+            if (mode & 1)
+            {
+                std::vector<unsigned long long> h2(256 * 16);
+                CK(hipMemcpy(h2.data(), ts2, h2.size() * 8, hipMemcpyDeviceToHost));
+                unsigned long long pmin = ~0ull, pmax = 0;
+                for (int cu = 0; cu < 256; ++cu)
+                    for (int w = 0; w < 3; ++w)
+                        if (h2[cu * 16 + w])
+                        {
+                            pmin = h2[cu * 16 + w] < pmin ? h2[cu * 16 + w] : pmin;
+                            pmax = h2[cu * 16 + w] > pmax ? h2[cu * 16 + w] : pmax;
+                        }
+                double sum_end = 0, max_end = 0, sum_pass = 0, sum_n = 0, sum_start = 0;
+                for (int cu = 0; cu < 256; ++cu)
+                {
+                    const unsigned long long* t = &h2[cu * 16];
+                    const int n = (int) t[5] > 7 ? 7 : (int) t[5];
+                    const double end = ((double) t[5 + n] - (double) pmax) * 0.01;
+                    sum_end += end;
+                    max_end = end > max_end ? end : max_end;
+                    sum_n += (double) t[5];
+                    sum_pass += ((double) t[5 + n] - (double) t[4]) * 0.01 / n;
+                    sum_start += ((double) t[4] - (double) pmin) * 0.01;
+                }
+                printf("   X1 edge of layer %d: publishes spread over %.2f us; a gatherer starts %.2f us after the first publish, needs %.2f passes of %.2f us, is complete %.2f us (mean) / %.2f us (worst) after the LAST publish\n",
+                    layers / 2, (double) (pmax - pmin) * 0.01, sum_start / 256, sum_n / 256, sum_pass / 256, sum_end / 256, max_end);
+                const unsigned long long* t = &h2[0];
+                printf("   CU 0: sweep start %.2f us after the last publish; passes end at", ((double) t[4] - (double) pmax) * 0.01);
+                for (int i = 0; i < (int) t[5] && i < 7; ++i)
+                    printf(" %.2f", ((double) t[6 + i] - (double) pmax) * 0.01);
+                printf("\n");
+            }
+            for (int w = 0; w < 2; ++w)
+            {
+                const unsigned long long* t = h + w * 64;
+                printf("   CU %3d, layer %d, first consumer (us since x ready):", w ? 100 : 0, layers / 2);
+                for (int i = 1; i < 12; ++i)
+                    printf(" %s %.2f |", names[i], (double) (t[i] - t[0]) * 0.01);
+                printf(" sweep passes in the layer %llu", t[12] - t[13]);
+                printf("\n   CU %3d loader: %.1f us stalled on a full ring in %llu stalls, of %.1f us\n", w ? 100 : 0, (double) t[32] * 0.01, t[33], (double) t[34] * 0.01);
+            }
+        }
         CK(hipGraphExecDestroy(exec));
         CK(hipGraphDestroy(graph));
         if (mode_arg >= 0)
