@@ -86,6 +86,19 @@ int main(int argc, char** argv)
         {"y w8  N304 rms  none   ", 1, 1, 0, 1, 304, D},
         {"x fp N12288 K4096 rms  ", 0, 1, 0, 1, 3 * D, D},
         {"x fp N6144  K4096 rms  ", 0, 1, 0, 1, 6144, D},
+        // per-rank extents under tensor parallelism: QKV / gate|up split their rows, O / down their K
+        {"tp2 sq qkv   rms+q     ", 3, 2, 0, 1, 3 * D / 2, D},
+        {"tp2 sq o     q +res    ", 3, 4, 1, 1, D, D / 2},
+        {"tp2 sq gateup rmsq swiq", 3, 2, 3, 2, I / 2, D},
+        {"tp2 sq down  none +res ", 3, 0, 1, 1, D, I / 2},
+        {"tp4 sq qkv   rms+q     ", 3, 2, 0, 1, 3 * D / 4, D},
+        {"tp4 sq o     q +res    ", 3, 4, 1, 1, D, D / 4},
+        {"tp4 sq gateup rmsq swiq", 3, 2, 3, 2, I / 4, D},
+        {"tp4 sq down  none +res ", 3, 0, 1, 1, D, I / 4},
+        {"tp8 sq qkv   rms+q     ", 3, 2, 0, 1, 3 * D / 8, D},
+        {"tp8 sq o     q +res    ", 3, 4, 1, 1, D, D / 8},
+        {"tp8 sq gateup rmsq swiq", 3, 2, 3, 2, I / 8, D},
+        {"tp8 sq down  none +res ", 3, 0, 1, 1, D, I / 8},
     };
     void *x, *gamma, *res, *y, *scales, *fs;
     CK(hipMalloc(&x, 65536));
