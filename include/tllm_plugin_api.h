@@ -179,7 +179,14 @@ int32_t tllm_comm_destroy_all(void);
  *   all_reduce : direct entry (tests); spins are bounded, tllm_comm_p2p_error() returns non-zero after a time-out. */
 int32_t tllm_comm_p2p_create(int32_t world, int32_t rank, int64_t max_bytes, void* handle64);
 int32_t tllm_comm_p2p_attach(const void* handles);
-void tllm_comm_p2p_enable(int32_t on);
+int32_t tllm_comm_p2p_enable(int32_t on); /* non-zero: refused (not attached; or out of service after a time-out - the ranks'
+                                             epochs are no longer in step - until create + attach on every rank) */
+/* The verdict of the caller's validation of the fused layer seam below (default on).  Off keeps the all-reduce peer-to-peer
+ * and the residual add / RMSNorm / quantiser in the consuming kernels.  Sessions pick the change up at their next step (a
+ * captured step graph is re-captured). */
+void tllm_comm_p2p_enable_fused(int32_t on);
+/* bit 0 attached, bit 1 enabled (the decode all-reduce runs peer-to-peer), bit 2 the fused layer seam is in use */
+int32_t tllm_comm_p2p_state(void);
 int32_t tllm_comm_p2p_all_reduce(void* buf, int64_t count, tllm_stream_t stream);
 int32_t tllm_comm_p2p_error(void);
 /* The tensor-parallel layer seam in ONE launch: all-reduce + residual add + the next RMSNorm (+ SmoothQuant activation quantiser).

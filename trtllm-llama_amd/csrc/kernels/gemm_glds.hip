@@ -550,6 +550,44 @@ static bool glds_serves(const GemmParams& p)
     return true;
 }
 
+// The static rule: fewest workgroup rounds over the CUs, then the largest tile (fewest operand re-reads through L2)
+static int static_shape_cfg(const GemmParams& p)
+{
+    static std::atomic<int> cus_cache{0};
+    int cus = cus_cache.load();
+    if (!cus)
+    {
+        int dev = 0;
+        (void) hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        cus_cache.store(cus);
+    }
+    double best = 1e30;
+    int cfg = 8;
+    for (const Shape& s : kShapes)
+    {
+        const int64_t tiles = (int64_t) ((p.M + s.bm - 1) / s.bm) * ((p.N + s.bn - 1) / s.bn);
+        // time ~ tiles on the busiest CU x tile area; the small tile pays ~15 % for its lower MFMA : LDS ratio
+        const double cost = (double) ((tiles + cus - 1) / cus) * s.bm * s.bn * (s.bm * s.bn == 128 * 128 ? 1.15 : 1.0);
+        if (cost < best)
+        {
+            best = cost;
+            cfg = s.id;
+        }
+    }
+    return cfg;
+}
+
+// the kernel id launch_gemm_glds runs for this problem when no profile entry exists (the tactic profiler's incumbent)
+int gemm_static_cfg(const GemmParams& p)
+{
+    if (!glds_serves(p))
+        return 0;
+    const int cfg = static_shape_cfg(p);
+    return (p.wtype == W_INT8_SQ && cfg == 6) ? 20 : cfg; // the 256 x 192 SmoothQuant tile runs its phased sibling (gemm_sqp.hip)
+}
+
 // exactly kernel `cfg`, no fall-back: 0 launched, -1 launch error, 1 this kernel does not serve the problem (the tactic profiler)
 int launch_gemm_cfg(const GemmParams& p, int cfg, hipStream_t stream)
 {
@@ -587,31 +625,7 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
         cfg = 0; // not served there (shape / alignment): the heuristic below picks a lock-step shape
     }
     if (cfg <= 0 || !((cfg >= 1 && cfg <= kNumCfg) || cfg == 36 || cfg == 37))
-    {
-        // fewest workgroup rounds over 256 CUs, then the largest tile (fewest operand re-reads through L2)
-        static std::atomic<int> cus_cache{0};
-        int cus = cus_cache.load();
-        if (!cus)
-        {
-            int dev = 0;
-            (void) hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-                cus = 256;
-            cus_cache.store(cus);
-        }
-        double best = 1e30;
-        for (const Shape& s : kShapes)
-        {
-            const int64_t tiles = (int64_t) ((p.M + s.bm - 1) / s.bm) * ((p.N + s.bn - 1) / s.bn);
-            // time ~ tiles on the busiest CU x tile area; the small tile pays ~15 % for its lower MFMA : LDS ratio
-            const double cost = (double) ((tiles + cus - 1) / cus) * s.bm * s.bn * (s.bm * s.bn == 128 * 128 ? 1.15 : 1.0);
-            if (cost < best)
-            {
-                best = cost;
-                cfg = s.id;
-            }
-        }
-    }
+        cfg = static_shape_cfg(p);
     if (sq && cfg == 6 && gemm_tune_cfg <= 0 && !from_table)
     {
         // the 256 x 192 SmoothQuant tile has a phased sibling (gemm_sqp.hip) that measures 2-5 % faster at the 7B prefill

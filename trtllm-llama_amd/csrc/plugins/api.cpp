@@ -326,9 +326,20 @@ int32_t tllm_comm_p2p_attach(const void* handles)
     return comm::p2p::attach(handles) ? 1 : 0;
 }
 
-void tllm_comm_p2p_enable(int32_t on)
+int32_t tllm_comm_p2p_enable(int32_t on)
 {
-    comm::p2p::enable(on != 0);
+    return comm::p2p::enable(on != 0) ? 1 : 0;
+}
+
+void tllm_comm_p2p_enable_fused(int32_t on)
+{
+    comm::p2p::enable_fused(on != 0);
+}
+
+int32_t tllm_comm_p2p_state(void)
+{
+    return (comm::p2p::attached() ? 1 : 0) | (comm::p2p::enabled() ? 2 : 0)
+        | ((comm::p2p::enabled() && comm::p2p::usable_fused_flag()) ? 4 : 0);
 }
 
 int32_t tllm_comm_p2p_all_reduce(void* buf, int64_t count, tllm_stream_t stream)

@@ -25,9 +25,17 @@ namespace p2p
 {
 int create(int world, int rank, size_t max_bytes, void* handle64);
 int attach(const void* handles);
-void enable(bool on);
+int enable(bool on); // -1: refused (not attached, or out of service after a time-out until create + attach)
+// the verdict of the caller's validation of the fused layer seam (default on); off keeps the all-reduce peer-to-peer but the
+// residual add / RMSNorm / quantiser in the consuming kernels
+void enable_fused(bool on);
 bool attached();
 bool usable(int world, int64_t bytes);
+bool usable_fused(int world, int64_t bytes);
+bool usable_fused_flag();
+// what a captured step graph depends on (enable / fused / create / time-out all bump it) and the count of time-outs
+uint64_t generation();
+uint64_t error_generation();
 int64_t slot_capacity(int world); // bytes one exchange can carry when the path is enabled for this world size, else 0
 bool enabled();
 // after a time-out: takes the transport out of service and clears the error / poison words, so that the sticky flag does not

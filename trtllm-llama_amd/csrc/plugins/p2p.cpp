@@ -22,8 +22,16 @@ struct State
     void* peer[8] = {};             // every rank's region as mapped here (peer[rank] == local)
     uint32_t* counters = nullptr;   // [0] epoch, [1] error  (ordinary device memory)
     bool attached = false, enabled = false;
+    bool fused = true;          // the fused layer seam (all-reduce + residual + RMSNorm + quantiser) passed its validation
+    bool out_of_service = false; // a time-out took the transport out: enable(true) is refused until create + attach
     int max_spins = 0;
 };
+// Bumped by every change of what a captured step graph may contain (create, enable on / off, fused on / off, time-out): a
+// session compares it with the value it captured its graph under and re-captures on a difference (session.cpp).
+uint64_t g_generation = 1;
+// Bumped by disable_after_error only: a session whose last check saw an older value has work in flight (or in a captured
+// graph) that ran against the broken group, and must fail that call (session.cpp check_comm).
+uint64_t g_error_generation = 0;
 std::mutex g_mu;
 State g;
 
@@ -37,6 +45,7 @@ void release_locked()
     if (g.counters)
         (void) hipFree(g.counters);
     g = State();
+    ++g_generation;
 }
 } // namespace
 
@@ -109,15 +118,53 @@ int attach(const void* handles)
     return 0;
 }
 
-void enable(bool on)
+int enable(bool on)
 {
     std::lock_guard<std::mutex> lk(g_mu);
-    g.enabled = on && g.attached;
+    if (on && g.out_of_service)
+    {
+        // the epochs of the ranks are no longer in step after a time-out; only a fresh region (create + attach on every rank) is
+        set_error("p2p: the transport timed out earlier and is out of service; tllm_comm_p2p_create + attach bring it back");
+        return -1;
+    }
+    const bool v = on && g.attached;
+    if (v != g.enabled)
+        ++g_generation;
+    g.enabled = v;
+    return (on && !v) ? -1 : 0;
+}
+
+void enable_fused(bool on)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (on != g.fused)
+        ++g_generation;
+    g.fused = on;
 }
 
 bool usable(int world, int64_t bytes)
 {
     return g.enabled && g.world == world && bytes > 0 && (size_t) bytes <= g.slot_bytes && bytes % 16 == 0;
+}
+
+bool usable_fused(int world, int64_t bytes)
+{
+    return g.fused && usable(world, bytes);
+}
+
+bool usable_fused_flag()
+{
+    return g.fused;
+}
+
+uint64_t generation()
+{
+    return g_generation;
+}
+
+uint64_t error_generation()
+{
+    return g_error_generation;
 }
 
 int64_t slot_capacity(int world)
@@ -145,6 +192,9 @@ void disable_after_error()
 {
     std::lock_guard<std::mutex> lk(g_mu);
     g.enabled = false;
+    g.out_of_service = true;
+    ++g_generation;
+    ++g_error_generation;
     if (g.counters)
         (void) hipMemset(g.counters + 1, 0, 4);
     if (g.local)

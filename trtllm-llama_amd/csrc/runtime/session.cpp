@@ -211,6 +211,8 @@ struct tllm_session
     int end_id = -1;
     hipGraphExec_t graph = nullptr;
     hipStream_t graph_stream = nullptr;
+    uint64_t graph_comm_gen = 0;   // comm::p2p::generation() the step graph was captured under
+    uint64_t comm_err_seen = 0;    // comm::p2p::error_generation() at this session's last check_comm
     hipStream_t own_stream = nullptr; // used when the caller passes the NULL stream (it cannot be captured)
 
     // ---- optional per-launch instrumentation (tllm_session_profile): event pairs around every launch class
@@ -520,18 +522,27 @@ struct tllm_session
         if (off || layers.empty() || packed) // packed inputs: M varies with the prompt batch, the nearest bucket entry serves
             return 0;
         const Layer& L = layers[0];
+        // weight-only prefill runs gemm_woq.hip (one kernel per shape class, no tactic table); only the r02 expand path
+        // (TLLM_WOQ_EXPAND=1) runs the fp16 kernels on the expanded weights
+        const bool woq_l = L.qkv.wtype == W_INT8_WOQ || L.qkv.wtype == W_INT4_WOQ;
+        if (woq_l && !getenv("TLLM_WOQ_EXPAND"))
+            return 0;
         for (const Linear* l : {&L.qkv, &L.dense, &L.fc, &L.proj})
         {
-            // weight-only prefill GEMMs run the fp16 kernel on the expanded weights
             const int wt = l->wtype == W_INT8_SQ ? W_INT8_SQ : W_FP16;
-            if (gemm_tactic_known(wt, M, l->N, l->K))
+            // an entry of the same power-of-two M bucket (what the engine file brought along, Builder._profile_gemm_tactics)
+            // serves: the launcher would use it for this M anyway
+            if (gemm_tactic_lookup(wt, M, l->N, l->K) > 0)
                 continue;
             int cfg = 0;
             float us = 0.f;
             // best effort: a profile that cannot run (no memory left for its operands next to a large session) leaves the shape
-            // to the static rule - it must not fail the set-up
+            // to the static rule - it must not fail the set-up, nor leave its message behind for a later, unrelated failure
             if (gemm_profile(wt, M, l->N, l->K, &cfg, &us, nullptr))
+            {
+                set_error("%s", "");
                 break;
+            }
         }
         return 0;
     }
@@ -843,8 +854,10 @@ struct tllm_session
         // Q/llama_model.py:107-118 adds, PY/layers/normalization.py:33-54).  The row-parallel GEMVs then write their bare partial
         // sums, every rank adds the residual itself (no rank is special), and the consuming GEMV starts from its operand type.
         // RCCL (or TLLM_NO_FUSED_ALLREDUCE=1) keeps the three-stage path: rank 0 carries the residual, the consumers normalise.
-        static const bool fused_off = getenv("TLLM_NO_FUSED_ALLREDUCE") != nullptr;
-        const bool fused_ar = tp > 1 && !fused_off && D % 8 == 0 && comm::p2p::usable(tp, (int64_t) B * D * 2);
+        // decided ONCE per step (layers and head must take the same branch) from the transport's own state: the verdict of the
+        // caller's validation lives in comm::p2p (tllm_comm_p2p_enable_fused), not in a process-wide cached getenv;
+        // TLLM_NO_FUSED_ALLREDUCE=1 stays as the user's A/B switch and is read per step
+        const bool fused_ar = tp > 1 && !getenv("TLLM_NO_FUSED_ALLREDUCE") && D % 8 == 0 && comm::p2p::usable_fused(tp, (int64_t) B * D * 2);
         const int ar_quant = !sq ? 0 : (per_token ? 2 : 1);
         const float* ar_rows = (sq && per_token) ? ar_scale : nullptr; // per-token scales behind the fused quantiser
         auto fused_seam = [&](const void* gamma, const float* qscale, int quant) {
@@ -1000,8 +1013,7 @@ struct tllm_session
         }
         if (ok >= 0)
             return 0;
-        const bool head_normed = tp > 1 && !getenv("TLLM_NO_FUSED_ALLREDUCE") && D % 8 == 0 && comm::p2p::usable(tp, (int64_t) B * D * 2);
-        RUN(run_head(head_normed ? ar_norm : x, B, st, head_normed));
+        RUN(run_head(fused_ar ? ar_norm : x, B, st, fused_ar));
         RUN(run_sampler(1, st));
         return 0;
     }
@@ -1423,7 +1435,9 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
     RUN(s->dalloc(&s->logits, (size_t) B * s->Vr * s->tp * 4));
     RUN(s->dalloc(&s->last_hidden, (size_t) B * D * 2));
     RUN(s->dalloc(&s->ctx_ws, context_attention_workspace_size(Bc, s->Hr, s->Dh, S) + 256));
-    if (s->woq && Bc * S >= 32)
+    // the fp16 image of the largest weight matrix is needed by the r02 expand path only (TLLM_WOQ_EXPAND=1, the A/B switch);
+    // the production weight-only prefill dequantises in the GEMM's main loop (gemm_woq.hip) and needs no scratch
+    if (s->woq && Bc * S >= 32 && getenv("TLLM_WOQ_EXPAND"))
     {
         size_t mx = 0;
         for (auto& L : s->layers)
@@ -1511,7 +1525,25 @@ static int check_comm(tllm_session_t s)
 {
     // only while the transport is IN SERVICE: once a time-out has taken it out (below), later calls run over RCCL and the
     // words that recorded the failure must not fail them (disable_after_error clears them as well)
-    if ((s->tp == 1 && !s->force_comm) || !comm::p2p::enabled())
+    if (s->tp == 1 && !s->force_comm)
+        return 0;
+    // A time-out detected through ANOTHER live session of this process took the transport out of service (and cleared the
+    // words) since this session last looked: the launches this call replayed from its captured graph ran against the broken
+    // group - they spun to their time-out and left x / ar_norm untouched.  Fail this call too and drop the graph.
+    const uint64_t eg = comm::p2p::error_generation();
+    if (eg != s->comm_err_seen)
+    {
+        s->comm_err_seen = eg;
+        if (s->graph && s->graph_comm_gen != comm::p2p::generation())
+        {
+            (void) hipGraphExecDestroy(s->graph);
+            s->graph = nullptr;
+            set_error("session: the peer-to-peer transport timed out (seen by another session of this process) while this "
+                      "session's captured step still used it; the results of this call are invalid, later calls use RCCL");
+            return 1;
+        }
+    }
+    if (!comm::p2p::enabled())
         return 0;
     uint32_t e = 0;
     if (comm::p2p::error_flag(&e) != 0)
@@ -1522,6 +1554,7 @@ static int check_comm(tllm_session_t s)
     if (e)
     {
         comm::p2p::disable_after_error();
+        s->comm_err_seen = comm::p2p::error_generation();
         if (s->graph) // the captured step holds the peer-to-peer launches
         {
             (void) hipGraphExecDestroy(s->graph);
@@ -1620,7 +1653,9 @@ int32_t tllm_session_step(tllm_session_t s, int32_t n_steps, int32_t use_graph, 
         return 1;
     }
     hipStream_t st = s->pick(stream);
-    if (use_graph && (!s->graph || s->graph_stream != st))
+    // a graph captured while the transport was in another state (enabled / fused seam / a re-created region) holds launches
+    // that no longer match what an eager step would issue: capture again
+    if (use_graph && (!s->graph || s->graph_stream != st || (s->tp > 1 && s->graph_comm_gen != comm::p2p::generation())))
     {
         if (s->graph)
         {
@@ -1646,6 +1681,7 @@ int32_t tllm_session_step(tllm_session_t s, int32_t n_steps, int32_t use_graph, 
             return 1;
         }
         s->graph_stream = st;
+        s->graph_comm_gen = comm::p2p::generation();
     }
     for (int i = 0; i < n_steps; ++i)
     {

@@ -159,7 +159,12 @@ class Builder():
         m_max = int(cfg.get('max_batch_size', 1)) * int(cfg.get('max_input_len', 0))
         if m_max < 32:
             return ''
-        wtype = 3 if int(cfg.get('quant_mode', 0)) & 4 else 0  # SmoothQuant int8, else fp16 (also the weight-only prefill)
+        qm = int(cfg.get('quant_mode', 0))
+        if (qm & 3) and not (qm & 4) and not os.environ.get('TLLM_WOQ_EXPAND'):  # weight-only (no activation quantisation)
+            # weight-only prefill dequantises in the GEMM's main loop (csrc/kernels/gemm_woq.hip): one kernel per shape class,
+            # the fp16 tactic table is never consulted - nothing to profile
+            return ''
+        wtype = 3 if qm & 4 else 0  # SmoothQuant int8, else fp16
         shapes = {(3 * D // tp, D), (D, D // tp), (inter // tp, D), (D, inter // tp)}
         ms = sorted({m_max} | {1 << i for i in range(5, 14) if (1 << i) < m_max})
         for m in ms:
