@@ -426,3 +426,77 @@ def run(torch, dev, layers=32, prompt_len=128, new_tokens=128, n_prompts=8, cpu_
     del ref, parent, sd, act
     torch.cuda.empty_cache()
     return res, cpu, cpu_info
+
+
+# ----------------------------------------------------------------------------------------------------------------------------
+# The same question on a TRAINED parent (tests/golden/trained_llama, made by tests/golden/train_tiny_llama.py): "ROUGE-L delta vs
+# HF <= 1" cannot be decided by free-running generation on random weights (margins below the int8 noise); on
+# a parent whose greedy continuations mean something it can.  The flow is the product's own command line, as the reference runs
+# it (hf_llama_convert.py -> build.py -> summarize.py --test_hf --test_trt_llm, Q/summarize.py:91,260,321-323,352): 24 prompts x
+# 100 new tokens, HF fp32 beside the engine, ROUGE of both against the language's own continuation (the `highlights`).
+# tests/test_gpu_trained_accuracy.py asserts the same numbers per configuration.
+# ----------------------------------------------------------------------------------------------------------------------------
+TRAINED_CONFIGS = {
+    'fp16': (False, []),
+    'int8_kv': (False, ['--int8_kv_cache']),
+    'woq8_int8kv': (False, ['--use_weight_only', '--int8_kv_cache']),
+    'woq4_int8kv': (False, ['--use_weight_only', '--weight_only_precision', 'int4', '--int8_kv_cache']),
+    'sq_static_int8kv': (True, ['--use_smooth_quant', '--per_channel', '--int8_kv_cache']),
+    'sq_per_token_int8kv': (True, ['--use_smooth_quant', '--per_token', '--per_channel', '--int8_kv_cache']),
+}
+
+
+def trained_parent_report(log=print, configs=None, workdir=None):
+    import json
+    import subprocess
+    import tempfile
+
+    import numpy as np
+    fix = os.path.join(ROOT, 'tests', 'golden', 'trained_llama')
+    if not os.path.exists(os.path.join(fix, 'eval.npz')):
+        return {'error': 'tests/golden/trained_llama is missing'}
+    base = workdir or tempfile.mkdtemp(prefix='tllm_trained_')
+    e = np.load(os.path.join(fix, 'eval.npz'))
+    for k in ('prompts', 'lengths', 'reference', 'calib'):
+        np.save(os.path.join(base, k + '.npy'), e[k])
+    new = int(e['hf_tokens'].shape[1])
+    info = json.load(open(os.path.join(fix, 'TRAINLOG.json')))
+    out = {'parent': 'tests/golden/trained_llama (D 256, 4 layers, 4 heads x 64, FFN 768, vocab 512; trained by '
+                     'tests/golden/train_tiny_llama.py)', 'prompts': int(e['prompts'].shape[0]), 'new_tokens': new,
+           'hf_margin_median': info['margin']['median'], 'hf_margin_frac_below_0p2': info['margin']['frac_below_0p2'],
+           'criterion': '|ROUGE-L(engine vs highlights) - ROUGE-L(HF fp32 vs highlights)| <= 1 (README.md:921, summarize.py)',
+           'configs': {}}
+    ft = {}
+    py = sys.executable
+    for name, (sq, flags) in TRAINED_CONFIGS.items():
+        if configs and name not in configs:
+            continue
+        t0 = time.time()
+        try:
+            if sq not in ft:
+                d = os.path.join(base, 'ft_sq' if sq else 'ft')
+                subprocess.run([py, os.path.join(EX, 'hf_llama_convert.py'), '-i', fix, '-o', d, '--calibrate-kv-cache', '--calib-ids',
+                                os.path.join(base, 'calib.npy')] + (['-sq', '0.5'] if sq else []), check=True, cwd=EX, timeout=900,
+                               capture_output=True)
+                ft[sq] = os.path.join(d, '1-gpu')
+            eng = os.path.join(base, 'eng_' + name)
+            subprocess.run([py, os.path.join(EX, 'build.py'), '--model_dir', ft[sq], '--output_dir', eng, '--max_batch_size', '4',
+                            '--max_input_len', '256', '--max_output_len', str(new), '--log_level', 'error'] + flags, check=True, cwd=EX,
+                           timeout=900, capture_output=True)
+            res = os.path.join(base, f'rouge_{name}.json')
+            subprocess.run([py, os.path.join(EX, 'summarize.py'), '--hf_model_location', fix, '--test_hf', '--test_trt_llm', '--data_type',
+                            'fp32', '--engine_dir', eng, '--prompts_npy', os.path.join(base, 'prompts.npy'), '--prompt_lengths_npy',
+                            os.path.join(base, 'lengths.npy'), '--references_npy', os.path.join(base, 'reference.npy'), '--output_len',
+                            str(new), '--batch_size', '4', '--max_ite', str(int(e['prompts'].shape[0]) // 4), '--log_level', 'error',
+                            '--output_json', res], check=True, cwd=EX, timeout=1800, capture_output=True)
+            r = json.load(open(res))
+            out['configs'][name] = {'rougeL': r['tensorrt_llm']['rougeL'], 'hf_rougeL': r['hf']['rougeL'],
+                                    'rougeL_delta_vs_hf': r['rougeL_delta_vs_hf'], 'within_1': abs(r['rougeL_delta_vs_hf']) <= 1.0,
+                                    'rougeL_of_engine_text_vs_hf_text': r['tensorrt_llm_vs_hf']['rougeL'],
+                                    'token_match_rate': r['token_match_rate'], 'seconds': time.time() - t0}
+            log(f'trained parent, {name}: ROUGE-L {r["tensorrt_llm"]["rougeL"]:.2f} (HF {r["hf"]["rougeL"]:.2f}, delta '
+                f'{r["rougeL_delta_vs_hf"]:+.2f}), token match {r["token_match_rate"]:.3f}')
+        except Exception as ex:  # side report: one failing configuration must not cost the others
+            msg = getattr(ex, 'stderr', b'')
+            out['configs'][name] = {'error': repr(ex), 'stderr_tail': (msg.decode(errors='replace')[-600:] if msg else '')}
+    return out

@@ -10,19 +10,20 @@ below the int8 noise and falls into 1-4-token cycles, so free-running generation
 language that has what a summarisation prompt has: a long prompt whose content the continuation depends on.
 
 The language ("records and phrases", vocab 512):
-  document = BOS, 32 x (key, value) records in random key order, SEP, then phrases until the end.
-  phrase p (160 of them) = its own head token, 2..6 body tokens drawn from a SHARED pool (the same body token occurs in many
-    phrases, so the next token depends on the head a few positions back), and for 40 % of the phrases a key token followed
-    by THE VALUE THE DOCUMENT'S HEADER BOUND TO THAT KEY (a look-up over up to ~250 positions: attention + KV cache).
+  document = BOS, 16 RECORD tokens in random order (a record token names one of 16 keys AND the one of 16 values bound to it),
+             SEP, 0..48 re-queries (a key token, then the value token its record binds it to; random keys), SEP2, then phrases.
+  phrase p (120 of them) = its own head token, 1..4 body tokens drawn from a SHARED pool (the same body token occurs in many
+    phrases, so the next token depends on the head a few positions back), and for 60 % of the phrases a key token followed
+    by THE VALUE THE DOCUMENT'S RECORD BINDS TO THAT KEY (a look-up over up to ~250 positions: attention + KV cache).
   the next phrase is perm[p] with probability 0.85, uniform otherwise (perm: a seeded random permutation - long cycles).
 So the most likely continuation of a prompt is a deterministic, non-repeating chain of phrases with look-ups into the
 prompt's header - `reference_continuation()` - which plays the part of the dataset's `highlights`.
 
 Fixture (all seeded; regenerate with this script):
   config.json, model.safetensors   HF LlamaForCausalLM, fp16 weights (D 256, 4 layers, 4 heads x 64, FFN 768, vocab 512)
-  eval.npz   prompts [24, Lmax] (+ lengths, ragged 90..156), reference continuations [24, 100] (the language's own),
+  eval.npz   prompts [24, Lmax] (+ lengths, ragged ~95..205), reference continuations [24, 100] (the language's own),
              HF fp32 greedy continuations [24, 100] of the fp16-rounded weights, HF fp32 logits of every generated step on
-             HF's own path [24, 100, 512], calibration prompts [64, 192] for hf_llama_convert.py --calib-npy
+             HF's own path for the first 8 prompts [8, 100, 512], calibration prompts [64, 192] for hf_llama_convert.py --calib-npy
   TRAINLOG.json   loss curve, margins, accuracy of HF greedy against the reference continuation
 """
 import argparse
@@ -36,12 +37,13 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 V = 512
-PAD, BOS, EOS, SEP = 0, 1, 2, 3
-KEY0, NKEY = 16, 32
-VAL0, NVAL = 48, 128
-HEAD0, NPHRASE = 176, 160
-POOL0, NPOOL = HEAD0 + NPHRASE, V - HEAD0 - NPHRASE  # 336 .. 511
-DOC_LEN = 288
+PAD, BOS, EOS, SEP, SEP2 = 0, 1, 2, 3, 4
+KEY0, NKEY = 16, 16
+VAL0, NVAL = 32, 16
+REC0 = 48                      # record tokens: REC0 + key * NVAL + value  (256 of them)
+HEAD0, NPHRASE = REC0 + NKEY * NVAL, 120
+POOL0, NPOOL = HEAD0 + NPHRASE, V - HEAD0 - NPHRASE  # 424 .. 511
+DOC_LEN = 320
 CFG = dict(hidden_size=256, num_attention_heads=4, num_key_value_heads=4, intermediate_size=768, vocab_size=V,
            num_hidden_layers=4, max_position_embeddings=512, rms_norm_eps=1e-6, hidden_act='silu', attention_bias=False,
            tie_word_embeddings=False, bos_token_id=BOS, eos_token_id=EOS, pad_token_id=PAD)
@@ -50,8 +52,8 @@ CFG = dict(hidden_size=256, num_attention_heads=4, num_key_value_heads=4, interm
 class Language:
     def __init__(self, seed=1234):
         r = np.random.default_rng(seed)
-        self.body = [r.integers(POOL0, POOL0 + NPOOL, int(r.integers(2, 7))).tolist() for _ in range(NPHRASE)]
-        self.key = [int(r.integers(0, NKEY)) if r.random() < 0.4 else -1 for _ in range(NPHRASE)]
+        self.body = [r.integers(POOL0, POOL0 + NPOOL, int(r.integers(1, 5))).tolist() for _ in range(NPHRASE)]
+        self.key = [int(r.integers(0, NKEY)) if r.random() < 0.6 else -1 for _ in range(NPHRASE)]
         self.perm = r.permutation(NPHRASE)
 
     def phrase(self, p, binding):
@@ -60,19 +62,27 @@ class Language:
             t += [KEY0 + self.key[p], VAL0 + binding[self.key[p]]]
         return t
 
-    def document(self, r, length=DOC_LEN):
+    def document(self, r, length=DOC_LEN, n_queries=None):
         binding = r.integers(0, NVAL, NKEY)
         order = r.permutation(NKEY)
         t = [BOS]
-        for k in order:
-            t += [KEY0 + int(k), VAL0 + int(binding[k])]
+        for k in order:  # one RECORD token per key: it names the key and the value bound to it
+            t.append(REC0 + int(k) * NVAL + int(binding[k]))
         t.append(SEP)
+        # a block of re-queries (key, its value) in random order: half of a training document's tokens behind the header are
+        # look-ups, which is what makes the two-layer look-up circuit form within a few thousand steps on a CPU
+        nq = int(r.integers(0, 49)) if n_queries is None else n_queries
+        for k in r.integers(0, NKEY, nq):
+            t += [KEY0 + int(k), VAL0 + int(binding[k])]
+        t.append(SEP2)
+        body0 = len(t)
         p = int(r.integers(0, NPHRASE))
         starts = []
         while len(t) < length:
             starts.append((len(t), p))
             t += self.phrase(p, binding)
             p = int(self.perm[p]) if r.random() < 0.85 else int(r.integers(0, NPHRASE))
+        self.body0 = body0
         return np.array(t[:length], np.int64), binding, starts
 
     def reference_continuation(self, doc, binding, starts, cut, n):
@@ -90,30 +100,16 @@ def batch(lang, r, n):
     return torch.from_numpy(np.stack([lang.document(r)[0] for _ in range(n)]))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--steps', type=int, default=3000)
-    ap.add_argument('--batch', type=int, default=48)
-    ap.add_argument('--lr', type=float, default=3e-3)
-    ap.add_argument('--threads', type=int, default=8)
-    ap.add_argument('--out', default=os.path.join(HERE, 'trained_llama'))
-    ap.add_argument('--n_eval', type=int, default=24)
-    ap.add_argument('--new_tokens', type=int, default=100)
-    args = ap.parse_args()
-    torch.set_num_threads(args.threads)
-    torch.manual_seed(0)
+def train(args, lang, log, t0):
     from transformers import LlamaConfig, LlamaForCausalLM
     cfg = LlamaConfig(**CFG)
     cfg._attn_implementation = 'sdpa'
     model = LlamaForCausalLM(cfg).float().train()
-    lang = Language()
     r = np.random.default_rng(7)
     opt = torch.optim.AdamW(model.parameters(), lr=args.lr, betas=(0.9, 0.95), weight_decay=0.05)
     warm = 100
     sched = torch.optim.lr_scheduler.LambdaLR(
         opt, lambda s: min(1.0, (s + 1) / warm) * (0.05 + 0.95 * 0.5 * (1 + np.cos(np.pi * min(s, args.steps) / args.steps))))
-    log = []
-    t0 = time.time()
     for step in range(args.steps):
         ids = batch(lang, r, args.batch)
         out = model(input_ids=ids, labels=ids)
@@ -123,8 +119,14 @@ def main():
         opt.step()
         sched.step()
         if step % 50 == 0 or step == args.steps - 1:
-            log.append((step, float(out.loss)))
-            print(f'step {step} loss {float(out.loss):.4f} ({time.time() - t0:.0f} s)', flush=True)
+            # how many of the body's look-ups (the token behind a key, beyond the header) the model gets right, teacher-forced
+            with torch.no_grad():
+                pred = out.logits[:, :-1].argmax(-1)
+                is_key = (ids[:, :-1] >= KEY0) & (ids[:, :-1] < KEY0 + NKEY)
+                is_key[:, :NKEY + 1] = False
+                look = float((pred[is_key] == ids[:, 1:][is_key]).float().mean()) if bool(is_key.any()) else 0.0
+            log.append((step, float(out.loss.detach()), look))
+            print(f'step {step} loss {float(out.loss.detach()):.4f} look-up accuracy {look:.3f} ({time.time() - t0:.0f} s)', flush=True)
 
     # ---- the parent = the fp16-rounded weights (every engine and HF start from the same numbers)
     model.eval()
@@ -135,12 +137,39 @@ def main():
     model.half().save_pretrained(args.out, safe_serialization=True)
     model.float()
 
+    return model
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=3000)
+    ap.add_argument('--batch', type=int, default=48)
+    ap.add_argument('--lr', type=float, default=3e-3)
+    ap.add_argument('--threads', type=int, default=8)
+    ap.add_argument('--out', default=os.path.join(HERE, 'trained_llama'))
+    ap.add_argument('--n_eval', type=int, default=24)
+    ap.add_argument('--new_tokens', type=int, default=100)
+    ap.add_argument('--n_logits', type=int, default=8, help='prompts whose per-step HF logits are stored (fp32)')
+    ap.add_argument('--eval_only', action='store_true')
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    torch.manual_seed(0)
+    from transformers import LlamaConfig, LlamaForCausalLM
+    lang = Language()
+    log = []
+    t0 = time.time()
+    if args.eval_only:  # re-make eval.npz / TRAINLOG.json from the saved parent
+        model = LlamaForCausalLM.from_pretrained(args.out).float().eval()
+        prev = json.load(open(os.path.join(args.out, 'TRAINLOG.json')))
+        log, t0 = prev.get('loss', []), time.time() - prev.get('seconds', 0.0)
+    else:
+        model = train(args, lang, log, t0)
     # ---- evaluation set
     re = np.random.default_rng(99)
     prompts, refs, lens = [], [], []
     for _ in range(args.n_eval):
-        doc, binding, starts = lang.document(re, length=400)
-        cut = int(re.integers(90, 157))
+        doc, binding, starts = lang.document(re, length=480, n_queries=int(re.integers(4, 25)))
+        cut = lang.body0 + int(re.integers(20, 90))  # somewhere inside the phrases, possibly inside one
         prompts.append(doc[:cut])
         lens.append(cut)
         refs.append(lang.reference_continuation(doc, binding, starts, cut, args.new_tokens))
@@ -168,9 +197,9 @@ def main():
     acc = float(np.mean(hf_out == np.stack(refs)))
     calib = np.stack([lang.document(re, length=192)[0] for _ in range(64)]).astype(np.int32)
     np.savez_compressed(os.path.join(args.out, 'eval.npz'), prompts=P, lengths=np.array(lens, np.int32),
-                        reference=np.stack(refs).astype(np.int32), hf_tokens=hf_out, hf_logits=hf_logits.astype(np.float16),
+                        reference=np.stack(refs).astype(np.int32), hf_tokens=hf_out, hf_logits=hf_logits[:args.n_logits],
                         hf_logits_absmax=np.abs(hf_logits).max(), calib=calib)
-    info = dict(steps=args.steps, batch=args.batch, doc_len=DOC_LEN, seconds=time.time() - t0, loss=log,
+    info = dict(steps=len(log) and log[-1][0] + 1 or args.steps, batch=args.batch, doc_len=DOC_LEN, seconds=time.time() - t0, loss=log,
                 hf_greedy_vs_reference_token_accuracy=acc,
                 margin=dict(median=float(np.median(margin)), p05=float(np.quantile(margin, 0.05)), min=float(margin.min()),
                             frac_below_0p2=float(np.mean(margin < 0.2))),

@@ -202,3 +202,27 @@ def test_rope_vs_hf_rotary_at_far_positions(pos):
     # oracle output is rounded to fp16 (the plugin's contract): half an fp16 ulp of |x| <= ~4
     np.testing.assert_allclose(got, want, atol=2e-3, rtol=1e-3)
     assert np.abs(got - want).max() < 2.5e-3
+
+
+@pytest.mark.parametrize('dtype', ['float16', 'float32', 'int32'])
+@pytest.mark.parametrize('per_token,per_channel', [(False, False), (True, False), (False, True), (True, True)])
+def test_sq_gemm_oracle_vs_the_reference_known_answer_formula(dtype, per_token, per_channel):
+    """T/tests/quantization/_utils.py:91-121 `gt_matmul_smooth_quant`, restated in torch on the CPU (the original calls .cuda()):
+    int32 matmul, * (scale_a x scale_b) in fp32, ROUNDED when the output type is int32, cast.  Shapes / scale distributions of
+    test_smooth_quant_gemm.py:20-41,104-117 (M = 32, K = 768, N = 2304) and of test_quant_layer.py:200-303 (M = 30, K = 32, N = 64)."""
+    import torch
+    from oracle import llama_oracle as O
+    for (m, n, k) in ((32, 2304, 768), (30, 64, 32)):
+        torch.manual_seed(m + n)
+        a = torch.randint(-128, 128, (m, k), dtype=torch.int8)
+        w = torch.randint(-128, 128, (n, k), dtype=torch.int8)
+        sa = torch.ones((m if per_token else 1, 1)) * 1e-2 * torch.randint(1, 10, (m if per_token else 1, 1)).float()
+        sb = torch.ones((1, n if per_channel else 1)) * 1e-2 * torch.randint(1, 10, (1, n if per_channel else 1)).float()
+        ref = torch.matmul(a.to(torch.int32), w.t().to(torch.int32))
+        scaling = torch.matmul(sa.expand(m, 1), sb.expand(1, n))
+        ref = ref * scaling
+        if dtype == 'int32':
+            ref = torch.round(ref)
+        ref = ref.to({'float16': torch.float16, 'float32': torch.float32, 'int32': torch.int32}[dtype])
+        got = O.sq_gemm(a.numpy(), w.numpy(), sa.numpy(), sb.numpy(), dtype)
+        np.testing.assert_array_equal(np.asarray(got, dtype=np.float64), ref.double().numpy())

@@ -43,6 +43,9 @@ def main():
         mops = r.get('SQ_INSTS_VALU_MFMA_MOPS_I8')
         if mops:
             print(f'  -> int8 MFMA ops = MOPS_I8 x 512 = {mops * 512:.4g}')
+        mops = r.get('SQ_INSTS_VALU_MFMA_MOPS_F16')
+        if mops:
+            print(f'  -> fp16 MFMA flops = MOPS_F16 x 512 = {mops * 512:.4g}')
 
 
 if __name__ == '__main__':

@@ -24,6 +24,21 @@ __device__ __forceinline__ int8_t f2i8_rni_sat(float x)
     return (int8_t) ((x != x) ? 0 : v);
 }
 
+// int32 output of the SmoothQuant GEMM: CUTLASS NumericConverter<int32_t, float> = cvt.rni.s32.f32 (round-half-even, saturating,
+// NaN -> 0) applied to float(acc) * (scale_col * scale_row)   (epilogue_per_row_per_col_scale.h:296; the reference's known-answer
+// formula T/tests/quantization/_utils.py:112-114 rounds the SCALED product for dtype int32 - the raw accumulator never leaves)
+__device__ __forceinline__ int32_t f2i32_rni_sat(float x)
+{
+    const float r = __builtin_rintf(x);
+    if (x != x)
+        return 0;
+    if (r >= 2147483648.f)
+        return 2147483647;
+    if (r <= -2147483648.f)
+        return (int32_t) 0x80000000;
+    return (int32_t) r;
+}
+
 __device__ __forceinline__ float h2f(uint16_t bits)
 {
     _Float16 h;

@@ -30,6 +30,7 @@ using namespace dev;
 
 int gemm_tune_cfg = 0; // test/bench override of the tile shape (0 = heuristic)
 int launch_gemm_sqp(const GemmParams& p, int cfg, hipStream_t stream); // gemm_sqp.hip: phased SmoothQuant kernel, ids 13..
+int launch_gemm_f16p(const GemmParams& p, int cfg, hipStream_t stream); // gemm_sqp.hip: the same pipeline on fp16 operands, ids 50..
 extern void* gemm_clock_probe;                                              // gemm_sqp.hip (microbench hook)
 
 namespace
@@ -447,13 +448,12 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void gemm_glds_kernel(con
                 if constexpr (SQ)
                 {
                     const int a = acc[i][j][r];
-                    if (p.out_dtype == DT_INT32)
-                        reinterpret_cast<int32_t*>(p.c)[o] = a;
-                    else
                     {
                         const float sr = p.per_token ? s_row[row] : s_row[0];
                         const float v = (float) a * (sc[j] * sr);
-                        if (p.out_dtype == DT_HALF)
+                        if (p.out_dtype == DT_INT32)
+                            reinterpret_cast<int32_t*>(p.c)[o] = f2i32_rni_sat(v);
+                        else if (p.out_dtype == DT_HALF)
                             reinterpret_cast<uint16_t*>(p.c)[o] = f2h(v);
                         else
                             reinterpret_cast<float*>(p.c)[o] = v;
@@ -585,7 +585,7 @@ int gemm_static_cfg(const GemmParams& p)
     if (!glds_serves(p))
         return 0;
     const int cfg = static_shape_cfg(p);
-    return (p.wtype == W_INT8_SQ && cfg == 6) ? 20 : cfg; // the 256 x 192 SmoothQuant tile runs its phased sibling (gemm_sqp.hip)
+    return cfg == 6 ? (p.wtype == W_INT8_SQ ? 20 : 50) : cfg; // the 256 x 192 tile runs its phased sibling (gemm_sqp.hip)
 }
 
 // exactly kernel `cfg`, no fall-back: 0 launched, -1 launch error, 1 this kernel does not serve the problem (the tactic profiler)
@@ -599,7 +599,7 @@ int launch_gemm_cfg(const GemmParams& p, int cfg, hipStream_t stream)
         // a tile far larger than the problem only burns time in the sweep
         return sq ? launch_wt<W_INT8_SQ>(p, cfg, stream) : launch_wt<W_FP16>(p, cfg, stream);
     }
-    return sq ? launch_gemm_sqp(p, cfg, stream) : 1;
+    return sq ? launch_gemm_sqp(p, cfg, stream) : launch_gemm_f16p(p, cfg, stream);
 }
 
 // returns 0 on success, -1 on a launch error, 1 when the shape / type is not served by this kernel
@@ -617,15 +617,22 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
         from_table = cfg > 0;
     }
     const bool glds_id = (cfg >= 1 && cfg <= kNumCfg) || cfg == 36 || cfg == 37; // ids served by this file's table
-    if (sq && cfg > kNumCfg && !glds_id)
+    if (cfg > kNumCfg && !glds_id)
     {
-        const int r = launch_gemm_sqp(p, cfg, stream);
+        const int r = sq ? launch_gemm_sqp(p, cfg, stream) : launch_gemm_f16p(p, cfg, stream);
         if (r <= 0)
             return r;
         cfg = 0; // not served there (shape / alignment): the heuristic below picks a lock-step shape
     }
     if (cfg <= 0 || !((cfg >= 1 && cfg <= kNumCfg) || cfg == 36 || cfg == 37))
         cfg = static_shape_cfg(p);
+    if (!sq && cfg == 6 && gemm_tune_cfg <= 0 && !from_table)
+    {
+        // the same sibling on fp16 operands (r04): 6 - 7 % faster on QKV / gate / up at M = 1024 (profiles/r04_fp16_gemm_sweep.txt)
+        const int r = launch_gemm_f16p(p, 50, stream);
+        if (r <= 0)
+            return r;
+    }
     if (sq && cfg == 6 && gemm_tune_cfg <= 0 && !from_table)
     {
         // the 256 x 192 SmoothQuant tile has a phased sibling (gemm_sqp.hip) that measures 2-5 % faster at the 7B prefill

@@ -245,13 +245,12 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const GemmParams p)
                 if constexpr (SQ)
                 {
                     const int a = acc[i][j][r];
-                    if (p.out_dtype == DT_INT32)
-                        reinterpret_cast<int32_t*>(p.c)[o] = a;
-                    else
                     {
                         const float sr = p.per_token ? s_row[row] : s_row[0];
                         const float v = (float) a * (sc * sr);
-                        if (p.out_dtype == DT_HALF)
+                        if (p.out_dtype == DT_INT32)
+                            reinterpret_cast<int32_t*>(p.c)[o] = f2i32_rni_sat(v);
+                        else if (p.out_dtype == DT_HALF)
                             reinterpret_cast<uint16_t*>(p.c)[o] = f2h(v);
                         else
                             reinterpret_cast<float*>(p.c)[o] = v;

@@ -35,6 +35,8 @@ namespace
 {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 // one LDS-DMA instruction: 64 lanes x 16 bytes, global (wave-uniform base + per-lane 32-bit offset) -> LDS [m0 + lane * 16]
@@ -63,10 +65,18 @@ __device__ __forceinline__ int swz_g(int row)
 
 // SCL: the tile's scales are staged in LDS ahead of the operand stream (the epilogue issues no global load).  false: the epilogue
 // reads them from global / L2 instead - 1.25 KB of LDS less, which is what lets TWO 128 x 192 workgroups (2 x 80 KB) share a CU.
-template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRIO, int ABL, int RSP, bool DUAL = false, bool SCL = true>
+// F16 (r04): the same pipeline on fp16 operands - v_mfma_f32_16x16x32_f16 has the byte geometry of v_mfma_i32_16x16x64_i8 (a lane
+// holds 16 bytes of a 64-byte k-step of one row; 16 x 16 fp32 / int32 results in the same lanes), a 128-byte K line is 64 halfs,
+// so the quarter units, the swizzle, the DMA schedule and the counted waits carry over unchanged; fp32 accumulation, optional fp16
+// per-channel scale (the weight-only expand path), A7 P/gemmPlugin/gemmPlugin.cpp:121-190.
+template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRIO, int ABL, int RSP, bool DUAL = false, bool SCL = true,
+    bool F16 = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams p)
 {
     static_assert(SCL || !DUAL, "the fused SwiGLU epilogue reads its scales from LDS");
+    static_assert(!F16 || (!DUAL && !SCL), "the fp16 variant has no dual / staged-scale form");
+    using acc_t = typename std::conditional<F16, f32x4, i32x4>::type;
+    constexpr int ES = F16 ? 2 : 1; // bytes per operand element
     constexpr int NW = WR * WC;
     constexpr int AH = WR * MTH * 16, BH = WC * NTH * 16; // rows of an X-half / W-half unit
     constexpr int BM = 2 * AH, BN = 2 * BH;
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     // DUAL: W-half 0 = rows [n0, n0 + BH) of the first matrix, W-half 1 = the SAME rows of the second one; BH output columns
     const int m0 = tm * BM, n0 = tn * (DUAL ? BH : BN);
     const int M = p.M, N = p.N;
-    const int ntile = p.K / 128;
+    const int ntile = p.K * ES / 128;
 
     // ---- DMA sources.  Unit kinds: 0 = X0, 1 = W0, 2 = W1, 3 = X1 (issue order inside a K-tile).  Chunk c of a unit
     // covers rows [8c, 8c+8); lane l -> row 8c + (l >> 3), LDS piece l & 7 <- global piece (l & 7) ^ g(row).
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
             const int row = c * 8 + (lane >> 3);
             int gr = m0 + h * AH + row;
             gr = gr < M ? gr : M - 1;
-            xo[h][k] = (uint32_t) (gr * (int) p.lda + (((lane & 7) ^ swz_g(row)) << 4));
+            xo[h][k] = (uint32_t) (gr * (int) p.lda * ES + (((lane & 7) ^ swz_g(row)) << 4));
         }
 #pragma unroll
         for (int k = 0; k < BPW; ++k)
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         wrd[ks] = (wc * NTH * 16 + row16) * 128 + (((ks * 4 + kq) ^ gl) << 4);
     }
 
-    i32x4 acc[2][2][MTH][NTH];
+    acc_t acc[2][2][MTH][NTH];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
             for (int m = 0; m < MTH; ++m)
 #pragma unroll
                 for (int n = 0; n < NTH; ++n)
-                    acc[i][j][m][n] = i32x4{0, 0, 0, 0};
+                    acc[i][j][m][n] = acc_t{0, 0, 0, 0};
 
     i32x4 fa[2][MTH][2];     // X-half fragments [half][m][ks]
     i32x4 fb0[2][NTH][2];    // W-half 0 fragments, two sets: the next tile's are read while this tile's are still in use
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     // MFMAs: measured 1.17 us per K-tile without any DMA, against 0.64 of MFMA time), and the DMA of one unit sits after
     // MFMA number `dma_pos`.  Every step is pinned: the destination registers are not used before the next phase, so the
     // pinning costs no wait.
-    auto phase = [&](i32x4 (&c)[MTH][NTH], const i32x4 (&a)[MTH][2], const i32x4 (&b)[NTH][2], auto& rdst, auto rtiles,
+    auto phase = [&](acc_t (&c)[MTH][NTH], const i32x4 (&a)[MTH][2], const i32x4 (&b)[NTH][2], auto& rdst, auto rtiles,
                      const char* runit, const int (&roff)[2], bool do_read, int dma_pos, int kind, int t_dma, bool do_dma) {
         constexpr int RT = decltype(rtiles)::value, NR = RT * 2;
         if (PRIO)
@@ -293,6 +303,9 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                     {
                         asm volatile("" ::"v"(b[n][ks]), "v"(a[m][ks]));
                     }
+                    else if constexpr (F16)
+                        c[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, b[n][ks]),
+                            __builtin_bit_cast(f16x8, a[m][ks]), c[m][n], 0, 0, 0);
                     else
                         c[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b[n][ks], a[m][ks], c[m][n], 0, 0, 0);
                     if (r < NR && q == (RSP ? r * RSP : (r * QM) / NR))
@@ -385,6 +398,21 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     auto col_scales = [&](int cl) -> float4 {
         if constexpr (SCL)
             return *reinterpret_cast<const float4*>(sc_l + cl);
+        else if constexpr (F16)
+        {
+            // fp16: no scale at all, or - the weight-only expand path - an fp16 factor per output channel
+            const uint16_t* g = reinterpret_cast<const uint16_t*>(p.scale_col);
+            if (!g)
+                return make_float4(1.f, 1.f, 1.f, 1.f);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+            {
+                const int col = n0 + cl + r;
+                v[r] = h2f(g[col < N ? col : N - 1]);
+            }
+            return make_float4(v[0], v[1], v[2], v[3]);
+        }
         else
         {
             const float* g = reinterpret_cast<const float*>(p.scale_col);
@@ -403,6 +431,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     auto row_scale = [&](int rl) -> float {
         if constexpr (SCL)
             return sr_l[rl];
+        else if constexpr (F16)
+            return 1.f;
         else
         {
             const int row = m0 + rl;
@@ -506,7 +536,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                     {
                         const int rl = i * AH + (wr * MTH + m) * 16 + (lane & 15);
                         const float sr = row_scale(rl);
-                        const i32x4 a = acc[i][j][m][n];
+                        const acc_t a = acc[i][j][m][n];
                         const uint32_t lo = (uint32_t) f2h((float) a[0] * (sc.x * sr)) | ((uint32_t) f2h((float) a[1] * (sc.y * sr)) << 16);
                         const uint32_t hi = (uint32_t) f2h((float) a[2] * (sc.z * sr)) | ((uint32_t) f2h((float) a[3] * (sc.w * sr)) << 16);
                         *reinterpret_cast<uint2*>(ot + rl * PITCH + cl * 2) = make_uint2(lo, hi);
@@ -565,19 +595,18 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                     const float sr = row_scale(rl);
                     const float4 sc4 = col_scales(cl);
                     const float scv[4] = {sc4.x, sc4.y, sc4.z, sc4.w};
-                    const i32x4 a = acc[i][j][m][n];
+                    const acc_t a = acc[i][j][m][n];
                     const int64_t o = (int64_t) row * p.ldc + col;
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                     {
                         if (col + r >= N)
                             continue;
-                        if (p.out_dtype == DT_INT32)
-                            reinterpret_cast<int32_t*>(p.c)[o + r] = a[r];
-                        else
                         {
                             const float v = (float) a[r] * (scv[r] * sr);
-                            if (p.out_dtype == DT_FLOAT)
+                            if (p.out_dtype == DT_INT32)
+                                reinterpret_cast<int32_t*>(p.c)[o + r] = f2i32_rni_sat(v);
+                            else if (p.out_dtype == DT_FLOAT)
                                 reinterpret_cast<float*>(p.c)[o + r] = v;
                             else
                             {
@@ -592,13 +621,14 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         }
 }
 
-template <int WR, int WC, int MTH, int NTH, int DP0, int DP1, bool PRIO, int ABL = 0, int RSP = 0, bool DUAL = false, bool SCL = true>
+template <int WR, int WC, int MTH, int NTH, int DP0, int DP1, bool PRIO, int ABL = 0, int RSP = 0, bool DUAL = false, bool SCL = true,
+    bool F16 = false>
 int launch_sqp(const GemmParams& p, hipStream_t stream)
 {
     constexpr int BM = 2 * WR * MTH * 16, BN = 2 * WC * NTH * 16;
     constexpr size_t smem = (size_t) 2 * (BM + BN) * 128 + (SCL ? (BM + BN) * 4 : 0); // operand buffers + the tile's scales
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP, DUAL, SCL>;
+    auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP, DUAL, SCL, F16>;
     static std::atomic<bool> attr_done{false};
     if (!attr_done)
     {
@@ -666,6 +696,30 @@ int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
     case 31: return launch_sqp<4, 2, 2, 3, 0, 6, false, 32>(p, stream); // everything, without the barriers
     case 32: return launch_sqp<4, 2, 2, 3, 0, 6, false, 64>(p, stream); // everything, without the DMA waits
     case 33: return launch_sqp<4, 2, 2, 3, 0, 6, false, 32 + 5>(p, stream); // MFMA only, no barriers
+    default: return 1;
+    }
+}
+
+// fp16 operands on the phased pipeline (ids 50..): returns 1 when this kernel does not serve the problem
+int launch_gemm_f16p(const GemmParams& pin, int cfg, hipStream_t stream)
+{
+    GemmParams p = pin;
+    p.clock_probe = gemm_clock_probe;
+    if (p.wtype != W_FP16 || p.out_dtype == DT_INT32)
+        return 1;
+    if ((reinterpret_cast<uintptr_t>(p.a) & 15) || ((p.lda * 2) & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) || (p.ldw & 15)
+        || ((p.K * 2) % 128) || p.K <= 0 || p.M < 32)
+        return 1;
+    if ((int64_t) p.M * p.lda * 2 >= (1ll << 31) || (int64_t) p.N * p.ldw >= (1ll << 31))
+        return 1; // 32-bit DMA offsets
+    if (p.residual && p.out_dtype != DT_HALF)
+        return 1;
+    switch (cfg)
+    {
+    case 50: return launch_sqp<4, 2, 2, 3, 0, 6, false, 16, 0, false, false, true>(p, stream); // 256 x 192, non-temporal stores
+    case 51: return launch_sqp<4, 2, 1, 2, 1, 3, true, 0, 0, false, false, true>(p, stream);  // 128 x 128 on 8 waves
+    case 52: return launch_sqp<2, 2, 2, 2, 1, 5, true, 0, 0, false, false, true>(p, stream);  // 128 x 128 on 4 waves, 2 per CU
+    case 53: return launch_sqp<4, 2, 2, 3, 2, 8, true, 0, 0, false, false, true>(p, stream);  // 256 x 192 with setprio
     default: return 1;
     }
 }

@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
             else if (p.out_dtype == DT_FLOAT)
                 reinterpret_cast<float*>(p.y)[oidx] = r0;
             else
-                reinterpret_cast<int32_t*>(p.y)[oidx] = SQ ? ai : (int32_t) r0;
+                reinterpret_cast<int32_t*>(p.y)[oidx] = f2i32_rni_sat(r0);
         }
     };
 

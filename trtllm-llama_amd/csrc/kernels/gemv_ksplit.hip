@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void gemv_ksplit_kernel(const GemvParams p, in
         else if (p.out_dtype == DT_FLOAT)
             reinterpret_cast<float*>(p.y)[n] = r0;
         else
-            reinterpret_cast<int32_t*>(p.y)[n] = (int32_t) tot;
+            reinterpret_cast<int32_t*>(p.y)[n] = f2i32_rni_sat(r0);
     }
 }
 

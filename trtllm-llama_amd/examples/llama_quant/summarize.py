@@ -176,8 +176,8 @@ def main(args):
         profiler.start('load HF model')
         model = AutoModelForCausalLM.from_pretrained(args.hf_model_location)
         profiler.stop('load HF model')
-        if args.data_type == 'fp16':
-            model.half()
+        # explicit either way: newer transformers load a checkpoint in the dtype it was saved in
+        model = model.half() if args.data_type == 'fp16' else model.float()
         model.to('cuda' if torch.cuda.is_available() else 'cpu').eval()
         vocab = vocab or model.config.vocab_size
 
@@ -191,8 +191,15 @@ def main(args):
             references.append(dataset[i]['highlights'])
     elif args.prompts_npy:
         arr = np.load(args.prompts_npy)
-        prompts = [np.asarray(r, np.int32)[:test_token_num] for r in arr][:args.max_ite * args.batch_size]
+        n = args.max_ite * args.batch_size
+        if args.prompt_lengths_npy:  # ragged prompts in a padded [n, Lmax] array
+            plens = np.load(args.prompt_lengths_npy)
+            prompts = [np.asarray(r, np.int32)[:int(l)][:test_token_num] for r, l in zip(arr, plens)][:n]
+        else:
+            prompts = [np.asarray(r, np.int32)[:test_token_num] for r in arr][:n]
         references = [None] * len(prompts)
+        if args.references_npy:  # the dataset's `highlights`, as token ids [n, L]: the texts are the token-id strings
+            references = [ids_to_text(r) for r in np.load(args.references_npy)][:n]
     else:
         rng = np.random.default_rng(1)
         n = args.max_ite * args.batch_size
@@ -286,6 +293,9 @@ def main(args):
         if args.check_accuracy:
             key = 'tensorrt_llm' if 'tensorrt_llm' in result else 'tensorrt_llm_vs_hf'
             assert result[key]['rouge1'] > args.tensorrt_llm_rouge1_threshold, result
+            # the team's acceptance criterion, "ROUGE difference within about 1" (README.md:921), when HF ran beside the engine
+            if args.rougeL_delta_threshold is not None and 'rougeL_delta_vs_hf' in result:
+                assert abs(result['rougeL_delta_vs_hf']) <= args.rougeL_delta_threshold, result
         if args.output_json:
             with open(args.output_json, 'w') as f:
                 json.dump(result, f, indent=1)
@@ -310,6 +320,11 @@ def parse_arguments(argv=None):
     parser.add_argument('--top_k', type=int, default=1)
     # additions for boxes without the dataset / tokenizer
     parser.add_argument('--prompts_npy', type=str, default=None, help='int token-id prompts [n, L] instead of cnn_dailymail')
+    parser.add_argument('--prompt_lengths_npy', type=str, default=None, help='int lengths [n] of the (padded) --prompts_npy rows')
+    parser.add_argument('--references_npy', type=str, default=None,
+                        help='reference continuations [n, L] (token ids) for --prompts_npy: ROUGE of the engine and of HF against them')
+    parser.add_argument('--rougeL_delta_threshold', type=float, default=None,
+                        help='with --check_accuracy: |rougeL(engine) - rougeL(HF)| against the references must not exceed this')
     parser.add_argument('--synthetic', action='store_true', help='seeded random token prompts')
     parser.add_argument('--synthetic_len', type=int, default=64)
     parser.add_argument('--output_len', type=int, default=100)
