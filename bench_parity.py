@@ -126,9 +126,15 @@ INT8_KV = 32
 # ------------------------------------------------------------------------------------------------------------------
 class FakeQuantSQ:
 
-    def __init__(self, torch, tensors, layers, heads=32, eps=1e-6, reduce_dtype=None):
+    def __init__(self, torch, tensors, layers, heads=32, eps=1e-6, reduce_dtype=None, as_built=False):
         self.t, self.torch, self.L, self.H, self.eps = tensors, torch, layers, heads, eps
         self.rd = reduce_dtype or torch.float64
+        # as_built: the two places where the HIP attention rounds LATER than the reference ("Where the HIP
+        # kernels round later than the reference, on purpose"): cached K / V are used as exact integers times the scale (the
+        # reference rounds every dequantised element to fp16 first, MM/...Utils.h:2358-2365), and the probabilities are rounded to
+        # fp16 UN-normalised, the division by the row sum coming once at the end (the reference rounds p / sum).  With the flag
+        # the restatement takes the engine's rounding points, so engine-vs-restatement measures summation order only.
+        self.as_built = as_built
 
     def f16(self, x):
         return x.half().float()
@@ -165,8 +171,10 @@ class FakeQuantSQ:
         pos = torch.arange(T, device=qkv.device)
         q, k = self.rope(q, pos), self.rope(k, pos)
         # what a generation step reads back from the int8 cache
-        k8 = self.f16((k * kv_oq).round().clamp_(-128, 127) * kv_qo)
-        v8 = self.f16((v * kv_oq).round().clamp_(-128, 127) * kv_qo)
+        k8 = (k * kv_oq).round().clamp_(-128, 127) * kv_qo
+        v8 = (v * kv_oq).round().clamp_(-128, 127) * kv_qo
+        if not self.as_built:
+            k8, v8 = self.f16(k8), self.f16(v8)
         inv = 1.0 / (Dh ** 0.5)
         qh, kh, vh, k8h, v8h = (z.permute(1, 0, 2).to(self.rd) for z in (q, k, v, k8, v8))  # [H, T, Dh]
         s_f = (qh @ kh.transpose(1, 2)).float() * inv    # fp16 keys
@@ -180,12 +188,18 @@ class FakeQuantSQ:
         mx = sc.max(-1, keepdim=True).values
         e = (sc - mx).exp()
         ssum = e.to(self.rd).sum(-1, keepdim=True).float()
-        p_ctx = self.f16(e / ssum)
-        p_gen = self.f16(e * (1.0 / (ssum + 1e-6)))
-        p = torch.where(gen[None], p_gen, p_ctx).to(self.rd)
+        if self.as_built:
+            p = self.f16(e).to(self.rd)  # rounded relative to the row maximum; normalised once, behind the P V sum
+            norm = torch.where(gen[None], 1.0 / (ssum + 1e-6), 1.0 / ssum)
+        else:
+            p_ctx = self.f16(e / ssum)
+            p_gen = self.f16(e * (1.0 / (ssum + 1e-6)))
+            p = torch.where(gen[None], p_gen, p_ctx).to(self.rd)
+            norm = None
         p_cache = torch.where(use_q[None], p, torch.zeros_like(p))
         p_own = p - p_cache
-        out = self.f16((p_cache @ v8h + p_own @ vh).float())  # [H, T, Dh]
+        acc = (p_cache @ v8h + p_own @ vh).float()
+        out = self.f16(acc * norm if norm is not None else acc)  # [H, T, Dh]
         return out.permute(1, 0, 2).reshape(T, H * Dh)
 
     def forward(self, ids, P, taps=None, first_row=0):
@@ -370,6 +384,12 @@ def run(torch, dev, layers=32, prompt_len=128, new_tokens=128, n_prompts=8, cpu_
         fq_logits = teacher_forced(lambda full: fq.forward(full, P, first_row=P - 1), gpu['sq']['tokens'])
         fq32 = FakeQuantSQ(torch, sq_tensors, layers, reduce_dtype=torch.float32)
         fq32_logits = teacher_forced(lambda full: fq32.forward(full, P, first_row=P - 1), gpu['sq']['tokens'])
+        # the restatement with the ENGINE's rounding points in the attention (as_built): what is left between it and the engine
+        # is summation order - to be compared with the control
+        fqb = FakeQuantSQ(torch, sq_tensors, layers, as_built=True)
+        fqb_logits = teacher_forced(lambda full: fqb.forward(full, P, first_row=P - 1), gpu['sq']['tokens'])
+        e_built = np.abs(gpu['sq']['logits'] - fqb_logits)
+        e_points = np.abs(fqb_logits - fq_logits)
         e_kernel = np.abs(gpu['sq']['logits'] - fq_logits)
         e_algo = np.abs(fq_logits - tf_ref['sq'])
         e_ctrl = np.abs(fq32_logits - fq_logits)
@@ -386,6 +406,12 @@ def run(torch, dev, layers=32, prompt_len=128, new_tokens=128, n_prompts=8, cpu_
             # the control: two restatements of the SAME algorithm on the same integers, fp64 vs fp32 reductions
             'control_algorithm_fp64_vs_fp32_reductions_max_abs_logit_err': _err_stats(np, e_ctrl, steps),
             'control_algorithm_fp64_vs_fp32_reductions_mean_abs_logit_err': float(e_ctrl.mean()),
+            # r04: the same with the engine's two later rounding points (int8 KV used as scaled integers, un-normalised fp16
+            # probabilities) in the restatement; and how far those two rounding points alone move the restatement
+            'engine_vs_algorithm_as_built_max_abs_logit_err': _err_stats(np, e_built, steps),
+            'engine_vs_algorithm_as_built_mean_abs_logit_err': float(e_built.mean()),
+            'algorithm_reference_rounding_vs_as_built_max_abs_logit_err': float(e_points.max()),
+            'algorithm_reference_rounding_vs_as_built_mean_abs_logit_err': float(e_points.mean()),
             'engine_vs_algorithm_fp32_reductions_max_abs_logit_err': float(e_kernel32.max()),
             'engine_vs_algorithm_fp32_reductions_mean_abs_logit_err': float(e_kernel32.mean()),
             'argmax_agreement_engine_vs_algorithm': float((gpu['sq']['logits'].argmax(-1) == fq_logits.argmax(-1)).mean()),

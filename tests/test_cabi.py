@@ -130,3 +130,20 @@ def test_session_configuration_errors_are_reported_not_fatal():
     assert lib.tllm_session_finalize(h) != 0 and 'vocab_embedding' in capi.last_error()  # first missing tensor is named
     lib.tllm_session_destroy.argtypes = [ctypes.c_void_p]
     lib.tllm_session_destroy(h)
+
+
+def test_p2p_transport_state_entries_without_a_gpu():
+    """The transport's switches are plain host state (ADVICE r03: verdicts live in comm::p2p, not in environment variables):
+    enabling a transport nobody attached is refused with a message, the fused-seam verdict toggles, the state word reports both."""
+    lib = capi.load_library()
+    lib.tllm_comm_p2p_enable.argtypes = [ctypes.c_int32]
+    lib.tllm_comm_p2p_enable.restype = ctypes.c_int32
+    lib.tllm_comm_p2p_enable_fused.argtypes = [ctypes.c_int32]
+    lib.tllm_comm_p2p_enable_fused.restype = None
+    lib.tllm_comm_p2p_state.restype = ctypes.c_int32
+    assert lib.tllm_comm_p2p_state() == 0
+    assert lib.tllm_comm_p2p_enable(1) != 0      # not attached: refused
+    assert lib.tllm_comm_p2p_enable(0) == 0      # switching off always works
+    lib.tllm_comm_p2p_enable_fused(0)
+    lib.tllm_comm_p2p_enable_fused(1)
+    assert lib.tllm_comm_p2p_state() == 0        # bit 2 only together with "enabled"

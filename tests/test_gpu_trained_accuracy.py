@@ -7,7 +7,7 @@ of the engine's and of HF's summaries against the highlights.  Here: the product
 
     hf_llama_convert.py -> build.py <flags> -> summarize.py --test_hf --test_trt_llm --check_accuracy --rougeL_delta_threshold 1
 
-on 24 prompts (ragged, 90 - 156 tokens) x 100 new tokens of the synthetic language the parent was trained on; the language's own
+on 24 prompts (ragged, 64 - 139 tokens) x 100 new tokens of the synthetic language the parent was trained on; the language's own
 most likely continuation plays the part of the `highlights`.  A random-weight parent cannot decide this: its
 top-1 / top-2 margins are below the int8 noise.  This parent's margins: tests/golden/trained_llama/TRAINLOG.json.
 
@@ -54,7 +54,7 @@ def test_fixture_is_a_decidable_parent():
     assert info['margin']['median'] > 2.0 and info['margin']['frac_below_0p2'] < 0.02, info['margin']
     assert info['distinct_tokens_per_continuation'] > 40
     lg = e['hf_logits'].astype(np.float32)
-    np.testing.assert_array_equal(lg.argmax(-1), e['hf_tokens'])
+    np.testing.assert_array_equal(lg.argmax(-1), e['hf_tokens'][:lg.shape[0]])  # logits are kept for the first 8 prompts
 
 
 @pytest.fixture(scope='module')
@@ -82,7 +82,7 @@ def build(base, ft, name, flags):
     eng = base / f'eng_{name}'
     if not (eng / 'config.json').exists():
         subprocess.run([sys.executable, os.path.join(EX, 'build.py'), '--model_dir', ft, '--output_dir', str(eng),
-                        '--max_batch_size', '4', '--max_input_len', '160', '--max_output_len', str(NEW), '--log_level', 'error']
+                        '--max_batch_size', '4', '--max_input_len', '256', '--max_output_len', str(NEW), '--log_level', 'error']
                        + flags, check=True, cwd=EX, timeout=900)
     return eng
 
@@ -125,7 +125,7 @@ def test_teacher_forced_logits_within_the_reference_tolerance(ft_dirs, name):
     sess = GenerationSession(ModelConfig(vocab_size=cfg['vocab_size'], num_layers=cfg['num_hidden_layers'],
                                          num_heads=cfg['num_attention_heads'], hidden_size=cfg['hidden_size']), blob, Mapping(1, 0))
     B = 4
-    n = e['prompts'].shape[0] // B * B
+    n = e['hf_logits'].shape[0] // B * B  # the prompts whose per-step HF logits the fixture holds
     worst, sum_err, cnt, agree, confident, conf_agree = 0.0, 0.0, 0, 0, 0, 0
     for i0 in range(0, n, B):
         lens = e['lengths'][i0:i0 + B].astype(np.int32)
