@@ -561,6 +561,8 @@ int launch_dh(const MmhaParams& p, hipStream_t stream)
         return launch_nit<DH, 16>(p, stream);
     if (p.rows_per_group == 12)
         return launch_nit<DH, 12>(p, stream);
+    if (p.rows_per_group == 9)
+        return launch_nit<DH, 9>(p, stream);
     return launch_nit<DH, 4>(p, stream);
 }
 
@@ -584,7 +586,7 @@ int mmha_split_layout(int32_t head_size, int32_t max_seq_len, int32_t rows_per_g
     const int lpr = head_size / 8;
     if (lpr <= 0 || 64 % lpr)
         return -1;
-    const int nit = rows_per_group == 16 ? 16 : (rows_per_group == 12 ? 12 : 4);
+    const int nit = rows_per_group == 16 ? 16 : (rows_per_group == 12 ? 12 : (rows_per_group == 9 ? 9 : 4));
     const int tc = kWaves * (64 / lpr) * nit;
     const int ns = (max_seq_len + tc - 1) / tc;
     if (tchunk)

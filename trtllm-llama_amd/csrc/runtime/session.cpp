@@ -1504,6 +1504,11 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
             // 1024-token bench context), attention -0.85 us, the merge in the O-projection +0.65 us per layer
             if (mmha_split_layout(s->Dh, Smax, 12, B, s->Hr, &tc, &ns, &off) == 0 && ns <= 8)
                 s->attn_nit = 12;
+            // experiment switch (r04): TLLM_ATTN_ROWS=9 -> 144-token splits = 8 x 32 = 256 workgroups at the
+            // 1024-token bench context, all CUs busy; the merge then takes 8 slots
+            const char* rows_env = getenv("TLLM_ATTN_ROWS");
+            if (rows_env && atoi(rows_env) == 9 && mmha_split_layout(s->Dh, Smax, 9, B, s->Hr, &tc, &ns, &off) == 0 && ns <= 8)
+                s->attn_nit = 9;
         }
         if (mmha_split_layout(s->Dh, Smax, s->attn_nit, B, s->Hr, &tc, &ns, &off))
         {

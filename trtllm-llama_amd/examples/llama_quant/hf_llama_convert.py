@@ -36,6 +36,7 @@ class ProgArgs:
     processes: int = 2
     calibrate_kv_cache: bool = False
     smoothquant: float = None
+    smoothquant_down: float = None
     model: str = 'llama'
     storage_type: str = 'float16'
     dataset_cache_dir: str = None
@@ -55,6 +56,10 @@ class ProgArgs:
         p.add_argument('--smoothquant', '-sq', type=float, default=None,
                        help='Set the alpha parameter (see https://arxiv.org/pdf/2211.10438.pdf) to Smoothquant the model, '
                        'and output int8 weights. A good first try is 0.5. Must be in [0, 1]')
+        p.add_argument('--smoothquant-down', '-sqd', type=float, default=None,
+                       help='migration strength of the down_proj input alone (default: the -sq value).  The SwiGLU product in front of '
+                       'down_proj is the heavy-tailed activation of a LLaMA layer; on the trained test parent 1.0 halves the mean '
+                       'logit error of the static engine (tools/sq_trained_sweep.py).  Not a reference flag.')
         p.add_argument('--model', default='llama', type=str)
         p.add_argument('--storage-type', '-t', type=str, default='float16', choices=['float32', 'float16'])
         p.add_argument('--dataset-cache-dir', type=str, default=None, help='cache dir to load the hugging face dataset (lambada)')
@@ -85,8 +90,10 @@ def calibration_samples(args: ProgArgs, vocab_size: int):
 
 
 @torch.no_grad()
-def smooth_llama_model(sd, act_range, alpha, num_layers, num_heads, num_kv_heads):
-    """Apply SmoothQuant to the float32 state dict `sd` in place and keep `act_range` consistent with it."""
+def smooth_llama_model(sd, act_range, alpha, num_layers, num_heads, num_kv_heads, alpha_down=None):
+    """Apply SmoothQuant to the float32 state dict `sd` in place and keep `act_range` consistent with it.
+    `alpha_down`: migration strength of the down_proj input alone (None = alpha), see --smoothquant-down."""
+    alpha_down = alpha if alpha_down is None else alpha_down
     assert num_kv_heads == num_heads, 'folding the o_proj smoother into v_proj needs one V head per Q head'
     for l in range(num_layers):
         p = f'model.layers.{l}.'
@@ -106,7 +113,7 @@ def smooth_llama_model(sd, act_range, alpha, num_layers, num_heads, num_kv_heads
         act_range[p + 'self_attn.o_proj']['x'] = act_range[p + 'self_attn.o_proj']['x'] / s.float()
         act_range[p + 'self_attn.v_proj']['y'] = act_range[p + 'self_attn.v_proj']['y'] / s.float()
         # down_proj input = silu(gate) * up, linear in up: channel j <- row j of up_proj
-        s = smooth_gemm([down], act_range[p + 'mlp.down_proj']['x'], None, None, alpha)
+        s = smooth_gemm([down], act_range[p + 'mlp.down_proj']['x'], None, None, alpha_down)
         up.div_(s.to(up.dtype).view(-1, 1))
         act_range[p + 'mlp.down_proj']['x'] = act_range[p + 'mlp.down_proj']['x'] / s.float()
         act_range[p + 'mlp.up_proj']['y'] = act_range[p + 'mlp.up_proj']['y'] / s.float()
@@ -142,7 +149,7 @@ def hf_llama_converter(args: ProgArgs):
 
     sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
     if args.smoothquant is not None:
-        smooth_llama_model(sd, act_range, args.smoothquant, num_layers, num_heads, num_kv_heads)
+        smooth_llama_model(sd, act_range, args.smoothquant, num_layers, num_heads, num_kv_heads, alpha_down=args.smoothquant_down)
 
     config = configparser.ConfigParser()
     config['llama'] = {}

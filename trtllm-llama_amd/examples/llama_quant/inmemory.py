@@ -24,7 +24,7 @@ def _f32(x, dev):
 
 @torch.no_grad()
 def engine_tensors(sd, num_layers, mode='fp16', act_range=None, alpha=0.5, per_channel=True, per_token=False,
-                   int8_kv=False, num_heads=None, threads=16):
+                   int8_kv=False, num_heads=None, threads=16, alpha_down=None):
     """sd: HF-named state dict (torch tensors, one device).  mode: 'fp16' | 'woq8' | 'woq4' | 'sq'.
     `act_range` (capture_activation_range of the UN-smoothed model) is needed for 'sq' and for int8_kv; with 'sq' the
     state dict is smoothed on a float32 copy first.  Returns {engine tensor name: torch tensor}."""
@@ -36,7 +36,7 @@ def engine_tensors(sd, num_layers, mode='fp16', act_range=None, alpha=0.5, per_c
         assert act_range is not None and num_heads is not None
         act_range = {k: {kk: vv.clone() for kk, vv in v.items()} for k, v in act_range.items()}
         sd = {k: (v.detach().float().clone() if '.layers.' in k else v) for k, v in sd.items()}
-        smooth_llama_model(sd, act_range, alpha, num_layers, num_heads, num_heads)
+        smooth_llama_model(sd, act_range, alpha, num_layers, num_heads, num_heads, alpha_down=alpha_down)
     woq_jobs = []
     for i in range(num_layers):
         hp, p = f'model.layers.{i}.', f'layers.{i}.'
