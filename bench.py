@@ -531,7 +531,7 @@ def main():
     # PMC counters cannot be read from inside the timed run: `traffic` is the committed rocprofv3 measurement of this same
     # kernel / shape (tools/refresh_pmc.sh -> profiles/*_pmc_summary.json), named in `traffic_source` - not this run's
     traffic = traffic_source = None
-    for rnd in ('r03', 'r02', 'r01'):
+    for rnd in ('r04', 'r03', 'r02', 'r01'):
         pmc = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_summary.json')
         if os.path.exists(pmc):
             try:

@@ -93,3 +93,37 @@ def test_full_size_paged_cache_equals_linear(beam):
         outs.append(s.generate(ids, lens, NEW))
         s.close()
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize('mode', ['sq', 'fp16'])
+def test_in_launch_attention_merge_equals_the_prologue_merge(mode, monkeypatch):
+    """TLLM_ATTN_TAIL_MERGE=1 (r04 experiment, mmha_decode.hip step 6): the last split of a head to arrive merges the partials inside
+    the attention launch - write-through partials, one ticket per workgroup, agent-scope loads - instead of every O-projection
+    workgroup merging them in its prologue.  Same slot order, same fp32 arithmetic: tokens and logits must be IDENTICAL, eager and
+    replayed from the graph, over contexts that use 1 ... 7 splits (a stale or torn partial would show up as a wrong logit)."""
+    cfg = dict(bench.LLAMA_7B, num_layers=4)
+    int8_kv = mode != 'fp16'
+    dev = torch.device('cuda', 0)
+    w = bench.synth_weights(torch, cfg, mode, int8_kv, 1, 0, dev)
+    r = np.random.default_rng(23)
+    results = {}
+    for tail in (False, True):
+        if tail:
+            monkeypatch.setenv('TLLM_ATTN_TAIL_MERGE', '1')
+        else:
+            monkeypatch.delenv('TLLM_ATTN_TAIL_MERGE', raising=False)
+        s = NativeSession(dict(cfg, quant_mode=bench.QM[mode] | (bench.INT8_KV if int8_kv else 0), tp_size=1, tp_rank=0))
+        for k, v in w.items():
+            s.set_tensor(k, v)
+        s.finalize()
+        outs = []
+        for S, NEW in ((40, 12), (700, 24), (1100, 40)):
+            ids = np.random.default_rng(S).integers(3, cfg['vocab_size'], (1, S)).astype(np.int32)
+            s.setup(1, S, NEW)
+            toks = s.generate(ids, np.array([S], np.int32), NEW)  # first step eager, the rest from the graph
+            outs.append((toks.copy(), s.logits().copy()))
+        results[tail] = outs
+        s.close()
+    for (t0, l0), (t1, l1) in zip(results[False], results[True]):
+        np.testing.assert_array_equal(t0, t1)
+        np.testing.assert_array_equal(l0, l1)

@@ -204,8 +204,8 @@ def test_gpt_attention_smoothquant(per_token, per_channel, rot):
         # moves a probability by 10 %; per-token activation scales (up to 9x larger rows) make such ties 6x more frequent
         d = np.abs(as_f32(ctx) - g_ctx.numpy())
         tol = (5e-3 if step == 0 else 2e-3) + 2e-3 * np.abs(g_ctx.numpy())
-        frac = float(np.mean(d > tol))
-        assert frac < (5e-4 if per_token else 3e-5) and d.max() < 0.25, (step, frac, float(d.max()))
+        bad = int(np.sum(d > tol))  # (a generation step has only 4096 outputs: the allowance is a count there, not a fraction)
+        assert bad <= max(8 if per_token else 2, (5e-4 if per_token else 3e-5) * d.size) and d.max() < 0.25, (step, bad, float(d.max()))
         # (2) everything behind the attention is a LOCAL map of its output - quantiser and dense GEMM: bit-exact on the product's
         # own attention output
         np.testing.assert_array_equal(got, tail(ctx.cpu().float(), kernel_arithmetic=True))

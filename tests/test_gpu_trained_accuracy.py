@@ -213,3 +213,31 @@ def test_teacher_forced_logits_within_the_reference_tolerance(ft_dirs, name):
               f'{d_mean:.5f}')
         assert abs(sum_err / cnt - a_mean) <= 0.1 * a_mean and abs(worst - a_worst) <= 0.25 * a_worst
         assert d_mean <= 0.5 * a_mean
+
+
+@pytest.mark.gpu
+def test_the_criterion_fails_for_a_miscalibrated_engine(ft_dirs, tmp_path):
+    """Negative control: the same flow with the int8 KV-cache scale of every layer 24 x too small (keys and values saturate at +-127)
+    must NOT pass - the criterion on this parent is decidable in both directions, not vacuous."""
+    import shutil
+    base, ft = ft_dirs
+    bad = tmp_path / 'ft_bad'
+    shutil.copytree(ft[False], bad)
+    for f in sorted(bad.glob('*attention.query_key_value.scale_y_quant_orig.bin')):
+        (np.fromfile(f, np.float32) / 24.0).astype(np.float32).tofile(f)
+    eng = tmp_path / 'eng_bad'
+    subprocess.run([sys.executable, os.path.join(EX, 'build.py'), '--model_dir', str(bad), '--output_dir', str(eng), '--max_batch_size', '4',
+                    '--max_input_len', '256', '--max_output_len', str(NEW), '--log_level', 'error', '--int8_kv_cache'], check=True, cwd=EX,
+                   timeout=900)
+    out = tmp_path / 'rouge_bad.json'
+    r = subprocess.run([sys.executable, os.path.join(EX, 'summarize.py'), '--hf_model_location', FIX, '--test_hf', '--test_trt_llm',
+                        '--data_type', 'fp32', '--engine_dir', str(eng), '--prompts_npy', str(base / 'prompts.npy'),
+                        '--prompt_lengths_npy', str(base / 'lengths.npy'), '--references_npy', str(base / 'reference.npy'),
+                        '--output_len', str(NEW), '--batch_size', '4', '--max_ite', '6', '--log_level', 'error',
+                        '--check_accuracy', '--tensorrt_llm_rouge1_threshold', '15', '--rougeL_delta_threshold', '1.0',
+                        '--output_json', str(out)], cwd=EX, timeout=1800, capture_output=True, text=True)
+    res = json.load(open(out)) if out.exists() else None
+    print(f'[trained parent, int8 KV scale / 24] rc {r.returncode}, '
+          + (f'ROUGE-L delta {res["rougeL_delta_vs_hf"]:+.2f}, token match {res["token_match_rate"]:.3f}' if res else 'no result'))
+    assert r.returncode != 0  # --check_accuracy --rougeL_delta_threshold 1 rejects it
+    assert res is None or abs(res['rougeL_delta_vs_hf']) > 1.0

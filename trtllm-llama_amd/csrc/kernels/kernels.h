@@ -171,6 +171,13 @@ struct MmhaParams
     int32_t tokens_per_block = 0, max_blocks_per_seq = 0;
     int32_t skip_combine = 0;        // 1: leave the split partials in the workspace (the consumer merges them:
                                      // GemvParams::attn_*), no combine launch
+    // r04 experiment ("merge once, not per consumer workgroup"): when set (uint32 [B * H], zero before the
+    // first launch, self-resetting), the LAST split of a (sequence, head) to arrive merges all partials inside this launch and
+    // writes the normalised context to `out` (and, with tail_quant_scale, its static int8 image to tail_out_q8) - the
+    // O-projection then starts from a plain 8 KB / 4 KB vector instead of merging ns x 16 KB in each of its ~500 workgroups.
+    uint32_t* tail_tickets = nullptr;
+    const float* tail_quant_scale = nullptr; // f32 [1]: SmoothQuant static activation scale of the O-projection's input
+    void* tail_out_q8 = nullptr;             // s8 [B, H*Dh]
     void* out = nullptr;       // fp16 [B, H*Dh]
     void* workspace = nullptr; // mmha_workspace_size bytes
 };

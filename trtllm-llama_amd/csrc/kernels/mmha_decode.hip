@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
         sm_w[tid] = (sm_m[tid] == -INFINITY) ? 0.f : __expf(sm_m[tid] - M);
     __syncthreads();
     const int64_t pi = ((int64_t) b * H + h) * nsplit_max + c;
+    const bool tail = p.tail_tickets != nullptr; // uniform
     for (int d = tid; d < DH; d += 256)
     {
         float L = 0.f, O = 0.f;
@@ -442,9 +443,70 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
             L += sm_l[g] * sm_w[g];
             O += sm_o[g][d] * sm_w[g];
         }
-        ws_o[pi * DH + d] = O;
-        if (d == 0)
-            ws_ml[pi] = make_float2(M, L);
+        if (tail)
+        {
+            // write-through (agent-scope) stores: the merging workgroup may sit on another XCD, whose L2 never sees this one's
+            __hip_atomic_store(ws_o + pi * DH + d, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == 0)
+            {
+                __hip_atomic_store(&ws_ml[pi].x, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ws_ml[pi].y, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        else
+        {
+            ws_o[pi * DH + d] = O;
+            if (d == 0)
+                ws_ml[pi] = make_float2(M, L);
+        }
+    }
+    if (!tail)
+        return;
+    // ---- 6. (tail merge) the partial is written through -> one ticket per workgroup -> the last arriver of the (sequence, head)
+    //         merges.  Protocol: write-through payload, drained (vmcnt(0), in asm: the compiler may drop its own wait), relaxed
+    //         agent-scope ticket; the consumer reads the payload with agent-scope (L1-bypassing) loads behind the ticket it took.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ uint32_t sm_ticket;
+    const int nact = min(tl / G::TCHUNK + 1, nsplit_max); // splits that run (the others returned above)
+    if (tid == 0)
+        sm_ticket = __hip_atomic_fetch_add(p.tail_tickets + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if ((int) sm_ticket != nact - 1)
+        return;
+    if (tid == 0) // re-arm for the next launch (ordered by the kernel boundary)
+        __hip_atomic_store(p.tail_tickets + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int64_t base = ((int64_t) b * H + h) * nsplit_max;
+    for (int d = tid; d < DH; d += 256)
+    {
+        // the arithmetic of the O-projection's merge prologue (gemv_impl.h PK_ATTN), slot order, fp32: bit-identical results
+        float ms[8], ls[8], os[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+        {
+            const int ic = i < nact ? i : 0;
+            ms[i] = __hip_atomic_load(&ws_ml[base + ic].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ls[i] = __hip_atomic_load(&ws_ml[base + ic].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            os[i] = __hip_atomic_load(ws_o + (base + ic) * DH + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        float Mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            Mx = i < nact ? fmaxf(Mx, ms[i]) : Mx;
+        float Lt = 0.f, Ot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+        {
+            const bool act = i < nact && ms[i] != -INFINITY;
+            const float e = act ? __expf(ms[i] - Mx) : 0.f;
+            Lt += act ? ls[i] * e : 0.f;
+            Ot += act ? os[i] * e : 0.f;
+        }
+        const uint16_t h16 = f2h(Ot * (1.f / (Lt + 1.e-6f)));
+        const int64_t o = ((int64_t) b * H + h) * DH + d;
+        reinterpret_cast<uint16_t*>(p.out)[o] = h16;
+        if (p.tail_out_q8)
+            reinterpret_cast<int8_t*>(p.tail_out_q8)[o] = f2i8_rni_sat(h2f(h16) * p.tail_quant_scale[0]);
     }
 }
 
@@ -515,6 +577,11 @@ int launch_nit(const MmhaParams& p, hipStream_t stream)
         set_error("mmha: max_seq_len %d needs more than 256 splits", p.max_seq_len);
         return -1;
     }
+    if (p.tail_tickets && (ns > 8 || (p.tail_out_q8 && !p.tail_quant_scale)))
+    {
+        set_error("mmha: the in-launch merge takes at most 8 splits (got %d) and a scale with its int8 output", ns);
+        return -1;
+    }
     char* ws = reinterpret_cast<char*>(p.workspace);
     float2* ws_ml = reinterpret_cast<float2*>(ws);
     const size_t ml_bytes = ((size_t) p.batch * p.num_heads * ns * sizeof(float2) + 255) / 256 * 256;
@@ -543,7 +610,7 @@ int launch_nit(const MmhaParams& p, hipStream_t stream)
             TLLM_MMHA_LAUNCH(false, CACHE_LINEAR);
     }
 #undef TLLM_MMHA_LAUNCH
-    if (!p.skip_combine)
+    if (!p.skip_combine && !p.tail_tickets)
         hipLaunchKernelGGL((mmha_combine_kernel<DH, NIT>), dim3(p.num_heads, p.batch), dim3(256), 0, stream, p, ws_ml, ws_o, ns);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)

@@ -208,6 +208,10 @@ struct tllm_session
     int attn_nit = 4, attn_tchunk = 0, attn_ns = 0;
     size_t attn_o_off = 0;
     bool attn_fused = false; // split-KV merge fused into the O-projection prologue
+    // r04 experiment (TLLM_ATTN_TAIL_MERGE=1): the last split of a head to arrive merges inside the attention launch (mmha_decode.hip)
+    bool attn_tail = false;
+    uint32_t* attn_tickets = nullptr;
+    void* ctx_q8 = nullptr;
     int end_id = -1;
     hipGraphExec_t graph = nullptr;
     hipStream_t graph_stream = nullptr;
@@ -929,6 +933,16 @@ struct tllm_session
             m.max_blocks_per_seq = max_blocks;
             m.rows_per_group = attn_nit;
             m.skip_combine = attn_fused ? 1 : 0;
+            const bool tail_q8 = attn_tail && sq && !per_token;
+            if (attn_tail)
+            {
+                m.tail_tickets = attn_tickets;
+                if (tail_q8)
+                {
+                    m.tail_out_q8 = ctx_q8;
+                    m.tail_quant_scale = L.attn_qscale;
+                }
+            }
             m.out = ctx;
             m.workspace = mmha_ws;
             if (ok < 0 || ok == 2)
@@ -944,9 +958,12 @@ struct tllm_session
                     else
                         tap_dst = tap_ptr(1, li);
                 }
+                // (tail merge + static SmoothQuant: the attention launch left the int8 operand itself - no prologue at all)
+                const void* o_in = tail_q8 ? ctx_q8 : ctx;
+                const int pro_o2 = tail_q8 ? (int) PRO_NONE : pro_o;
                 const int rc4 = fused_ar
-                    ? gemv(L.dense, B, pro_o, EPI_NONE, ctx, Dr, nullptr, L.attn_qscale, nullptr, nullptr, ar_partial, D, DT_HALF, nullptr, st)
-                    : gemv(L.dense, B, pro_o, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE, ctx, Dr, nullptr, L.attn_qscale, x, nullptr, x, D,
+                    ? gemv(L.dense, B, pro_o2, EPI_NONE, o_in, Dr, nullptr, L.attn_qscale, nullptr, nullptr, ar_partial, D, DT_HALF, nullptr, st)
+                    : gemv(L.dense, B, pro_o2, (tp == 1 || r0) ? EPI_RESIDUAL : EPI_NONE, o_in, Dr, nullptr, L.attn_qscale, x, nullptr, x, D,
                           DT_HALF, nullptr, st);
                 tap_dst = nullptr;
                 RUN(rc4);
@@ -1509,6 +1526,16 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
             const char* rows_env = getenv("TLLM_ATTN_ROWS");
             if (rows_env && atoi(rows_env) == 9 && mmha_split_layout(s->Dh, Smax, 9, B, s->Hr, &tc, &ns, &off) == 0 && ns <= 8)
                 s->attn_nit = 9;
+        }
+        s->attn_tail = false;
+        if (s->attn_fused && getenv("TLLM_ATTN_TAIL_MERGE"))
+        {
+            // same split geometry, but the merge moves from the O-projection's prologue into the tail of the attention launch
+            s->attn_fused = false;
+            s->attn_tail = true;
+            RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_tickets), (size_t) B * s->Hr * 4));
+            HIP_OK(hipMemset(s->attn_tickets, 0, (size_t) B * s->Hr * 4));
+            RUN(s->dalloc(&s->ctx_q8, (size_t) B * s->Dr));
         }
         if (mmha_split_layout(s->Dh, Smax, s->attn_nit, B, s->Hr, &tc, &ns, &off))
         {
