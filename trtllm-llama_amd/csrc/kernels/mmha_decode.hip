@@ -435,6 +435,7 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
     __syncthreads();
     const int64_t pi = ((int64_t) b * H + h) * nsplit_max + c;
     const bool tail = p.tail_tickets != nullptr; // uniform
+    __shared__ __attribute__((aligned(16))) float sm_out[DH];
     for (int d = tid; d < DH; d += 256)
     {
         float L = 0.f, O = 0.f;
@@ -445,13 +446,10 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
         }
         if (tail)
         {
-            // write-through (agent-scope) stores: the merging workgroup may sit on another XCD, whose L2 never sees this one's
-            __hip_atomic_store(ws_o + pi * DH + d, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == 0)
-            {
-                __hip_atomic_store(&ws_ml[pi].x, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ws_ml[pi].y, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            sm_out[d] = O;
+            if (d == 0) // (m, l) as ONE 8-byte write-through store
+                __hip_atomic_store(reinterpret_cast<uint64_t*>(ws_ml + pi),
+                    (uint64_t) __float_as_uint(M) | ((uint64_t) __float_as_uint(L) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         else
         {
@@ -462,6 +460,16 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
     }
     if (!tail)
         return;
+    // write-through (sc1) 16-byte stores of the partial: the merging workgroup may sit on another XCD, whose L2 never sees this
+    // one's; scalar write-through stores are one fabric write each (guide: dword ~6 x the dwordx4 time per byte)
+    __syncthreads();
+    if (tid < DH / 4)
+    {
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(&sm_out[tid * 4]);
+        float* dst = ws_o + pi * DH + tid * 4;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+    }
     // ---- 6. (tail merge) the partial is written through -> one ticket per workgroup -> the last arriver of the (sequence, head)
     //         merges.  Protocol: write-through payload, drained (vmcnt(0), in asm: the compiler may drop its own wait), relaxed
     //         agent-scope ticket; the consumer reads the payload with agent-scope (L1-bypassing) loads behind the ticket it took.
@@ -485,8 +493,9 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
         for (int i = 0; i < 8; ++i)
         {
             const int ic = i < nact ? i : 0;
-            ms[i] = __hip_atomic_load(&ws_ml[base + ic].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ls[i] = __hip_atomic_load(&ws_ml[base + ic].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t mlb = __hip_atomic_load(reinterpret_cast<const uint64_t*>(ws_ml + base + ic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ms[i] = __uint_as_float((uint32_t) mlb);
+            ls[i] = __uint_as_float((uint32_t) (mlb >> 32));
             os[i] = __hip_atomic_load(ws_o + (base + ic) * DH + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         float Mx = -INFINITY;

@@ -208,7 +208,8 @@ struct tllm_session
     int attn_nit = 4, attn_tchunk = 0, attn_ns = 0;
     size_t attn_o_off = 0;
     bool attn_fused = false; // split-KV merge fused into the O-projection prologue
-    // r04 experiment (TLLM_ATTN_TAIL_MERGE=1): the last split of a head to arrive merges inside the attention launch (mmha_decode.hip)
+    // r04: the last split of a head to arrive merges inside the attention launch (mmha_decode.hip step 6); TLLM_NO_ATTN_TAIL_MERGE=1
+    // brings the r01 - r03 path back (every O-projection workgroup merges all partials in its prologue)
     bool attn_tail = false;
     uint32_t* attn_tickets = nullptr;
     void* ctx_q8 = nullptr;
@@ -953,7 +954,9 @@ struct tllm_session
             {
                 if (taps)
                 {
-                    if (pro_o == PRO_NONE) // nothing is transformed in the prologue: the input itself is the tap
+                    if (tail_q8) // the attention launch left the quantised operand itself
+                        HIP_OK(hipMemcpyAsync(tap_ptr(1, li), ctx_q8, (size_t) B * Dr, hipMemcpyDeviceToDevice, st));
+                    else if (pro_o == PRO_NONE) // nothing is transformed in the prologue: the input itself is the tap
                         HIP_OK(hipMemcpyAsync(tap_ptr(1, li), ctx, (size_t) B * Dr * 2, hipMemcpyDeviceToDevice, st));
                     else
                         tap_dst = tap_ptr(1, li);
@@ -1528,7 +1531,7 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
                 s->attn_nit = 9;
         }
         s->attn_tail = false;
-        if (s->attn_fused && getenv("TLLM_ATTN_TAIL_MERGE"))
+        if (s->attn_fused && !getenv("TLLM_NO_ATTN_TAIL_MERGE"))
         {
             // same split geometry, but the merge moves from the O-projection's prologue into the tail of the attention launch
             s->attn_fused = false;
