@@ -95,8 +95,9 @@ def test_full_size_paged_cache_equals_linear(beam):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize('form', ['nodrain', 'drain'])
 @pytest.mark.parametrize('mode,layers', [('sq', 4), ('sq', 32), ('fp16', 4), ('woq8', 4)])
-def test_in_launch_attention_merge_equals_the_prologue_merge(mode, layers, monkeypatch):
+def test_in_launch_attention_merge_equals_the_prologue_merge(mode, layers, form, monkeypatch):
     """The split-KV merge inside the attention launch (r04, mmha_decode.hip step 6: write-through partials, one ticket per
     workgroup, the last arriver of a head merges with agent-scope loads) against the r01 - r03 path (TLLM_NO_ATTN_TAIL_MERGE=1:
     every O-projection workgroup merges all partials in its prologue).  Same slot order, same fp32 arithmetic, and for SmoothQuant
@@ -110,6 +111,7 @@ def test_in_launch_attention_merge_equals_the_prologue_merge(mode, layers, monke
     w = bench.synth_weights(torch, cfg, mode, int8_kv, 1, 0, dev)
     results = {}
     for tail in (False, True):
+        monkeypatch.setenv('TLLM_ATTN_TAIL', form)
         if tail:
             monkeypatch.delenv('TLLM_NO_ATTN_TAIL_MERGE', raising=False)
         else:

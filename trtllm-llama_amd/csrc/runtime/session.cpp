@@ -212,6 +212,8 @@ struct tllm_session
     // brings the r01 - r03 path back (every O-projection workgroup merges all partials in its prologue)
     bool attn_tail = false;
     uint32_t* attn_tickets = nullptr;
+    uint64_t* attn_granules = nullptr; // no-drain form (mmha_decode.hip step 6'): {value, tag} granules, per-head launch epochs
+    uint32_t *attn_epochs = nullptr, *attn_error = nullptr;
     void* ctx_q8 = nullptr;
     int end_id = -1;
     hipGraphExec_t graph = nullptr;
@@ -938,6 +940,9 @@ struct tllm_session
             if (attn_tail)
             {
                 m.tail_tickets = attn_tickets;
+                m.tail_granules = attn_granules;
+                m.tail_epochs = attn_epochs;
+                m.tail_error = attn_error;
                 if (tail_q8)
                 {
                     m.tail_out_q8 = ctx_q8;
@@ -1539,6 +1544,21 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
             RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_tickets), (size_t) B * s->Hr * 4));
             HIP_OK(hipMemset(s->attn_tickets, 0, (size_t) B * s->Hr * 4));
             RUN(s->dalloc(&s->ctx_q8, (size_t) B * s->Dr));
+            s->attn_granules = nullptr;
+            const char* form = getenv("TLLM_ATTN_TAIL");
+            if (!(form && !strcmp(form, "drain")))
+            {
+                int tcg = 0, nsg = 0;
+                size_t offg = 0;
+                (void) mmha_split_layout(s->Dh, Smax, s->attn_nit, B, s->Hr, &tcg, &nsg, &offg);
+                const size_t gbytes = (size_t) B * s->Hr * nsg * (s->Dh + 2) * 8;
+                RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_granules), gbytes));
+                HIP_OK(hipMemset(s->attn_granules, 0, gbytes));
+                RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_epochs), (size_t) B * s->Hr * 4));
+                HIP_OK(hipMemset(s->attn_epochs, 0, (size_t) B * s->Hr * 4));
+                RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_error), 4));
+                HIP_OK(hipMemset(s->attn_error, 0, 4));
+            }
         }
         if (mmha_split_layout(s->Dh, Smax, s->attn_nit, B, s->Hr, &tc, &ns, &off))
         {
@@ -1558,6 +1578,22 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
 // service, so that later sessions of this process fall back to RCCL.
 static int check_comm(tllm_session_t s)
 {
+    // the in-launch attention merge polls granules that are in flight, with a bound: a poll that gave up left garbage behind
+    if (s->attn_error)
+    {
+        uint32_t e = 0;
+        if (hipMemcpy(&e, s->attn_error, 4, hipMemcpyDeviceToHost) != hipSuccess)
+        {
+            set_error("session: cannot read the attention merge's error word");
+            return 1;
+        }
+        if (e)
+        {
+            (void) hipMemset(s->attn_error, 0, 4);
+            set_error("session: the in-launch attention merge gave up waiting for a split's partial; the results of this call are invalid");
+            return 1;
+        }
+    }
     // only while the transport is IN SERVICE: once a time-out has taken it out (below), later calls run over RCCL and the
     // words that recorded the failure must not fail them (disable_after_error clears them as well)
     if (s->tp == 1 && !s->force_comm)
