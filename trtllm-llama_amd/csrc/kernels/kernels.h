@@ -176,14 +176,6 @@ struct MmhaParams
     // writes the normalised context to `out` (and, with tail_quant_scale, its static int8 image to tail_out_q8) - the
     // O-projection then starts from a plain 8 KB / 4 KB vector instead of merging ns x 16 KB in each of its ~500 workgroups.
     uint32_t* tail_tickets = nullptr;
-    // no-drain form of the same merge: every value of a partial travels as ONE naturally aligned 8-byte {value, tag} granule
-    // (write-through), tag = the head's launch epoch + 1, so a workgroup takes its ticket right behind ISSUING its stores; the last
-    // arriver polls its siblings' granules until they carry this launch's tag (they are in flight: every sibling issued them
-    // before its ticket), merges, and bumps the epoch.  tail_granules: uint64 [B * H * nsplit * (Dh + 2)], tail_epochs: uint32
-    // [B * H], both zero before the first launch; tail_error (optional): set by a poll that gave up.
-    uint64_t* tail_granules = nullptr;
-    uint32_t* tail_epochs = nullptr;
-    uint32_t* tail_error = nullptr;
     const float* tail_quant_scale = nullptr; // f32 [1]: SmoothQuant static activation scale of the O-projection's input
     void* tail_out_q8 = nullptr;             // s8 [B, H*Dh]
     void* out = nullptr;       // fp16 [B, H*Dh]

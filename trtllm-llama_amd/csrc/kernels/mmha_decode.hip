@@ -17,7 +17,9 @@
 // loads; MmhaParams::tail_tickets), which leaves the O-projection a plain fp16 / int8 vector; r01 - r03 merged in the prologue of
 // every O-projection workgroup instead (gemv_impl.h PK_ATTN, TLLM_NO_ATTN_TAIL_MERGE=1): ~60 MB of L2 reads per launch for
 // 116 KB of distinct data.  (r01's first ticket merge used __threadfence() - an L2 write-back + invalidate per workgroup - and
-// measured 23 us; a one-workgroup-per-head variant 22 - 35 us.)  RoPE coefficients come from a 512-byte row the sampler
+// measured 23 us; a one-workgroup-per-head variant 22 - 35 us.  Two forms without the store drain - data-tagged granules polled by
+// a designated split, and epoch-tagged granules behind an un-drained ticket - were built in r04, bit-identical, and not faster:
+// profiles/r04_attn_granule_ab.txt.)  RoPE coefficients come from a 512-byte row the sampler
 // prepared for this step (GreedyParams::rope_row_out), so nothing chases length -> position -> table.
 //
 // Numerics follow SURVEY Appendix A.1: RoPE in fp32 -> fp16; int8 cache store = sat(rni(float(k16) * s)),
@@ -42,6 +44,7 @@ namespace
 {
 
 constexpr int kWaves = 4; // 256-thread workgroups
+constexpr int kTailSlots = 16; // partials the in-launch merge takes (MmhaParams::tail_tickets)
 
 template <int DH, int NIT>
 struct MmhaGeom
@@ -203,10 +206,6 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
     const uint4 k_raw = *reinterpret_cast<const uint4*>(qkv + (int64_t) (H + h) * DH + li * 8);
     const uint4 v_new = *reinterpret_cast<const uint4*>(qkv + (int64_t) (2 * H + h) * DH + li * 8);
     const int tl = p.sequence_length[b]; // slots already used; the new token goes to slot tl
-    // (no-drain tail merge) this head's launch epoch: requested here with everything else, unconditionally (a valid dummy address
-    // when the feature is off - no branch around a load)
-    const uint32_t* epoch_ptr = p.tail_epochs ? p.tail_epochs + b * H + h : reinterpret_cast<const uint32_t*>(p.sequence_length) + b;
-    const uint32_t epoch = __hip_atomic_load(epoch_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int mk[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i)
@@ -442,8 +441,6 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
     const int64_t pi = ((int64_t) b * H + h) * nsplit_max + c;
     const bool tail = p.tail_tickets != nullptr; // uniform
     __shared__ __attribute__((aligned(16))) float sm_out[DH];
-    __shared__ float sm_lsum;
-    __shared__ uint32_t sm_ticket;
     for (int d = tid; d < DH; d += 256)
     {
         float L = 0.f, O = 0.f;
@@ -455,9 +452,7 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
         if (tail)
         {
             sm_out[d] = O;
-            if (d == 0)
-                sm_lsum = L;
-            if (d == 0 && !p.tail_granules) // (m, l) as ONE 8-byte write-through store
+            if (d == 0) // (m, l) as ONE 8-byte write-through store
                 __hip_atomic_store(reinterpret_cast<uint64_t*>(ws_ml + pi),
                     (uint64_t) __float_as_uint(M) | ((uint64_t) __float_as_uint(L) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -470,96 +465,6 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
     }
     if (!tail)
         return;
-    const int nact = min(tl / G::TCHUNK + 1, nsplit_max); // splits that run (the others returned above)
-    if (p.tail_granules) // uniform
-    {
-        // ---- 6'. no-drain form: {value, tag} granules, ticket right behind the stores' ISSUE, the last arriver polls for this
-        //          launch's tag.  Nobody waits for a workgroup that has not run: whoever holds the last ticket knows that every
-        //          sibling has issued its stores.
-        constexpr int GW = DH + 2; // granules per partial: o[DH], m, l
-        const uint32_t tag = epoch + 1u;
-        uint64_t* gbase = p.tail_granules + ((int64_t) b * H + h) * nsplit_max * GW;
-        __syncthreads(); // sm_out / sm_lsum complete
-        for (int d = tid; d < GW; d += 256)
-        {
-            const float val = d < DH ? sm_out[d] : (d == DH ? M : sm_lsum);
-            __hip_atomic_store(gbase + (int64_t) c * GW + d, (uint64_t) __float_as_uint(val) | ((uint64_t) tag << 32), __ATOMIC_RELAXED,
-                __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads(); // every wave has issued its stores
-        if (tid == 0)
-            sm_ticket = __hip_atomic_fetch_add(p.tail_tickets + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if ((int) sm_ticket != nact - 1)
-            return;
-        for (int d = tid; d < DH; d += 256)
-        {
-            float ms[8], ls[8], os[8];
-            uint32_t have = 1u << c; // the own partial comes from LDS
-            ms[0] = ls[0] = os[0] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i == c)
-                {
-                    ms[i] = M;
-                    ls[i] = sm_lsum;
-                    os[i] = sm_out[d];
-                }
-            const uint32_t want = (1u << nact) - 1u;
-            int spins = 0;
-            while (have != want)
-            {
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                {
-                    if (i < nact && !((have >> i) & 1u))
-                    {
-                        const uint64_t* g = gbase + (int64_t) i * GW;
-                        const uint64_t go = __hip_atomic_load(g + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const uint64_t gm = __hip_atomic_load(g + DH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const uint64_t gl = __hip_atomic_load(g + DH + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((uint32_t) (go >> 32) == tag && (uint32_t) (gm >> 32) == tag && (uint32_t) (gl >> 32) == tag)
-                        {
-                            os[i] = __uint_as_float((uint32_t) go);
-                            ms[i] = __uint_as_float((uint32_t) gm);
-                            ls[i] = __uint_as_float((uint32_t) gl);
-                            have |= 1u << i;
-                        }
-                    }
-                }
-                if (have != want && ++spins > (1 << 20)) // the stores are in flight; ~a second means something else is broken
-                {
-                    if (p.tail_error)
-                        atomicOr(p.tail_error, 1u);
-                    break;
-                }
-            }
-            float Mx = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                Mx = (i < nact && ((have >> i) & 1u)) ? fmaxf(Mx, ms[i]) : Mx;
-            float Lt = 0.f, Ot = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-            {
-                const bool act = i < nact && ((have >> i) & 1u) && ms[i] != -INFINITY;
-                const float e = act ? __expf(ms[i] - Mx) : 0.f;
-                Lt += act ? ls[i] * e : 0.f;
-                Ot += act ? os[i] * e : 0.f;
-            }
-            const uint16_t h16 = f2h(Ot * (1.f / (Lt + 1.e-6f)));
-            const int64_t o = ((int64_t) b * H + h) * DH + d;
-            reinterpret_cast<uint16_t*>(p.out)[o] = h16;
-            if (p.tail_out_q8)
-                reinterpret_cast<int8_t*>(p.tail_out_q8)[o] = f2i8_rni_sat(h2f(h16) * p.tail_quant_scale[0]);
-        }
-        if (tid == 0) // next launch: a new tag, a fresh ticket count (ordered by the kernel boundary)
-        {
-            __hip_atomic_store(p.tail_epochs + b * H + h, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p.tail_tickets + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-    }
     // write-through (sc1) 16-byte stores of the partial: the merging workgroup may sit on another XCD, whose L2 never sees this
     // one's; scalar write-through stores are one fabric write each (guide: dword ~6 x the dwordx4 time per byte)
     __syncthreads();
@@ -575,6 +480,8 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
     //         agent-scope ticket; the consumer reads the payload with agent-scope (L1-bypassing) loads behind the ticket it took.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    __shared__ uint32_t sm_ticket;
+    const int nact = min(tl / G::TCHUNK + 1, nsplit_max); // splits that run (the others returned above)
     if (tid == 0)
         sm_ticket = __hip_atomic_fetch_add(p.tail_tickets + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -585,10 +492,11 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
     const int64_t base = ((int64_t) b * H + h) * nsplit_max;
     for (int d = tid; d < DH; d += 256)
     {
-        // the arithmetic of the O-projection's merge prologue (gemv_impl.h PK_ATTN), slot order, fp32: bit-identical results
-        float ms[8], ls[8], os[8];
+        // the arithmetic of the O-projection's merge prologue (gemv_impl.h PK_ATTN), slot order, fp32: bit-identical results.
+        // Up to kTailSlots partials (the prologue form stops at 8: there every slot costs each of ~500 workgroups a load)
+        float ms[kTailSlots], ls[kTailSlots], os[kTailSlots];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < kTailSlots; ++i)
         {
             const int ic = i < nact ? i : 0;
             const uint64_t mlb = __hip_atomic_load(reinterpret_cast<const uint64_t*>(ws_ml + base + ic), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -598,11 +506,11 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
         }
         float Mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < kTailSlots; ++i)
             Mx = i < nact ? fmaxf(Mx, ms[i]) : Mx;
         float Lt = 0.f, Ot = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < kTailSlots; ++i)
         {
             const bool act = i < nact && ms[i] != -INFINITY;
             const float e = act ? __expf(ms[i] - Mx) : 0.f;
@@ -684,9 +592,9 @@ int launch_nit(const MmhaParams& p, hipStream_t stream)
         set_error("mmha: max_seq_len %d needs more than 256 splits", p.max_seq_len);
         return -1;
     }
-    if (p.tail_tickets && (ns > 8 || (p.tail_out_q8 && !p.tail_quant_scale)))
+    if (p.tail_tickets && (ns > kTailSlots || (p.tail_out_q8 && !p.tail_quant_scale)))
     {
-        set_error("mmha: the in-launch merge takes at most 8 splits (got %d) and a scale with its int8 output", ns);
+        set_error("mmha: the in-launch merge takes at most %d splits (got %d) and a scale with its int8 output", kTailSlots, ns);
         return -1;
     }
     char* ws = reinterpret_cast<char*>(p.workspace);

@@ -212,8 +212,6 @@ struct tllm_session
     // brings the r01 - r03 path back (every O-projection workgroup merges all partials in its prologue)
     bool attn_tail = false;
     uint32_t* attn_tickets = nullptr;
-    uint64_t* attn_granules = nullptr; // no-drain form (mmha_decode.hip step 6'): {value, tag} granules, per-head launch epochs
-    uint32_t *attn_epochs = nullptr, *attn_error = nullptr;
     void* ctx_q8 = nullptr;
     int end_id = -1;
     hipGraphExec_t graph = nullptr;
@@ -940,9 +938,6 @@ struct tllm_session
             if (attn_tail)
             {
                 m.tail_tickets = attn_tickets;
-                m.tail_granules = attn_granules;
-                m.tail_epochs = attn_epochs;
-                m.tail_error = attn_error;
                 if (tail_q8)
                 {
                     m.tail_out_q8 = ctx_q8;
@@ -1519,46 +1514,36 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
         int tc = 0, ns = 0;
         size_t off = 0;
         s->attn_fused = false;
+        s->attn_tail = false;
         s->attn_nit = 4;
-        if (!getenv("TLLM_NO_FUSED_ATTN_MERGE") && mmha_split_layout(s->Dh, Smax, 16, B, s->Hr, &tc, &ns, &off) == 0 && ns <= 8
-            && s->Dr <= 256 * 8 * 6)
+        // The split-KV merge: inside the attention launch by the last split of a head to arrive (r04, up to 16 partials: 16-row
+        // splits cover 4096 cache slots), in the prologue of every O-projection workgroup (r01 - r03, TLLM_NO_ATTN_TAIL_MERGE=1; up to
+        // 8 partials - there every slot costs each of ~500 workgroups a load), or by a combine launch (TLLM_NO_FUSED_ATTN_MERGE=1,
+        // or more partials than either takes).
+        const bool want_tail = !getenv("TLLM_NO_ATTN_TAIL_MERGE");
+        const int max_parts = want_tail ? 16 : 8;
+        if (!getenv("TLLM_NO_FUSED_ATTN_MERGE") && mmha_split_layout(s->Dh, Smax, 16, B, s->Hr, &tc, &ns, &off) == 0 && ns <= max_parts
+            && (want_tail || s->Dr <= 256 * 8 * 6))
         {
-            s->attn_fused = true;
             s->attn_nit = 16;
             // 12 rows per lane group while that still needs <= 8 partials: more workgroups (7 x 32 instead of 5 x 32 at the
-            // 1024-token bench context), attention -0.85 us, the merge in the O-projection +0.65 us per layer
+            // 1024-token bench context; beyond 8 the launch would exceed one workgroup per CU)
             if (mmha_split_layout(s->Dh, Smax, 12, B, s->Hr, &tc, &ns, &off) == 0 && ns <= 8)
                 s->attn_nit = 12;
             // experiment switch (r04): TLLM_ATTN_ROWS=9 -> 144-token splits = 8 x 32 = 256 workgroups at the
-            // 1024-token bench context, all CUs busy; the merge then takes 8 slots
+            // 1024-token bench context, all CUs busy (measured: no gain, profiles/r04_attn_rows*_ab.txt)
             const char* rows_env = getenv("TLLM_ATTN_ROWS");
             if (rows_env && atoi(rows_env) == 9 && mmha_split_layout(s->Dh, Smax, 9, B, s->Hr, &tc, &ns, &off) == 0 && ns <= 8)
                 s->attn_nit = 9;
-        }
-        s->attn_tail = false;
-        if (s->attn_fused && !getenv("TLLM_NO_ATTN_TAIL_MERGE"))
-        {
-            // same split geometry, but the merge moves from the O-projection's prologue into the tail of the attention launch
-            s->attn_fused = false;
-            s->attn_tail = true;
-            RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_tickets), (size_t) B * s->Hr * 4));
-            HIP_OK(hipMemset(s->attn_tickets, 0, (size_t) B * s->Hr * 4));
-            RUN(s->dalloc(&s->ctx_q8, (size_t) B * s->Dr));
-            s->attn_granules = nullptr;
-            const char* form = getenv("TLLM_ATTN_TAIL");
-            if (!(form && !strcmp(form, "drain")))
+            if (want_tail)
             {
-                int tcg = 0, nsg = 0;
-                size_t offg = 0;
-                (void) mmha_split_layout(s->Dh, Smax, s->attn_nit, B, s->Hr, &tcg, &nsg, &offg);
-                const size_t gbytes = (size_t) B * s->Hr * nsg * (s->Dh + 2) * 8;
-                RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_granules), gbytes));
-                HIP_OK(hipMemset(s->attn_granules, 0, gbytes));
-                RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_epochs), (size_t) B * s->Hr * 4));
-                HIP_OK(hipMemset(s->attn_epochs, 0, (size_t) B * s->Hr * 4));
-                RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_error), 4));
-                HIP_OK(hipMemset(s->attn_error, 0, 4));
+                s->attn_tail = true;
+                RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_tickets), (size_t) B * s->Hr * 4));
+                HIP_OK(hipMemset(s->attn_tickets, 0, (size_t) B * s->Hr * 4));
+                RUN(s->dalloc(&s->ctx_q8, (size_t) B * s->Dr));
             }
+            else
+                s->attn_fused = true;
         }
         if (mmha_split_layout(s->Dh, Smax, s->attn_nit, B, s->Hr, &tc, &ns, &off))
         {
@@ -1578,22 +1563,6 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
 // service, so that later sessions of this process fall back to RCCL.
 static int check_comm(tllm_session_t s)
 {
-    // the in-launch attention merge polls granules that are in flight, with a bound: a poll that gave up left garbage behind
-    if (s->attn_error)
-    {
-        uint32_t e = 0;
-        if (hipMemcpy(&e, s->attn_error, 4, hipMemcpyDeviceToHost) != hipSuccess)
-        {
-            set_error("session: cannot read the attention merge's error word");
-            return 1;
-        }
-        if (e)
-        {
-            (void) hipMemset(s->attn_error, 0, 4);
-            set_error("session: the in-launch attention merge gave up waiting for a split's partial; the results of this call are invalid");
-            return 1;
-        }
-    }
     // only while the transport is IN SERVICE: once a time-out has taken it out (below), later calls run over RCCL and the
     // words that recorded the failure must not fail them (disable_after_error clears them as well)
     if (s->tp == 1 && !s->force_comm)
