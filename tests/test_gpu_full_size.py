@@ -167,3 +167,53 @@ def test_in_launch_attention_merge_beyond_eight_partials():
     assert np.mean(t0[0, S:] == t1[0, S:]) >= 0.75
     if np.array_equal(t0, t1):
         np.testing.assert_allclose(l0, l1, atol=0.05 * max(1.0, float(np.abs(l1).max())))
+
+
+def test_in_launch_attention_merge_under_uneven_load():
+    """The hand-off of the in-launch merge (write-through partials -> drain -> ticket -> agent-scope loads) must hold when the chip
+    is NOT idle: the same SmoothQuant generation (32 layers, 1100-token context, graph replay) with a second stream streaming
+    512 MB copies through HBM and L2 the whole time - arrival order, store latency and cache state all differ from the quiet run -
+    must give the quiet run's tokens and logits bit for bit (a stale, torn or early-read partial would change a logit)."""
+    import threading
+    cfg = dict(bench.LLAMA_7B)
+    dev = torch.device('cuda', 0)
+    w = bench.synth_weights(torch, cfg, 'sq', True, 1, 0, dev)
+    s = NativeSession(dict(cfg, quant_mode=bench.QM['sq'] | bench.INT8_KV, tp_size=1, tp_rank=0))
+    for k, v in w.items():
+        s.set_tensor(k, v)
+    s.finalize()
+    S, NEW = 1100, 48
+    ids = np.random.default_rng(41).integers(3, cfg['vocab_size'], (1, S)).astype(np.int32)
+    lens = np.array([S], np.int32)
+
+    def run():
+        s.setup(1, S, NEW)
+        toks = s.generate(ids, lens, NEW)
+        return toks.copy(), s.logits().copy()
+
+    quiet = run()
+    stop = threading.Event()
+    side = torch.cuda.Stream(device=dev)
+    a = torch.empty(128 << 20, dtype=torch.float32, device=dev)  # 512 MB
+    b = torch.empty_like(a)
+
+    def hammer():
+        with torch.cuda.stream(side):
+            while not stop.is_set():
+                for _ in range(8):
+                    b.copy_(a, non_blocking=True)
+                    a.add_(1.0)
+                side.synchronize()
+
+    th = threading.Thread(target=hammer, daemon=True)
+    th.start()
+    try:
+        loaded = [run() for _ in range(3)]
+    finally:
+        stop.set()
+        th.join(timeout=30)
+    torch.cuda.synchronize()
+    for toks, logits in loaded:
+        np.testing.assert_array_equal(toks, quiet[0])
+        np.testing.assert_array_equal(logits, quiet[1])
+    s.close()
