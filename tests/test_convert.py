@@ -62,8 +62,10 @@ def test_product_smooth_gemm_matches_reference_fixture():
     np.testing.assert_allclose(w2.numpy(), g['w2_joint'], rtol=1e-6)
 
 
-def test_smoothing_is_an_exact_reparametrisation(tmp_path):
-    """Folding the smoothers (RMSNorm weights, v_proj / up_proj rows) must leave the fp32 model's function unchanged."""
+@pytest.mark.parametrize('alpha_down', [None, 1.0])
+def test_smoothing_is_an_exact_reparametrisation(tmp_path, alpha_down):
+    """Folding the smoothers (RMSNorm weights, v_proj / up_proj rows) must leave the fp32 model's function unchanged - also with the
+    down_proj input migrated at its own strength (hf_llama_convert.py --smoothquant-down, r04)."""
     import torch
     from transformers import LlamaForCausalLM
     import hf_llama_convert as C
@@ -76,7 +78,7 @@ def test_smoothing_is_an_exact_reparametrisation(tmp_path):
     assert act['model.layers.0.self_attn.q_proj']['w'].shape == (TINY['hidden_size'], )  # per OUTPUT channel
     assert act['model.layers.1.mlp.down_proj']['x'].shape == (TINY['intermediate_size'], )
     sd = {k: v.detach().float().clone() for k, v in m.state_dict().items()}
-    C.smooth_llama_model(sd, act, 0.5, 2, 4, 4)
+    C.smooth_llama_model(sd, act, 0.5, 2, 4, 4, alpha_down=alpha_down)
     m2 = LlamaForCausalLM(m.config).float().eval()
     m2.load_state_dict(sd)
     ids = torch.randint(3, TINY['vocab_size'], (2, 33), generator=g)
