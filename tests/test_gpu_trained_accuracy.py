@@ -148,7 +148,7 @@ def test_teacher_forced_logits_within_the_reference_tolerance(ft_dirs, name):
                                          num_heads=cfg['num_attention_heads'], hidden_size=cfg['hidden_size']), blob, Mapping(1, 0))
     B = 4
     n = e['hf_logits'].shape[0] // B * B  # the prompts whose per-step HF logits the fixture holds
-    worst, sum_err, cnt, agree, confident, conf_agree = 0.0, 0.0, 0, 0, 0, 0
+    worst, sum_err, cnt, agree, confident, conf_agree, kl_sum = 0.0, 0.0, 0, 0, 0, 0, 0.0
     engine_logits = np.zeros((n, NEW, cfg['vocab_size']), np.float32)
     for i0 in range(0, n, B):
         lens = e['lengths'][i0:i0 + B].astype(np.int32)
@@ -164,6 +164,12 @@ def test_teacher_forced_logits_within_the_reference_tolerance(ft_dirs, name):
             engine_logits[i0:i0 + B, step] = got
             want = e['hf_logits'][i0:i0 + B, step].astype(np.float32)
             err = np.abs(got - want)
+            # KL(HF || engine) of the next-token distributions: what the logit error does to the probabilities
+            lw = want - want.max(-1, keepdims=True)
+            lw = lw - np.log(np.exp(lw).sum(-1, keepdims=True))
+            lg = got - got.max(-1, keepdims=True)
+            lg = lg - np.log(np.exp(lg).sum(-1, keepdims=True))
+            kl_sum += float((np.exp(lw) * (lw - lg)).sum(-1).mean())
             worst = max(worst, float(err.max()))
             sum_err += float(err.mean())
             cnt += 1
@@ -179,7 +185,9 @@ def test_teacher_forced_logits_within_the_reference_tolerance(ft_dirs, name):
                 rt.step(1, use_graph=False)
     scale = float(e['hf_logits_absmax'])
     print(f'[trained parent, {name}] teacher-forced over {n} prompts x {NEW} steps: max |dlogit| {worst:.4f}, mean {sum_err / cnt:.5f} '
-          f'(logit scale {scale:.1f}), arg-max agreement {agree}/{n * NEW}, where HF margin > 2 x error {conf_agree}/{confident}')
+          f'(logit scale {scale:.1f}), mean KL(HF || engine) {kl_sum / cnt:.2e} nats, arg-max agreement {agree}/{n * NEW}, where HF margin > 2 x '
+          f'error {conf_agree}/{confident}')
+    assert kl_sum / cnt < (1e-5 if name == 'fp16' else 5e-3)
     assert conf_agree == confident and agree == n * NEW  # every arg-max is HF's
     tol_max, tol_mean = LOGIT_TOL[name]
     if tol_mean is None:
