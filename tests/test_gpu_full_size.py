@@ -217,3 +217,27 @@ def test_in_launch_attention_merge_under_uneven_load():
         np.testing.assert_array_equal(toks, quiet[0])
         np.testing.assert_array_equal(logits, quiet[1])
     s.close()
+
+
+@pytest.mark.parametrize('mode', ['fp16', 'woq8'])
+def test_batch_of_eight_at_7b_dimensions(mode):
+    """build.py's default --max_batch_size 8 at the 7B layer dimensions with fp16 activations: the down-projection's 8 activation
+    rows (K = 11008 halfs: 176 KB) do not fit a CU's LDS at once - the GEMV takes them in slabs of 4 (r04; refused before).  Every
+    row of the batch is the same prompt: all eight sequences must generate what the batch-1 run generates."""
+    cfg = dict(bench.LLAMA_7B, num_layers=2)
+    int8_kv = mode != 'fp16'
+    dev = torch.device('cuda', 0)
+    s = NativeSession(dict(cfg, quant_mode=bench.QM[mode] | (bench.INT8_KV if int8_kv else 0), tp_size=1, tp_rank=0))
+    for k, v in bench.synth_weights(torch, cfg, mode, int8_kv, 1, 0, dev).items():
+        s.set_tensor(k, v)
+    s.finalize()
+    S, NEW = 48, 10
+    ids = np.random.default_rng(9).integers(3, cfg['vocab_size'], (1, S)).astype(np.int32)
+    s.setup(1, S, NEW)
+    one = s.generate(ids, np.array([S], np.int32), NEW)
+    s.setup(8, S, NEW)
+    eight = s.generate(np.repeat(ids, 8, 0), np.full(8, S, np.int32), NEW)
+    s.close()
+    for b in range(8):
+        np.testing.assert_array_equal(eight[b], eight[0])
+    assert np.mean(eight[0, S:] == one[0, S:]) > 0.7  # batch 1 and batch 8 take different kernels: fp32 summation order

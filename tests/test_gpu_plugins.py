@@ -215,7 +215,7 @@ def test_smooth_quant_gemm_fp32_view_weight():
 
 # ---------------------------------------------------------------------------------------------- weight-only
 @pytest.mark.parametrize('bits', [8, 4])
-@pytest.mark.parametrize('m,n,k', [(1, 1024, 4096), (3, 4096, 4096), (1, 4096, 11008), (24, 512, 1024),
+@pytest.mark.parametrize('m,n,k', [(1, 1024, 4096), (3, 4096, 4096), (1, 4096, 11008), (24, 512, 1024), (1, 5120, 13824), (2, 256, 22016), (8, 4096, 11008),
                                     # prefill sizes: the fp16-expansion + LDS-DMA MFMA path (M >= 32), ragged M / N
                                     (300, 456, 1152), (64, 1024, 4096),
                                     # single token, long K: the K-split one-shot kernel with ragged row / chunk counts
@@ -313,7 +313,11 @@ def test_weight_only_gemv_with_a_dc_offset_in_the_activations(bits, m, n, k):
 
 
 @pytest.mark.parametrize('m,n,k', [(1, 4096, 4096), (2, 32000, 4096), (1, 4096, 11008), (19, 192, 64), (8, 24, 64),
-                                   (1, 1003, 5120), (1, 13, 12288), (1, 520, 2056)])  # K-split kernel, ragged rows / chunks
+                                   (1, 1003, 5120), (1, 13, 12288), (1, 520, 2056),  # K-split kernel, ragged rows / chunks
+                                   # rows beyond 12288 halfs: the down-projections of LLaMA-13B / 65B (the third activation bucket, r04)
+                                   (1, 5120, 13824), (3, 512, 22016),
+                                   # 8 rows of an fp16 K = 11008 vector exceed a CU's LDS: slabs of 4 rows (r04; refused before)
+                                   (8, 4096, 11008), (5, 256, 13824)])
 def test_gemm_fp16(m, n, k):
     r = rng(5)
     x, w = h(r.standard_normal((m, k))), h(r.standard_normal((n, k)) / np.sqrt(k))

@@ -19,6 +19,47 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
         return -1;
     }
     const bool sq = p.wtype == W_INT8_SQ;
+    // The kernel keeps the activation rows of its row bucket (1 / 2 / 4 / 8) in LDS: 8 rows of an fp16 K = 11008 vector are 176 KB -
+    // more than a CU has (LLaMA-7B's down-projection at batch 5 .. 8, every LLaMA's at 13B and beyond).  Such a call goes through
+    // in slabs of as many rows as fit, each slab streaming the weights again (r04; before, it was refused).
+    {
+        const int es = sq ? 1 : 2; // bytes per activation element in LDS
+        const int64_t kp = (p.K + 31) / 32 * 32;
+        int mb = p.M <= 1 ? 1 : (p.M <= 2 ? 2 : (p.M <= 4 ? 4 : 8));
+        int fit = mb;
+        while (fit > 1 && kRedBytes + (int64_t) fit * kp * es > 160 * 1024)
+            fit >>= 1;
+        if (fit < mb)
+        {
+            const bool raw_s8 = sq && p.pro == PRO_NONE;
+            for (int m0 = 0; m0 < p.M; m0 += fit)
+            {
+                GemvParams q = p;
+                q.M = p.M - m0 < fit ? p.M - m0 : fit;
+                if (p.pro < PRO_ATTN)
+                    q.x = static_cast<const char*>(p.x) + (int64_t) m0 * p.ldx * (raw_s8 ? 1 : 2);
+                else
+                {
+                    q.attn_ml = static_cast<const char*>(p.attn_ml) + (int64_t) m0 * p.attn_heads * p.attn_nsmax * 8;
+                    q.attn_o = p.attn_o + (int64_t) m0 * p.attn_heads * p.attn_nsmax * p.attn_dh;
+                    q.attn_seq_len = p.attn_seq_len + m0;
+                }
+                const int yes = p.out_dtype == DT_INT8 ? 1 : (p.out_dtype == DT_HALF ? 2 : 4);
+                q.y = static_cast<char*>(p.y) + (int64_t) m0 * p.ldy * yes;
+                if (p.residual)
+                    q.residual = static_cast<const char*>(p.residual) + (int64_t) m0 * p.ldy * 2;
+                if (p.per_token && p.scale_row)
+                    q.scale_row = p.scale_row + m0;
+                if (p.dyn_scale_out)
+                    q.dyn_scale_out = p.dyn_scale_out + m0;
+                if (p.x_pro_out)
+                    q.x_pro_out = static_cast<char*>(p.x_pro_out) + (int64_t) m0 * p.K * es;
+                if (launch_gemv(q, stream))
+                    return -1;
+            }
+            return 0;
+        }
+    }
     const bool swiglu = p.epi == EPI_SWIGLU || p.epi == EPI_SWIGLU_QSTATIC;
     const bool quant_pro = (p.pro >= PRO_RMSNORM_QSTATIC && p.pro <= PRO_QDYN) || p.pro == PRO_ATTN_QSTATIC
         || p.pro == PRO_ATTN_QDYN;
@@ -70,9 +111,10 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     // activations: 16-byte vectors kept in registers by 256 threads
     const bool raw_s8 = sq && p.pro == PRO_NONE;
     const int xvec = raw_s8 ? 16 : 8;
-    if ((p.K % xvec) || p.K > 256 * xvec * kNXVMax)
+    const int nxv_lim = ((pk == PK_COPY || pk == PK_QUANT) && !swiglu) ? kNXVLarge : kNXVMax; // (gemv_args.h)
+    if ((p.K % xvec) || p.K > 256 * xvec * nxv_lim)
     {
-        set_error("gemv: K=%d must be a multiple of %d and <= %d", p.K, xvec, 256 * xvec * kNXVMax);
+        set_error("gemv: K=%d must be a multiple of %d and <= %d", p.K, xvec, 256 * xvec * nxv_lim);
         return -1;
     }
     if (pk != PK_ATTN && ((reinterpret_cast<uintptr_t>(p.x) & 15) || ((p.ldx * (raw_s8 ? 1 : 2)) & 15)))

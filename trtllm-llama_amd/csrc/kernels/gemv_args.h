@@ -13,6 +13,10 @@ constexpr int R = 2, U = 4; // weight tile: 2 rows x 4 chunks of 1 KiB (int4 row
 constexpr int kRedBytes = 384; // reduction scratch: 32 floats sum of squares, 32 amax, 32 activation sums (weight-only int8)
 constexpr int kNXVMax = 6; // 16-byte x vectors a thread keeps in registers: K <= 256 * 8 * 6 = 12288 halfs
 constexpr int kNXVSmall = 2; // bucket for K <= 4096 halfs (every 7B hidden-size GEMV): 32 fewer VGPRs -> one more wave/SIMD
+// third bucket (r04): K <= 256 * 8 * 12 = 24576 halfs, for the prologues that do not normalise (plain input, or the SmoothQuant
+// quantiser) - the down-projection of LLaMA-13B / 30B / 65B (K = 13824 / 17920 / 22016) with fp16 activations, which the 12288 of
+// the middle bucket refused (found by the 13B-dimension parity test)
+constexpr int kNXVLarge = 12;
 
 enum ProKind
 {

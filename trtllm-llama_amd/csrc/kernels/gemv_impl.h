@@ -888,7 +888,12 @@ int launch_nxv(const GemvArgs& a, hipStream_t stream)
     const int xvec = (WT == W_INT8_SQ && PK == PK_COPY) ? 16 : 8;
     if (a.p.K <= 256 * xvec * kNXVSmall)
         return launch_mb<WT, PK, EK, kNXVSmall>(a, stream);
-    return launch_mb<WT, PK, EK, kNXVMax>(a, stream);
+    if (a.p.K <= 256 * xvec * kNXVMax)
+        return launch_mb<WT, PK, EK, kNXVMax>(a, stream);
+    if constexpr ((PK == PK_COPY || PK == PK_QUANT) && EK == EK_PLAIN)
+        return launch_mb<WT, PK, EK, kNXVLarge>(a, stream);
+    set_error("gemv: K=%d exceeds %d, the limit of the normalising / merging prologues and the SwiGLU epilogue", a.p.K, 256 * xvec * kNXVMax);
+    return -1;
 }
 
 template <int WT>
