@@ -563,3 +563,43 @@ def test_more_than_eight_sequences_run_in_slabs_of_eight(mode, int8_kv):
         np.testing.assert_allclose(cum[b], c1[0], atol=0.05)
         np.testing.assert_array_equal(beams[b, 0, :S + 2], b1[0, 0, :S + 2])
     s.close()
+
+
+@pytest.mark.parametrize('dims', ['30b', '65b'])
+@pytest.mark.parametrize('mode,int8_kv', [('fp16', 0), ('woq8', 1), ('sq_static_pc', 1), ('sq_dyn_pc', 1)])
+def test_one_layer_at_larger_llama_dimensions_vs_oracle(mode, int8_kv, dims):
+    """The layer dimensions of LLaMA-30B (D 6656, 52 heads, FFN 17920) and 65B (D 8192, 64 heads, FFN 22016) - what `build.py --n_embd
+    --n_head --inter_size` of the reference accepts - with a ragged batch of 5 (the GEMV's 8-row bucket; with fp16 activations its rows
+    exceed a CU's LDS and go through in slabs, gemv.hip): rows of 13 - 43 KiB, the third activation-vector bucket for the
+    down-projection, 52 / 64 heads in the attention launch and its in-launch merge.  Context + 3 generation steps (eager and graph)
+    against the oracle on identical weights and scales."""
+    H, D, I = {'30b': (52, 6656, 17920), '65b': (64, 8192, 22016)}[dims]
+    cfg, w = synth_model(29, L=1, H=H, D=D, I=I, V=512)
+    B, S, NEW = 5, 24, 4
+    r = np.random.default_rng(13)
+    ids = r.integers(3, cfg['vocab_size'], (B, S)).astype(np.int32)
+    lens = np.array([S, 13, 24, 7, 19], np.int32)
+    for b in range(B):
+        ids[b, lens[b]:] = 2
+    qmodel = QO.quantise_model(cfg, w, mode, int8_kv, calib_ids=ids, calib_lens=lens)
+    s = NativeSession(dict(cfg, quant_mode=qmodel['quant_mode']))
+    for k, v in qmodel['engine_tensors'].items():
+        s.set_tensor(k, v)
+    s.finalize()
+    s.setup(B, S, NEW)
+    s.context(ids, lens)
+    got = [s.logits()]
+    s.step(1, use_graph=False)
+    got.append(s.logits())
+    s.step(2, use_graph=True)
+    got.append(s.logits())
+    out = s.output_ids()
+    s.close()
+    ref_logits, _ = QO.run_model(qmodel, ids, lens, NEW, feed_ids=out[:, S:S + NEW])
+    scale = max(np.abs(ref_logits[0]).max(), 1.0)
+    sq = mode.startswith('sq')
+    for g, rr in ((got[0], ref_logits[0]), (got[1], ref_logits[1]), (got[2], ref_logits[3])):
+        assert np.isfinite(g).all()
+        print(f'[{dims} {mode}] max |d| / scale = {np.abs(g - rr).max() / scale:.4g}, mean |d| / scale = {np.abs(g - rr).mean() / scale:.4g}')
+        np.testing.assert_allclose(g, rr, atol=(6e-2 if sq else 1e-2) * scale)
+        assert np.abs(g - rr).mean() < (1.5e-2 if sq else 2.5e-3) * scale
