@@ -603,3 +603,38 @@ def test_one_layer_at_larger_llama_dimensions_vs_oracle(mode, int8_kv, dims):
         print(f'[{dims} {mode}] max |d| / scale = {np.abs(g - rr).max() / scale:.4g}, mean |d| / scale = {np.abs(g - rr).mean() / scale:.4g}')
         np.testing.assert_allclose(g, rr, atol=(6e-2 if sq else 1e-2) * scale)
         assert np.abs(g - rr).mean() < (1.5e-2 if sq else 2.5e-3) * scale
+
+
+@pytest.mark.parametrize('mode,int8_kv', [('fp16', 0), ('sq_static_pc', 1)])
+def test_odd_vocabulary_size_vs_oracle(mode, int8_kv):
+    """A vocabulary that is no multiple of anything (32001-style checkpoints with an added pad token; here 1003): lm_head rows, the fp32
+    logits buffer and the device-side arg-max at a ragged size - context + 3 generation steps against the oracle, and the greedy ids."""
+    cfg, w = synth_model(17, V=1003)
+    B, S, NEW = 3, 10, 4
+    r = np.random.default_rng(3)
+    ids = r.integers(3, cfg['vocab_size'], (B, S)).astype(np.int32)
+    lens = np.array([S, 4, 9], np.int32)
+    for b in range(B):
+        ids[b, lens[b]:] = 2
+    qmodel = QO.quantise_model(cfg, w, mode, int8_kv, calib_ids=ids, calib_lens=lens)
+    s = NativeSession(dict(cfg, quant_mode=qmodel['quant_mode']))
+    for k, v in qmodel['engine_tensors'].items():
+        s.set_tensor(k, v)
+    s.finalize()
+    s.setup(B, S, NEW)
+    s.context(ids, lens)
+    got = [s.logits()]
+    s.step(1, use_graph=False)
+    got.append(s.logits())
+    s.step(2, use_graph=True)
+    got.append(s.logits())
+    out = s.output_ids()
+    s.close()
+    assert got[0].shape == (B, 1003)
+    ref_logits, _ = QO.run_model(qmodel, ids, lens, NEW, feed_ids=out[:, S:S + NEW])
+    scale = max(np.abs(ref_logits[0]).max(), 1.0)
+    sq = mode.startswith('sq')
+    for step, (g, rr) in enumerate(((got[0], ref_logits[0]), (got[1], ref_logits[1]), (got[2], ref_logits[3]))):
+        np.testing.assert_allclose(g, rr, atol=(5e-2 if sq else 1e-2) * scale)
+    # the sampler's pick is the arg-max of the logits it was given, for every row, also in the last (ragged) stretch of the vocabulary
+    np.testing.assert_array_equal(out[:, S], got[0].argmax(-1))
