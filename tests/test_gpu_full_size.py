@@ -219,8 +219,9 @@ def test_in_launch_attention_merge_under_uneven_load():
     s.close()
 
 
+@pytest.mark.parametrize('B', [8, 12])
 @pytest.mark.parametrize('mode', ['fp16', 'woq8'])
-def test_batch_of_eight_at_7b_dimensions(mode):
+def test_batch_of_eight_at_7b_dimensions(mode, B):
     """build.py's default --max_batch_size 8 at the 7B layer dimensions with fp16 activations: the down-projection's 8 activation
     rows (K = 11008 halfs: 176 KB) do not fit a CU's LDS at once - the GEMV takes them in slabs of 4 (r04; refused before).  Every
     row of the batch is the same prompt: all eight sequences must generate what the batch-1 run generates."""
@@ -235,9 +236,9 @@ def test_batch_of_eight_at_7b_dimensions(mode):
     ids = np.random.default_rng(9).integers(3, cfg['vocab_size'], (1, S)).astype(np.int32)
     s.setup(1, S, NEW)
     one = s.generate(ids, np.array([S], np.int32), NEW)
-    s.setup(8, S, NEW)
-    eight = s.generate(np.repeat(ids, 8, 0), np.full(8, S, np.int32), NEW)
+    s.setup(B, S, NEW)  # 12: the session's slabs of 8 rows (8 + 4), each split again by the GEMV where its rows exceed the LDS
+    eight = s.generate(np.repeat(ids, B, 0), np.full(B, S, np.int32), NEW)
     s.close()
-    for b in range(8):
+    for b in range(B):
         np.testing.assert_array_equal(eight[b], eight[0])
     assert np.mean(eight[0, S:] == one[0, S:]) > 0.7  # batch 1 and batch 8 take different kernels: fp32 summation order

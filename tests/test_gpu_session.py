@@ -638,3 +638,38 @@ def test_odd_vocabulary_size_vs_oracle(mode, int8_kv):
         np.testing.assert_allclose(g, rr, atol=(5e-2 if sq else 1e-2) * scale)
     # the sampler's pick is the arg-max of the logits it was given, for every row, also in the last (ragged) stretch of the vocabulary
     np.testing.assert_array_equal(out[:, S], got[0].argmax(-1))
+
+
+@pytest.mark.parametrize('mode,int8_kv', [('fp16', 0), ('woq8', 1), ('woq4', 0), ('sq_static_pc', 1), ('sq_dyn', 0)])
+def test_awkward_dimensions_vs_oracle(mode, int8_kv):
+    """Dimensions no production kernel is tiled for - 5 heads of 64 (D = 320), FFN 992, vocabulary 777, a ragged batch of 3 with a
+    one-token prompt in it - so that the fall-back paths run: prefill GEMMs whose K is no multiple of the 128-byte K-tile (320 int8
+    bytes, 992) or of the weight-only kernel's 64 elements (992), row counts that are no multiple of any tile, the generic context
+    attention for 5 heads.  Context (M = 42 rows) + 3 generation steps against the oracle."""
+    cfg, w = synth_model(31, L=2, H=5, D=320, I=992, V=777)
+    B, S, NEW = 3, 14, 4
+    r = np.random.default_rng(7)
+    ids = r.integers(3, cfg['vocab_size'], (B, S)).astype(np.int32)
+    lens = np.array([S, 1, 9], np.int32)
+    for b in range(B):
+        ids[b, lens[b]:] = 2
+    qmodel = QO.quantise_model(cfg, w, mode, int8_kv, calib_ids=ids, calib_lens=lens)
+    s = NativeSession(dict(cfg, quant_mode=qmodel['quant_mode']))
+    for k, v in qmodel['engine_tensors'].items():
+        s.set_tensor(k, v)
+    s.finalize()
+    s.setup(B, S, NEW)
+    s.context(ids, lens)
+    got = [s.logits()]
+    s.step(1, use_graph=False)
+    got.append(s.logits())
+    s.step(2, use_graph=True)
+    got.append(s.logits())
+    out = s.output_ids()
+    s.close()
+    ref_logits, _ = QO.run_model(qmodel, ids, lens, NEW, feed_ids=out[:, S:S + NEW])
+    scale = max(np.abs(ref_logits[0]).max(), 1.0)
+    sq = mode.startswith('sq')
+    for g, rr in ((got[0], ref_logits[0]), (got[1], ref_logits[1]), (got[2], ref_logits[3])):
+        assert np.isfinite(g).all()
+        np.testing.assert_allclose(g, rr, atol=(6e-2 if sq else 1e-2) * scale)
