@@ -242,3 +242,36 @@ def test_batch_of_eight_at_7b_dimensions(mode, B):
     for b in range(B):
         np.testing.assert_array_equal(eight[b], eight[0])
     assert np.mean(eight[0, S:] == one[0, S:]) > 0.7  # batch 1 and batch 8 take different kernels: fp32 summation order
+
+
+@pytest.mark.parametrize('mode', ['sq', 'fp16'])
+def test_maximum_prefill_batch8_x_2048(mode):
+    """build.py's defaults at their limit: 8 prompts of 2048 tokens = 16384 rows through the prefill GEMMs (64 row tiles of 256; 32-bit
+    LDS-DMA offsets checked against M * K), the context attention at its longest sequence on 8 x 32 heads, the KV write of
+    8 x 2048 slots.  Every row of the batch is the same prompt: identical logits in all eight, equal (SmoothQuant: bit for bit, its
+    GEMMs are exact) to the prompt run alone."""
+    cfg = dict(bench.LLAMA_7B, num_layers=2)
+    int8_kv = mode != 'fp16'
+    dev = torch.device('cuda', 0)
+    s = NativeSession(dict(cfg, quant_mode=bench.QM[mode] | (bench.INT8_KV if int8_kv else 0), tp_size=1, tp_rank=0))
+    for k, v in bench.synth_weights(torch, cfg, mode, int8_kv, 1, 0, dev).items():
+        s.set_tensor(k, v)
+    s.finalize()
+    S = 2044
+    ids = np.random.default_rng(2).integers(3, cfg['vocab_size'], (1, S)).astype(np.int32)
+    s.setup(1, S, 4)
+    s.context(ids, np.array([S], np.int32))
+    one = s.logits().copy()
+    s.setup(8, S, 4)
+    s.context(np.repeat(ids, 8, 0), np.full(8, S, np.int32))
+    eight = s.logits().copy()
+    s.step(2, use_graph=False)
+    assert np.isfinite(s.logits()).all()
+    s.close()
+    assert np.isfinite(eight).all()
+    for b in range(1, 8):
+        np.testing.assert_array_equal(eight[b], eight[0])
+    if mode == 'sq':
+        np.testing.assert_array_equal(eight[0], one[0])
+    else:
+        np.testing.assert_allclose(eight[0], one[0], atol=2e-2 * max(1.0, float(np.abs(one).max())))
