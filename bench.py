@@ -629,7 +629,7 @@ def main():
             line['sq_gemm_mfma_large_m'] = {
                 str(m): {k: {kk: v[kk] for kk in ('us', 'TOP/s', 'frac_of_5POPs', 'tactic', 'static_rule_us', 'shader_MHz_held',
                                                    'frac_of_peak_at_held_clock') if kk in v}
-                         for k, v in sq_gemm_mfma_report(torch, dev, M=m).items()} for m in (4096, 8192)}
+                         for k, v in sq_gemm_mfma_report(torch, dev, M=m).items()} for m in (2048, 4096, 8192)}
         except Exception as e:  # the decode metric must not depend on the side report
             line.setdefault('sq_gemm_mfma', {'error': repr(e)})
             line['sq_gemm_mfma_large_m'] = {'error': repr(e)}

@@ -502,8 +502,11 @@ int launch_cfg(const GemmParams& p, hipStream_t stream)
 struct Shape
 {
     int id, bm, bn;
+    double f; // measured time per (workgroup round x tile area), relative to the phased 256 x 192 tile (profiles/r04_tile256x128.txt)
 };
-constexpr Shape kShapes[] = {{8, 128, 128}, {6, 256, 192}, {2, 256, 256}, {4, 128, 256}};
+// id 42 is the phased 256 x 128 tile of gemm_sqp.hip (its fp16 sibling is id 54): it has no lock-step form in this file
+constexpr int kPhased256x128 = 42;
+constexpr Shape kShapes[] = {{8, 128, 128, 1.40}, {6, 256, 192, 1.0}, {2, 256, 256, 1.12}, {4, 128, 256, 1.39}, {kPhased256x128, 256, 128, 1.08}};
 constexpr int kNumCfg = 12;
 
 template <int WT>
@@ -550,8 +553,10 @@ static bool glds_serves(const GemmParams& p)
     return true;
 }
 
-// The static rule: fewest workgroup rounds over the CUs, then the largest tile (fewest operand re-reads through L2)
-static int static_shape_cfg(const GemmParams& p)
+// The static rule: fewest workgroup rounds over the CUs x the tile's area x what a tile of that kind costs per area (the 128-wide
+// lock-step tiles pay ~40 % for their lower MFMA : LDS ratio and their exposed prologue / epilogue).  `phased_ok` = false leaves
+// out the tile that exists in gemm_sqp.hip only (its launcher refused the problem: alignment, 32-bit DMA offsets).
+static int static_shape_cfg(const GemmParams& p, bool phased_ok = true)
 {
     static std::atomic<int> cus_cache{0};
     int cus = cus_cache.load();
@@ -567,9 +572,10 @@ static int static_shape_cfg(const GemmParams& p)
     int cfg = 8;
     for (const Shape& s : kShapes)
     {
+        if (s.id == kPhased256x128 && !phased_ok)
+            continue;
         const int64_t tiles = (int64_t) ((p.M + s.bm - 1) / s.bm) * ((p.N + s.bn - 1) / s.bn);
-        // time ~ tiles on the busiest CU x tile area; the small tile pays ~15 % for its lower MFMA : LDS ratio
-        const double cost = (double) ((tiles + cus - 1) / cus) * s.bm * s.bn * (s.bm * s.bn == 128 * 128 ? 1.15 : 1.0);
+        const double cost = (double) ((tiles + cus - 1) / cus) * s.bm * s.bn * s.f;
         if (cost < best)
         {
             best = cost;
@@ -585,6 +591,8 @@ int gemm_static_cfg(const GemmParams& p)
     if (!glds_serves(p))
         return 0;
     const int cfg = static_shape_cfg(p);
+    if (cfg == kPhased256x128)
+        return p.wtype == W_INT8_SQ ? 42 : 54;
     return cfg == 6 ? (p.wtype == W_INT8_SQ ? 20 : 50) : cfg; // the 256 x 192 tile runs its phased sibling (gemm_sqp.hip)
 }
 
@@ -625,7 +633,17 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
         cfg = 0; // not served there (shape / alignment): the heuristic below picks a lock-step shape
     }
     if (cfg <= 0 || !((cfg >= 1 && cfg <= kNumCfg) || cfg == 36 || cfg == 37))
+    {
         cfg = static_shape_cfg(p);
+        if (cfg == kPhased256x128)
+        {
+            // one round of 256 x 128 tiles where 128 x 128 would take two (O / down at M = 2048: 34 vs 44 us, 84 vs 107 us)
+            const int r = sq ? launch_gemm_sqp(p, 42, stream) : launch_gemm_f16p(p, 54, stream);
+            if (r <= 0)
+                return r;
+            cfg = static_shape_cfg(p, false);
+        }
+    }
     if (!sq && cfg == 6 && gemm_tune_cfg <= 0 && !from_table)
     {
         // the same sibling on fp16 operands (r04): 6 - 7 % faster on QKV / gate / up at M = 1024 (profiles/r04_fp16_gemm_sweep.txt)

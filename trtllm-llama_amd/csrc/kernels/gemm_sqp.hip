@@ -685,6 +685,8 @@ int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
     // prologue / epilogue under the other's main loop, at the price of 43 % more LDS-DMA bytes per MFMA
     case 40: return launch_sqp<2, 2, 2, 3, 1, 7, false, 16, 0, false, false>(p, stream);
     case 41: return launch_sqp<2, 2, 2, 3, 2, 8, true, 16, 0, false, false>(p, stream);
+    // 256 x 128 on 8 waves (64 x 64 wave tiles): the tile a split-K-2 pass of the O / down shapes would run (256 workgroups at M = 1024)
+    case 42: return launch_sqp<4, 2, 2, 2, 0, 4, false, 16>(p, stream);
     // ablations of the 256 x 192 shape (wrong results on purpose; microbench only)
     case 21: return launch_sqp<4, 2, 2, 3, 2, 8, false, 1>(p, stream); // no DMA in the loop
     case 22: return launch_sqp<4, 2, 2, 3, 2, 8, false, 2>(p, stream); // no MFMA
@@ -720,6 +722,7 @@ int launch_gemm_f16p(const GemmParams& pin, int cfg, hipStream_t stream)
     case 51: return launch_sqp<4, 2, 1, 2, 1, 3, true, 0, 0, false, false, true>(p, stream);  // 128 x 128 on 8 waves
     case 52: return launch_sqp<2, 2, 2, 2, 1, 5, true, 0, 0, false, false, true>(p, stream);  // 128 x 128 on 4 waves, 2 per CU
     case 53: return launch_sqp<4, 2, 2, 3, 2, 8, true, 0, 0, false, false, true>(p, stream);  // 256 x 192 with setprio
+    case 54: return launch_sqp<4, 2, 2, 2, 0, 4, false, 16, 0, false, false, true>(p, stream); // 256 x 128
     default: return 1;
     }
 }
