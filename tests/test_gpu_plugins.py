@@ -271,7 +271,7 @@ def test_woq_prefill_gemm_dequantises_in_the_main_loop(bits, m, n, k, lib):
     wt = torch.from_numpy(processed).cuda().view(torch.float32).reshape(k, -1)
     outs = []
     try:
-        for cfg in (101, 102, 103, 104):
+        for cfg in (101, 102, 103, 104, 105, 106):
             lib.tllm_gemm_set_tile_cfg(cfg)
             out = torch.full((m, n), 7.0, dtype=torch.float16, device='cuda')
             run_plugin(p, [torch.from_numpy(x).cuda(), wt, torch.from_numpy(scales).cuda()], [out])

@@ -60,4 +60,4 @@ for name, (N, K) in shapes.items():
             res.setdefault(cfg, []).append(e0.elapsed_time(e1) * 100)
     lib.tllm_gemm_set_tile_cfg(0)
     print(f'{name:11s} M={M} N={N} K={K} int{bits}: ' + ' | '.join(
-        f'{cfg}: {min(v):6.1f} us {2.0 * M * N * K / min(v) / 1e9:5.0f} TF/s' for cfg, v in res.items()))
+        f'{cfg}: {min(v):6.1f} us {2.0 * M * N * K / min(v) / 1e6:5.0f} TF/s' for cfg, v in res.items()))

@@ -348,13 +348,15 @@ int launch_woq_bits(const GemmParams& p, int cfg, hipStream_t stream)
     case 2: return launch_woq_cfg<BITS, 2, 2, 2, 2, 4>(p, stream); // 128 x 128, 4 waves, 3 stages ahead
     case 3: return launch_woq_cfg<BITS, 4, 2, 2, 3, 3>(p, stream); // 256 x 192, 2 stages ahead
     case 4: return launch_woq_cfg<BITS, 2, 2, 4, 3, 2>(p, stream); // 256 x 192 on 4 waves (128 x 96 per wave): half the dequantisation per MFMA
+    case 5: return launch_woq_cfg<BITS, 4, 2, 2, 2, 3>(p, stream); // 256 x 128, 8 waves (64 x 64 per wave), 2 stages ahead
+    case 6: return launch_woq_cfg<BITS, 4, 2, 2, 2, 2>(p, stream); // 256 x 128, 1 stage ahead
     default: return launch_woq_cfg<BITS, 4, 2, 2, 3, 2>(p, stream); // 256 x 192, 8 waves, 1 stage ahead
     }
 }
 
 } // namespace
 
-int gemm_woq_tune_cfg = 0; // test / bench override (tllm_gemm_set_tile_cfg 101..104 -> 1..4)
+int gemm_woq_tune_cfg = 0; // test / bench override (tllm_gemm_set_tile_cfg 101..106 -> 1..6)
 
 // returns 0 on success, -1 on a launch error, 1 when the problem is not served (caller falls back to the expanded path)
 int launch_gemm_woq(const GemmParams& p, hipStream_t stream)
@@ -372,7 +374,7 @@ int launch_gemm_woq(const GemmParams& p, hipStream_t stream)
     int cfg = gemm_woq_tune_cfg;
     if (cfg <= 0)
     {
-        // fewest workgroup rounds over the CUs (the rule of gemm_glds.hip): 256 x 192 for QKV / gate / up, 128 x 128 for O / down
+        // fewest workgroup rounds over the CUs (the rule of gemm_glds.hip): at M = 1024 256 x 192 for QKV / gate / up, 128 x 128 for O / down
         static std::atomic<int> cus_cache{0};
         int cus = cus_cache.load();
         if (!cus)
@@ -383,9 +385,25 @@ int launch_gemm_woq(const GemmParams& p, hipStream_t stream)
                 cus = 256;
             cus_cache.store(cus);
         }
-        const int64_t t_big = (int64_t) ((p.M + 255) / 256) * ((p.N + 191) / 192), t_small = (int64_t) ((p.M + 127) / 128) * ((p.N + 127) / 128);
-        const double c_big = (double) ((t_big + cus - 1) / cus) * 256 * 192, c_small = (double) ((t_small + cus - 1) / cus) * 128 * 128 * 1.15;
-        cfg = c_big <= c_small ? 1 : 2;
+        // cost = workgroup rounds x tile area x the measured cost of a tile of that kind per area, relative to 256 x 192
+        // (profiles/r04_tile256x128.txt): 256 x 128 fills the chip in ONE round for O / down at M = 2048 where 128 x 128 takes two
+        struct Cand
+        {
+            int id, bm, bn;
+            double f;
+        };
+        const Cand cands[] = {{1, 256, 192, 1.0}, {6, 256, 128, 1.08}, {2, 128, 128, w8 ? 1.28 : 1.15}};
+        double best = 1e30;
+        for (const Cand& c : cands)
+        {
+            const int64_t t = (int64_t) ((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
+            const double cost = (double) ((t + cus - 1) / cus) * c.bm * c.bn * c.f;
+            if (cost < best)
+            {
+                best = cost;
+                cfg = c.id;
+            }
+        }
     }
     return w8 ? launch_woq_bits<8>(p, cfg, stream) : launch_woq_bits<4>(p, cfg, stream);
 }
