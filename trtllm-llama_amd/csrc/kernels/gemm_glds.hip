@@ -506,7 +506,7 @@ struct Shape
 };
 // id 42 is the phased 256 x 128 tile of gemm_sqp.hip (its fp16 sibling is id 54): it has no lock-step form in this file
 constexpr int kPhased256x128 = 42;
-constexpr Shape kShapes[] = {{8, 128, 128, 1.40}, {6, 256, 192, 1.0}, {2, 256, 256, 1.12}, {4, 128, 256, 1.39}, {kPhased256x128, 256, 128, 1.08}};
+constexpr Shape kShapes[] = {{8, 128, 128, 1.40}, {6, 256, 192, 1.0}, {2, 256, 256, 1.04}, {4, 128, 256, 1.39}, {kPhased256x128, 256, 128, 1.08}};
 constexpr int kNumCfg = 12;
 
 template <int WT>
@@ -575,6 +575,9 @@ static int static_shape_cfg(const GemmParams& p, bool phased_ok = true)
         if (s.id == kPhased256x128 && !phased_ok)
             continue;
         const int64_t tiles = (int64_t) ((p.M + s.bm - 1) / s.bm) * ((p.N + s.bn - 1) / s.bn);
+        // beyond two rounds the 256 x 128 tile loses to 256 x 256 / 256 x 192 (M = 8192: 162 vs 136 us on O, 467 vs 377 on gate / up)
+        if (s.id == kPhased256x128 && tiles > 2 * cus)
+            continue;
         const double cost = (double) ((tiles + cus - 1) / cus) * s.bm * s.bn * s.f;
         if (cost < best)
         {

@@ -397,6 +397,8 @@ int launch_gemm_woq(const GemmParams& p, hipStream_t stream)
         for (const Cand& c : cands)
         {
             const int64_t t = (int64_t) ((p.M + c.bm - 1) / c.bm) * ((p.N + c.bn - 1) / c.bn);
+            if (c.id == 6 && t > 2 * cus)
+                continue; // beyond two rounds 256 x 192 wins again (M = 8192: down 737 vs 845 us)
             const double cost = (double) ((t + cus - 1) / cus) * c.bm * c.bn * c.f;
             if (cost < best)
             {
