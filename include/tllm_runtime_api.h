@@ -203,8 +203,11 @@ typedef struct
 int32_t tllm_gemv(const tllm_gemv_params_t* p, tllm_stream_t stream);
 /* Test/bench knob: persistent workgroups per CU (0 = occupancy query). */
 void tllm_gemv_set_blocks_per_cu(int32_t n);
-/* Test/bench knob: tile shape of the LDS-DMA staged MFMA GEMM (0 = heuristic; 1 = 128x128, 2 = 256x256,
- * 3 = 256x192, 4 = 128x256). */
+/* Test/bench knob: kernel id of the prefill GEMM (0 = tactic table, else the static rule).  1..12: lock-step tile shapes of
+ * kernels/gemm_glds.hip (8 = 128x128, 6 = 256x192, 2 = 256x256, 4 = 128x256 are the production ones); 13..42: the phased
+ * SmoothQuant pipeline of kernels/gemm_sqp.hip (20 = 256x192, 42 = 256x128; 21..33 are ablations with wrong results on
+ * purpose); 50..54: the same pipeline on fp16 operands (50 = 256x192, 54 = 256x128); 101..106: the weight-only kernel of
+ * kernels/gemm_woq.hip (101 = 256x192, 102 = 128x128, 106 = 256x128).  The ids are what tllm_gemm_profile reports. */
 void tllm_gemm_set_tile_cfg(int32_t cfg);
 
 /* Kernel-level entry for the prefill GEMMs (kernels/gemm_mfma.hip; M <= 8 goes to the skinny GEMM):
