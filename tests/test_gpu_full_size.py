@@ -136,6 +136,41 @@ def test_in_launch_attention_merge_equals_the_prologue_merge(mode, layers, monke
                 np.testing.assert_allclose(l0, l1, atol=1e-2)
 
 
+@pytest.mark.parametrize('mode', ['fp16', 'woq8', 'woq4'])
+def test_prefill_epilogue_fusions_are_bit_identical(mode, monkeypatch):
+    """r04 prefill fusions of the fp16 / weight-only paths against the separate passes they replace: SwiGLU folded into the second
+    MLP projection's epilogue (GemmParams::silu_gate; TLLM_NO_SWIGLU_FUSE=1 runs swiglu_kernel) and the residual add folded into
+    the weight-only O / down GEMMs (TLLM_NO_WOQ_RESIDUAL_FUSE=1 runs add_kernel).  Same rounding points (fp16(gemm), fp16(silu),
+    fp16(product) / fp16(sum)): the context logits and the first greedy tokens must be IDENTICAL, at a prefill of one full
+    workgroup round (1024 tokens) and a ragged one (333)."""
+    cfg = dict(bench.LLAMA_7B, num_layers=3)
+    int8_kv = mode != 'fp16'
+    dev = torch.device('cuda', 0)
+    w = bench.synth_weights(torch, cfg, mode, int8_kv, 1, 0, dev)
+    results = {}
+    for fused in (False, True):
+        for k in ('TLLM_NO_SWIGLU_FUSE', 'TLLM_NO_WOQ_RESIDUAL_FUSE'):
+            if fused:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, '1')
+        s = NativeSession(dict(cfg, quant_mode=bench.QM[mode] | (bench.INT8_KV if int8_kv else 0), tp_size=1, tp_rank=0))
+        for k, v in w.items():
+            s.set_tensor(k, v)
+        s.finalize()
+        outs = []
+        for S in (1024, 333):
+            ids = np.random.default_rng(S).integers(3, cfg['vocab_size'], (1, S)).astype(np.int32)
+            s.setup(1, S, 4)
+            toks = s.generate(ids, np.array([S], np.int32), 4)
+            outs.append((toks.copy(), s.logits().copy()))
+        results[fused] = outs
+        s.close()
+    for (t0, l0), (t1, l1) in zip(results[False], results[True]):
+        np.testing.assert_array_equal(t0, t1)
+        np.testing.assert_array_equal(l0, l1)
+
+
 def test_in_launch_attention_merge_beyond_eight_partials():
     """More than 8 split partials (a cache of more than 2048 slots at head size 128): the in-launch merge takes up to 16, the
     prologue form stops at 8 and hands over to the finest split + combine launch - a different split, so fp32 summation order

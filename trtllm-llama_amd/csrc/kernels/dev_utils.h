@@ -58,6 +58,26 @@ __device__ __forceinline__ uint16_t f2h(float f)
     return b;
 }
 
+// SwiGLU with the gate operand already in memory, fused into the epilogue of the OTHER projection: u = this GEMM's finished fp16
+// values, g = the first projection's (8 halfs each).  Same rounding points as the separate pass (pointwise.hip swiglu_kernel;
+// PY/layers/mlp.py:68-73): fp16(silu(g)) then fp16(that * u).
+__device__ __forceinline__ uint16_t silu_mul_h(uint16_t g, uint16_t u)
+{
+    const float gf = h2f(g);
+    const float s = h2f(f2h(gf / (1.f + __expf(-gf))));
+    return f2h(s * h2f(u));
+}
+__device__ __forceinline__ uint4 epi_silu_gate8(const uint4& u, const uint4& g)
+{
+    const uint32_t u4[4] = {u.x, u.y, u.z, u.w}, g4[4] = {g.x, g.y, g.z, g.w};
+    uint32_t o4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        o4[e] = (uint32_t) silu_mul_h((uint16_t) (g4[e] & 0xffffu), (uint16_t) (u4[e] & 0xffffu))
+            | ((uint32_t) silu_mul_h((uint16_t) (g4[e] >> 16), (uint16_t) (u4[e] >> 16)) << 16);
+    return make_uint4(o4[0], o4[1], o4[2], o4[3]);
+}
+
 __device__ __forceinline__ h2_t u32_as_h2(uint32_t u)
 {
     h2_t r;

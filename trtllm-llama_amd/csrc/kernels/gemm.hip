@@ -107,6 +107,19 @@ int launch_gemm(const GemmParams& pin, hipStream_t stream)
         set_error("gemm: the fused residual needs fp16 output");
         return -1;
     }
+    if (pin.silu_gate && (pin.residual || pin.out_dtype != DT_HALF))
+    {
+        set_error("gemm: the fused SwiGLU gate needs fp16 output and excludes the fused residual");
+        return -1;
+    }
+    if (pin.silu_gate && pin.wtype == W_INT8_SQ)
+    {
+        // SmoothQuant has its own fused form (launch_gemm_swiglu); here: the plain product, then the pointwise pass
+        GemmParams q = pin;
+        q.silu_gate = nullptr;
+        const int rc = launch_gemm(q, stream);
+        return rc ? rc : launch_swiglu(pin.c, pin.silu_gate, pin.c, (int64_t) pin.M * pin.N, stream);
+    }
     if (pin.M > 8)
     {
         const bool woq = pin.wtype == W_INT8_WOQ || pin.wtype == W_INT4_WOQ;
@@ -148,6 +161,12 @@ int launch_gemm(const GemmParams& pin, hipStream_t stream)
     // the other paths write the plain product; the residual (if any) is added by a pointwise pass afterwards
     GemmParams p = pin;
     p.residual = nullptr;
+    p.silu_gate = nullptr;
+    if (pin.silu_gate && pin.ldc != pin.N)
+    {
+        set_error("gemm: a strided SwiGLU gate is only supported by the LDS-DMA kernels (M >= 32, aligned operands)");
+        return -1;
+    }
     if (pin.residual && (pin.ldc != pin.N || pin.residual == pin.c))
     {
         set_error("gemm: a strided or in-place residual is only supported by the LDS-DMA kernel (SQ / fp16, K bytes %% 128 == 0, M >= 32)");
@@ -156,6 +175,8 @@ int launch_gemm(const GemmParams& pin, hipStream_t stream)
     auto finish = [&](int rc) {
         if (rc == 0 && pin.residual)
             return launch_add(pin.c, pin.c, pin.residual, (int64_t) pin.M * pin.N, stream);
+        if (rc == 0 && pin.silu_gate)
+            return launch_swiglu(pin.c, pin.silu_gate, pin.c, (int64_t) pin.M * pin.N, stream); // elementwise: in place is fine
         return rc;
     };
     if (p.M > 8)

@@ -424,6 +424,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void gemm_glds_kernel(con
                                 | ((uint32_t) f2h(h2f((uint16_t) (a4[e] >> 16)) + h2f((uint16_t) (b4[e] >> 16))) << 16);
                         v = make_uint4(o4[0], o4[1], o4[2], o4[3]);
                     }
+                    else if (p.silu_gate)
+                        v = epi_silu_gate8(v, *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.silu_gate) + o));
                     *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.c) + o) = v;
                 }
             }
@@ -550,6 +552,10 @@ static bool glds_serves(const GemmParams& p)
         return false;
     if (p.residual && (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)))
         return false; // the fused residual lives in the vector epilogue
+    if (p.silu_gate
+        && (sq || p.residual || p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.silu_gate) & 15)))
+        return false; // so does the fused SwiGLU gate (fp16 operands only)
     return true;
 }
 

@@ -564,6 +564,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                             | ((uint32_t) f2h(h2f((uint16_t) (a4[e] >> 16)) + h2f((uint16_t) (b4[e] >> 16))) << 16);
                     v = make_uint4(o4[0], o4[1], o4[2], o4[3]);
                 }
+                else if (F16 && p.silu_gate)
+                    v = epi_silu_gate8(v, *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.silu_gate) + o));
                 if (ABL & 16)
                 {
                     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -658,7 +660,7 @@ int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
 {
     GemmParams p = pin;
     p.clock_probe = gemm_clock_probe;
-    if (p.wtype != W_INT8_SQ)
+    if (p.wtype != W_INT8_SQ || p.silu_gate)
         return 1;
     if ((reinterpret_cast<uintptr_t>(p.a) & 15) || (p.lda & 15) || (reinterpret_cast<uintptr_t>(p.w) & 15) || (p.ldw & 15)
         || (p.K % 128) || p.K <= 0 || p.M < 32)
@@ -716,6 +718,10 @@ int launch_gemm_f16p(const GemmParams& pin, int cfg, hipStream_t stream)
         return 1; // 32-bit DMA offsets
     if (p.residual && p.out_dtype != DT_HALF)
         return 1;
+    if (p.silu_gate
+        && (p.residual || p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.silu_gate) & 15)))
+        return 1; // the fused SwiGLU gate lives in the vector epilogue
     switch (cfg)
     {
     case 50: return launch_sqp<4, 2, 2, 3, 0, 6, false, 16, 0, false, false, true>(p, stream); // 256 x 192, non-temporal stores

@@ -279,6 +279,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_woq_kernel(const GemmParams
                                 | ((uint32_t) f2h(h2f((uint16_t) (a4[e] >> 16)) + h2f((uint16_t) (b4[e] >> 16))) << 16);
                         v = make_uint4(o4[0], o4[1], o4[2], o4[3]);
                     }
+                    else if (p.silu_gate)
+                        v = epi_silu_gate8(v, *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.silu_gate) + o));
                     *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.c) + o) = v;
                 }
             }
@@ -371,6 +373,10 @@ int launch_gemm_woq(const GemmParams& p, hipStream_t stream)
         return 1;
     if (p.residual && (p.out_dtype != DT_HALF))
         return 1;
+    if (p.silu_gate
+        && (p.residual || p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.silu_gate) & 15)))
+        return 1; // the fused SwiGLU gate lives in the vector epilogue
     int cfg = gemm_woq_tune_cfg;
     if (cfg <= 0)
     {

@@ -252,6 +252,9 @@ struct GemmParams
     void* c = nullptr;
     int64_t ldc = 0;
     const void* residual = nullptr; // optional fp16 [M, ldc]: C = fp16(fp16(gemm) + residual) (may alias c); fp16 output only
+    // optional fp16 [M, ldc] (fp16 / weight-only weights, fp16 output, not together with residual): C = fp16(fp16(silu(gate)) * fp16(gemm)) -
+    // the SwiGLU pass of the prefill MLP folded into the second projection (may alias c)
+    const void* silu_gate = nullptr;
     // SmoothQuant dual GEMM (prefill MLP, static activation scales): w2 / scale_col2 = the second weight matrix [N, ldw] and
     // its per-channel scales; c = int8 [M, ldc] = sat(rni(fp16(silu16(A W^T) * fp16(A W2^T)) * swiglu_qscale[0])) with the
     // fp16 rounding points of the un-fused path (two fp16 GEMM outputs, SwiGLU in fp16, static quantiser); launch_gemm_swiglu

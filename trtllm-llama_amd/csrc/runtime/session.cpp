@@ -491,10 +491,11 @@ struct tllm_session
 
     // context: plain GEMM on M rows (activation already in the operand type)
     int gemm(const Linear& L, int M, const void* a, const float* scale_row, int per_tok, void* c, int out_dtype,
-        hipStream_t st, const void* residual = nullptr)
+        hipStream_t st, const void* residual = nullptr, const void* silu_gate = nullptr)
     {
         GemmParams g;
         g.residual = residual;
+        g.silu_gate = silu_gate;
         g.scratch = woq_scratch; // weight-only prefill: room for the fp16 expansion of the largest weight matrix
         g.wtype = L.wtype;
         g.out_dtype = out_dtype;
@@ -654,9 +655,14 @@ struct tllm_session
                     RUN(launch_quantize_tensor(q8, ctx, DT_HALF, (int64_t) M * Dr, L.attn_qscale, st));
                 d_in = q8;
             }
-            const bool fuse_res = tp == 1 && !force_comm && M >= 32 && (L.dense.wtype == W_INT8_SQ || L.dense.wtype == W_FP16)
-                && (L.dense.K * (L.dense.wtype == W_FP16 ? 2 : 1)) % 128 == 0 && (L.proj.K * (L.proj.wtype == W_FP16 ? 2 : 1)) % 128 == 0
-                && D % 8 == 0;
+            // (weight-only: gemm_woq.hip adds the residual in its epilogue too - same two roundings; its own serve conditions)
+            const bool woq_w = L.dense.wtype == W_INT8_WOQ || L.dense.wtype == W_INT4_WOQ;
+            static const bool woq_expand = getenv("TLLM_WOQ_EXPAND") != nullptr;
+            const bool fuse_res = tp == 1 && !force_comm && M >= 32 && D % 8 == 0
+                && (woq_w ? (!woq_expand && !getenv("TLLM_NO_WOQ_RESIDUAL_FUSE") && L.dense.K % 64 == 0 && L.proj.K % 64 == 0)
+                          : ((L.dense.wtype == W_INT8_SQ || L.dense.wtype == W_FP16)
+                              && (L.dense.K * (L.dense.wtype == W_FP16 ? 2 : 1)) % 128 == 0
+                              && (L.proj.K * (L.proj.wtype == W_FP16 ? 2 : 1)) % 128 == 0));
             if (fuse_res)
             {
                 // x <- x + O(ctx): residual fused into the GEMM epilogue (same rounding: fp16(gemm) then fp16(sum))
@@ -728,6 +734,15 @@ struct tllm_session
             else
             {
             RUN(gemm(L.fc, M, a_in, sq && per_token ? qscale : nullptr, sq && per_token, g, DT_HALF, st));
+            const bool no_gate_fuse = getenv("TLLM_NO_SWIGLU_FUSE") != nullptr;
+            if (!sq && !no_gate_fuse)
+            {
+                // fp16 / weight-only: SwiGLU folded into the second projection's epilogue (g is read there instead of in a pass of
+                // its own; same rounding points) - one launch and a [M, Ir] write + read fewer per layer
+                RUN(gemm(L.gate, M, a_in, nullptr, 0, inter_buf, DT_HALF, st, nullptr, g));
+            }
+            else
+            {
             RUN(gemm(L.gate, M, a_in, sq && per_token ? qscale : nullptr, sq && per_token, u, DT_HALF, st));
             if (sq && !per_token)
             {
@@ -742,6 +757,7 @@ struct tllm_session
                     RUN(launch_quantize_per_token(q8, inter_buf, DT_HALF, M, Ir, qscale, st));
                     p_in = q8;
                 }
+            }
             }
             }
             if (fuse_res)
