@@ -766,3 +766,66 @@ def test_gemm_clock_probe_reports_a_plausible_shader_clock():
         run_plugin(p, [a.cuda(), w.cuda(), sa.cuda(), sb.cuda()], [out])
         torch.cuda.synchronize()
         assert int(probe.abs().sum().item()) == 0
+
+
+# ---------------------------------------------------------------------------------------------- decode GEMM on the matrix pipe
+class _GemvParams(ctypes.Structure):
+    _fields_ = [('wtype', ctypes.c_int32), ('pro', ctypes.c_int32), ('epi', ctypes.c_int32), ('out_dtype', ctypes.c_int32),
+                ('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('x', ctypes.c_void_p), ('ldx', ctypes.c_int64),
+                ('w', ctypes.c_void_p), ('ldw', ctypes.c_int64), ('scale_col', ctypes.c_void_p), ('scale_row', ctypes.c_void_p),
+                ('per_channel', ctypes.c_int32), ('per_token', ctypes.c_int32), ('gamma', ctypes.c_void_p), ('eps', ctypes.c_float),
+                ('act_scale', ctypes.c_void_p), ('dyn_scale_out', ctypes.c_void_p), ('x_pro_out', ctypes.c_void_p),
+                ('residual', ctypes.c_void_p), ('epi_scale', ctypes.c_void_p), ('y', ctypes.c_void_p), ('ldy', ctypes.c_int64)]
+
+
+@pytest.mark.parametrize('per_channel', [1, 0])
+@pytest.mark.parametrize('m,n,k,pro,epi', [
+    (8, 12288, 4096, 2, 0),    # RMSNorm + static quantiser -> QKV
+    (5, 4096, 4096, 0, 1),     # int8 context -> O + residual
+    (8, 11008, 4096, 2, 3),    # RMSNorm + quantiser -> gate | up -> SwiGLU -> static quantiser
+    (3, 11008, 4096, 2, 2),    # ... fp16 SwiGLU output
+    (8, 4096, 11008, 0, 1),    # int8 intermediate -> down + residual (43 k-steps per wave: a ragged last batch)
+    (4, 5120, 5120, 2, 0),     # 13B hidden size: the 6-vector RMSNorm bucket
+    (6, 512, 256, 0, 0),       # one k-step per wave, fewer row groups than CUs
+    (8, 1024, 13824, 0, 1),    # 13B down-projection rows (124 KB of LDS)
+])
+def test_mfma_skinny_gemm_equals_the_valu_kernel(m, n, k, pro, epi, per_channel, lib):
+    """The SmoothQuant decode GEMM for several sequences on v_mfma_i32_16x16x64_i8 (kernels/gemv_mfma_sq.hip, r04) against the
+    skinny vector-ALU kernel it replaces from 3 rows on (kernels/gemv_impl.h): exact int32 sums and the same rounding points in
+    prologue and epilogue, so every output must be IDENTICAL - for every prologue / epilogue the decode step uses, per-channel and
+    per-tensor scales, ragged K batches, and M from 3 to 8.  (The VALU kernel itself is held to the oracle by the tests above.)"""
+    lib.tllm_gemv.argtypes = [ctypes.POINTER(_GemvParams), ctypes.c_void_p]
+    lib.tllm_gemv.restype = ctypes.c_int32
+    lib.tllm_gemv_set_mfma_rows.argtypes = [ctypes.c_int32]
+    lib.tllm_gemv_set_mfma_rows.restype = None
+    g = torch.Generator(device='cuda').manual_seed(m * 1000 + n + k + pro + epi)
+    swiglu = epi in (2, 3)
+    rows = 2 * n if swiglu else n
+    w = torch.randint(-127, 128, (rows, k), dtype=torch.int8, device='cuda', generator=g)
+    sc = (torch.rand(rows if per_channel else 1, device='cuda', generator=g) * 2e-3 + 1e-4).float()
+    srow = torch.tensor([0.013], device='cuda')
+    if pro == 2:
+        x = (torch.randn((m, k), device='cuda', generator=g) * 1.7).half()
+        gamma = (torch.rand(k, device='cuda', generator=g) + 0.5).half()
+        act = torch.tensor([37.0], device='cuda')
+    else:
+        x = torch.randint(-127, 128, (m, k), dtype=torch.int8, device='cuda', generator=g)
+        gamma = act = None
+    res = torch.randn((m, n), device='cuda', generator=g).half() if epi == 1 else None
+    epi_q = torch.tensor([21.0], device='cuda') if epi == 3 else None
+    outs = []
+    try:
+        for rows_from in (0, 2):  # 0: the vector-ALU kernel; 2: the matrix-pipe kernel for every M >= 2
+            lib.tllm_gemv_set_mfma_rows(rows_from)
+            y = torch.full((m, n), 7, dtype=torch.int8 if epi == 3 else torch.float16, device='cuda')
+            q = _GemvParams(3, pro, epi, 2 if epi == 3 else 1, m, n, k, x.data_ptr(), k, w.data_ptr(), k, sc.data_ptr(), srow.data_ptr(),
+                            per_channel, 0, gamma.data_ptr() if gamma is not None else None, 1e-6,
+                            act.data_ptr() if act is not None else None, None, None, res.data_ptr() if res is not None else None,
+                            epi_q.data_ptr() if epi_q is not None else None, y.data_ptr(), n)
+            assert lib.tllm_gemv(ctypes.byref(q), torch.cuda.current_stream().cuda_stream) == 0, capi.last_error()
+            torch.cuda.synchronize()
+            outs.append(y.cpu().numpy().view(np.int8 if epi == 3 else np.uint16).copy())
+    finally:
+        lib.tllm_gemv_set_mfma_rows(-1)
+    assert np.abs(outs[0].astype(np.int64)).sum() > 0
+    np.testing.assert_array_equal(outs[0], outs[1])

@@ -26,7 +26,7 @@ for k, v in w.items():
 sess.finalize()
 stream = torch.cuda.current_stream().cuda_stream
 K = 64
-for B in (1, 2, 4, 8):
+for B in [int(b) for b in os.environ.get("BATCHES", "1,2,4,8").split(",")]:
     sess.setup(B, ctx, 2 * K + 16)
     sess.fake_context(ctx, seed=1, stream=stream)
     sess.step(2, use_graph=False, stream=stream)

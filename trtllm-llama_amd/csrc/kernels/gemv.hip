@@ -19,6 +19,13 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
         return -1;
     }
     const bool sq = p.wtype == W_INT8_SQ;
+    if (sq && p.M >= 2)
+    {
+        // several sequences: the skinny kernel's vector-ALU work grows with the rows, the matrix pipe's does not (gemv_mfma_sq.hip)
+        const int r = launch_gemv_mfma_sq(p, stream);
+        if (r <= 0)
+            return r;
+    }
     // The kernel keeps the activation rows of its row bucket (1 / 2 / 4 / 8) in LDS: 8 rows of an fp16 K = 11008 vector are 176 KB -
     // more than a CU has (LLaMA-7B's down-projection at batch 5 .. 8, every LLaMA's at 13B and beyond).  Such a call goes through
     // in slabs of as many rows as fit, each slab streaming the weights again (r04; before, it was refused).

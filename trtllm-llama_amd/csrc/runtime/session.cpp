@@ -40,6 +40,7 @@ namespace tllm
 namespace kernels
 {
 extern int gemv_tune_blocks_per_cu;
+extern int gemv_mfma_min_rows;
 extern int gemm_tune_cfg;
 extern int gemm_woq_tune_cfg;
 extern void* gemm_clock_probe;
@@ -2233,6 +2234,11 @@ int32_t tllm_gemm_tactic_lookup(int32_t wtype, int32_t M, int32_t N, int32_t K)
 void tllm_gemv_set_blocks_per_cu(int32_t n)
 {
     tllm::kernels::gemv_tune_blocks_per_cu = n;
+}
+
+void tllm_gemv_set_mfma_rows(int32_t n)
+{
+    tllm::kernels::gemv_mfma_min_rows = n;
 }
 
 int32_t tllm_gemm_swiglu_quant(const tllm_gemm_params_t* q, const void* w_up, const void* scale_col_up, const float* quant_scale,
