@@ -21,7 +21,8 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     const bool sq = p.wtype == W_INT8_SQ;
     if (sq && p.M >= 2)
     {
-        // several sequences: the skinny kernel's vector-ALU work grows with the rows, the matrix pipe's does not (gemv_mfma_sq.hip)
+        // several sequences on the matrix pipe (gemv_mfma_sq.hip): an experiment, off unless TLLM_GEMV_MFMA_ROWS / tllm_gemv_set_mfma_rows
+        // ask for it - returns 1 at once otherwise
         const int r = launch_gemv_mfma_sq(p, stream);
         if (r <= 0)
             return r;

@@ -1,16 +1,24 @@
-// SmoothQuant decode GEMM for SEVERAL sequences (3 <= M <= 8 rows, static activation scales) on the matrix pipe.
+// SmoothQuant decode GEMM for SEVERAL sequences (2 <= M <= 8 rows, static activation scales) on the matrix pipe - an EXPERIMENT, off by
+// default (TLLM_GEMV_MFMA_ROWS=<rows> or tllm_gemv_set_mfma_rows turn it on): exact, and not faster than the skinny kernel (below).
 //
 //   y[m, n] = epi( float(sum_k x8[m, k] * W[n, k]) * (s_col[n] * s_row) )        x8 = the int8 rows, or sat(rni(RMSNorm(x) * s))
 //
-// Why: the skinny kernel of gemv_impl.h spends one v_dot4 per row and 16 weight bytes plus a 64-lane reduction per row and output -
-// at 8 rows its layer GEMVs take 23.8 us where one row takes 12.4 (profiles/r04_batch_sweep.txt): the vector ALUs, not HBM, bound
-// the step.  Here a wave owns 16 weight rows: v_mfma_i32_16x16x64_i8 takes 16 B per lane of W (row = lane & 15, k-bytes
+// Why it was built: the skinny kernel of gemv_impl.h spends one v_dot4 per row and 16 weight bytes plus a 64-lane reduction per row
+// and output - at 8 rows its layer GEMVs take 23.8 us where one row takes 12.4 (profiles/r04_batch_sweep.txt): the vector ALUs, not
+// HBM, bound the step.  Here a wave owns 16 weight rows: v_mfma_i32_16x16x64_i8 takes 16 B per lane of W (row = lane & 15, k-bytes
 // (lane >> 4) * 16 of a 64-byte k-step: ONE 16-byte load per lane, no LDS on the weight side) against the activation rows from LDS in
 // the same geometry (rows >= M read a zero row), and leaves lane (m = lane & 15) four consecutive outputs n = 4 (lane >> 4) + e:
 // no cross-lane reduction at all, one MFMA per KiB of weights.  The four waves of a workgroup split K (k-step i of wave w is
 // 64-byte step 4 i + w: the workgroup reads 256 contiguous bytes per row), their int32 partials meet in LDS (exact, order-free) and
-// wave 0 finishes the 16 x M outputs while the others already stream the next row group.  Persistent: one workgroup per CU, the
-// prologue (the rows into LDS, normalised + quantised when asked) once per workgroup.
+// wave 0 finishes the 16 x M outputs while the others already stream the next row group.  Persistent, the prologue (the rows into
+// LDS, normalised + quantised when asked) once per workgroup.
+//
+// What it measures (profiles/r04_gemv_mfma.txt): its time hardly depends on M any more (QKV 19.5 us at 4 rows, 24.8 at 8 - the
+// difference is the RMSNorm prologue, ~1.3 us per row), but the weights arrive at 2.7 TB/s where the skinny kernel streams at 7: a
+// load instruction whose lanes ARE the MFMA fragment touches 16 rows x 64 bytes (the guide's "fragment-shaped loads are TA-bound"), and
+// neither 32 KB per wave in flight nor 2 - 3 workgroups per CU change that.  At 8 rows it equals the skinny kernel (QKV 24.8 vs
+// 22.9 us, gate|up 32.7 vs 32.6, down 17.4 vs 16.7), below it loses.  The form that would win stages the weights with LDS-DMA in
+// 4-row x 256-byte instructions (16-byte pieces rotated by the row so that the fragment reads are conflict-free) - DESIGN.md section 4.
 //
 // Arithmetic = gemv_impl.h's, stage by stage (same RMSNorm summation order, same rounding points, exact integer sums), so the
 // results are bit-identical to the skinny kernel's - tests/test_gpu_plugins.py::test_mfma_skinny_gemm_equals_the_valu_kernel.
@@ -32,7 +40,6 @@ namespace
 {
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRows = 8; // activation rows in LDS; row kRows is all zeros
-constexpr int kNB = 8;   // 64-byte k-steps per register batch (8 loads in flight per wave and matrix, double-buffered)
 
 __device__ __forceinline__ float silu_mul_fp16_(float g, float u)
 {
@@ -47,6 +54,8 @@ __device__ __forceinline__ float silu_mul_fp16_(float g, float u)
 template <int NXV, bool SWIGLU>
 __global__ __launch_bounds__(256) void gemv_mfma_sq_kernel(const GemvParams p, int pitch, int ngroups)
 {
+    // 64-byte k-steps per register batch: 16 KB per wave in flight per batch either way (one matrix x 16 loads, or two x 8), double-buffered
+    constexpr int kNB = SWIGLU ? 8 : 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NACC = SWIGLU ? 2 : 1;
     float* red = reinterpret_cast<float*>(smem);
@@ -328,7 +337,7 @@ int launch_gemv_mfma_sq(const GemvParams& p, hipStream_t stream)
     if (gemv_mfma_min_rows < 0)
     {
         const char* e = getenv("TLLM_GEMV_MFMA_ROWS");
-        gemv_mfma_min_rows = e ? atoi(e) : 3;
+        gemv_mfma_min_rows = e ? atoi(e) : 0; // off unless asked for: measured equal at 8 rows, slower below (header)
     }
     if (gemv_mfma_min_rows <= 0 || p.M < gemv_mfma_min_rows || p.M > kRows || p.wtype != W_INT8_SQ)
         return 1;
@@ -372,7 +381,11 @@ int launch_gemv_mfma_sq(const GemvParams& p, hipStream_t stream)
         cus_cache.store(cus);
     }
     const int ngroups = p.N / 16;
-    const int grid = ngroups < cus ? ngroups : cus;
+    // workgroups per CU: as many as the LDS holds, up to 2 (measured best of 1 / 2 / 3; each repeats the prologue)
+    static const int wgs_env = getenv("TLLM_GEMV_MFMA_WGS") ? atoi(getenv("TLLM_GEMV_MFMA_WGS")) : 2;
+    int wgs = (int) ((size_t) 160 * 1024 / smem);
+    wgs = wgs < 1 ? 1 : (wgs > wgs_env ? wgs_env : wgs);
+    const int grid = ngroups < cus * wgs ? ngroups : cus * wgs;
     if (!norm)
         return swiglu ? launch_inst<0, true>(p, pitch, ngroups, grid, smem, stream) : launch_inst<0, false>(p, pitch, ngroups, grid, smem, stream);
     if (p.K <= 256 * 8 * kNXVSmall)
