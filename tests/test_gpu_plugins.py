@@ -791,9 +791,9 @@ class _GemvParams(ctypes.Structure):
 ])
 def test_mfma_skinny_gemm_equals_the_valu_kernel(m, n, k, pro, epi, per_channel, lib):
     """The SmoothQuant decode GEMM for several sequences on v_mfma_i32_16x16x64_i8 (kernels/gemv_mfma_sq.hip, r04) against the
-    skinny vector-ALU kernel (kernels/gemv_impl.h; the production path - the matrix-pipe form is an opt-in experiment): exact int32 sums and the same rounding points in
+    skinny vector-ALU kernel (kernels/gemv_impl.h) that it replaces from 5 rows on: exact int32 sums and the same rounding points in
     prologue and epilogue, so every output must be IDENTICAL - for every prologue / epilogue the decode step uses, per-channel and
-    per-tensor scales, ragged K batches, and M from 3 to 8.  (The VALU kernel itself is held to the oracle by the tests above.)"""
+    per-tensor scales, K blocks that do not divide by the four waves, and M from 3 to 8.  (The VALU kernel itself is held to the oracle by the tests above.)"""
     lib.tllm_gemv.argtypes = [ctypes.POINTER(_GemvParams), ctypes.c_void_p]
     lib.tllm_gemv.restype = ctypes.c_int32
     lib.tllm_gemv_set_mfma_rows.argtypes = [ctypes.c_int32]

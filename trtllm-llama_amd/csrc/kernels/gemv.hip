@@ -21,8 +21,8 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     const bool sq = p.wtype == W_INT8_SQ;
     if (sq && p.M >= 2)
     {
-        // several sequences on the matrix pipe (gemv_mfma_sq.hip): an experiment, off unless TLLM_GEMV_MFMA_ROWS / tllm_gemv_set_mfma_rows
-        // ask for it - returns 1 at once otherwise
+        // several sequences: from 5 rows on (TLLM_GEMV_MFMA_ROWS) the matrix-pipe kernel, whose time hardly grows with the rows
+        // (gemv_mfma_sq.hip; bit-identical results) - returns 1 at once below its threshold or for a prologue it does not build
         const int r = launch_gemv_mfma_sq(p, stream);
         if (r <= 0)
             return r;

@@ -48,8 +48,8 @@ int launch_gemv_fp16(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream)
 int launch_gemv_woq8(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
 int launch_gemv_woq4(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
 int launch_gemv_sq(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
-// SmoothQuant, several rows (2 <= M <= 8), static activation scales: the matrix-pipe kernel (gemv_mfma_sq.hip, experiment); 1 = not served
-extern int gemv_mfma_min_rows; // rows from which launch_gemv tries it (0 = never = the default; -1 = re-read TLLM_GEMV_MFMA_ROWS on next use)
+// SmoothQuant, several rows (2 <= M <= 8), static activation scales: the matrix-pipe kernel (gemv_mfma_sq.hip); 1 = not served
+extern int gemv_mfma_min_rows; // rows from which launch_gemv tries it (0 = never; -1 = TLLM_GEMV_MFMA_ROWS or the default 5, read on next use)
 int launch_gemv_mfma_sq(const GemvParams& p, hipStream_t stream);
 // "few rows, long K" single-token projections, every weight type (gemv_ksplit.hip)
 bool gemv_ksplit_applies(const GemvArgs& a);

@@ -1,24 +1,23 @@
-// SmoothQuant decode GEMM for SEVERAL sequences (2 <= M <= 8 rows, static activation scales) on the matrix pipe - an EXPERIMENT, off by
-// default (TLLM_GEMV_MFMA_ROWS=<rows> or tllm_gemv_set_mfma_rows turn it on): exact, and not faster than the skinny kernel (below).
+// SmoothQuant decode GEMM for SEVERAL sequences (5 <= M <= 8 rows by default, static activation scales) on the matrix pipe.
+// TLLM_GEMV_MFMA_ROWS=<rows> / tllm_gemv_set_mfma_rows move the threshold (0 = never).
 //
 //   y[m, n] = epi( float(sum_k x8[m, k] * W[n, k]) * (s_col[n] * s_row) )        x8 = the int8 rows, or sat(rni(RMSNorm(x) * s))
 //
-// Why it was built: the skinny kernel of gemv_impl.h spends one v_dot4 per row and 16 weight bytes plus a 64-lane reduction per row
-// and output - at 8 rows its layer GEMVs take 23.8 us where one row takes 12.4 (profiles/r04_batch_sweep.txt): the vector ALUs, not
-// HBM, bound the step.  Here a wave owns 16 weight rows: v_mfma_i32_16x16x64_i8 takes 16 B per lane of W (row = lane & 15, k-bytes
-// (lane >> 4) * 16 of a 64-byte k-step: ONE 16-byte load per lane, no LDS on the weight side) against the activation rows from LDS in
-// the same geometry (rows >= M read a zero row), and leaves lane (m = lane & 15) four consecutive outputs n = 4 (lane >> 4) + e:
-// no cross-lane reduction at all, one MFMA per KiB of weights.  The four waves of a workgroup split K (k-step i of wave w is
-// 64-byte step 4 i + w: the workgroup reads 256 contiguous bytes per row), their int32 partials meet in LDS (exact, order-free) and
-// wave 0 finishes the 16 x M outputs while the others already stream the next row group.  Persistent, the prologue (the rows into
-// LDS, normalised + quantised when asked) once per workgroup.
+// Why: the skinny kernel of gemv_impl.h spends one v_dot4 per row and 16 weight bytes plus a 64-lane reduction per row and output -
+// at 8 rows its layer GEMVs take 23.8 us where one row takes 12.4 (profiles/r04_batch_sweep.txt): the vector ALUs, not HBM, bound
+// the step.  Here a wave owns 16 weight rows: v_mfma_i32_16x16x64_i8 takes 16 B per lane of W (row = lane & 15, k-bytes
+// (lane >> 4) * 16 of a 64-byte k-step) against the activation rows from LDS in the same geometry (rows >= M read a zero row), and
+// leaves lane (m = lane & 15) four consecutive outputs n = 4 (lane >> 4) + e: no cross-lane reduction at all, one MFMA per KiB of
+// weights.  The four waves of a workgroup split K (256-byte block j of a row group goes to wave j & 3), their int32 partials meet in
+// LDS (exact, order-free) and wave 0 finishes the 16 x M outputs while the others already stream the next row group.  Persistent, one
+// workgroup per CU; the prologue (the rows into LDS, normalised + quantised when asked) once per workgroup.
 //
-// What it measures (profiles/r04_gemv_mfma.txt): its time hardly depends on M any more (QKV 19.5 us at 4 rows, 24.8 at 8 - the
-// difference is the RMSNorm prologue, ~1.3 us per row), but the weights arrive at 2.7 TB/s where the skinny kernel streams at 7: a
-// load instruction whose lanes ARE the MFMA fragment touches 16 rows x 64 bytes (the guide's "fragment-shaped loads are TA-bound"), and
-// neither 32 KB per wave in flight nor 2 - 3 workgroups per CU change that.  At 8 rows it equals the skinny kernel (QKV 24.8 vs
-// 22.9 us, gate|up 32.7 vs 32.6, down 17.4 vs 16.7), below it loses.  The form that would win stages the weights with LDS-DMA in
-// 4-row x 256-byte instructions (16-byte pieces rotated by the row so that the fragment reads are conflict-free) - DESIGN.md section 4.
+// The weights come through a private LDS ring per wave, filled by LDS-DMA (see the kernel's comment).  The first version loaded the
+// MFMA fragments straight into registers - one 16-byte load per lane, i.e. 16 rows x 64 bytes per instruction: exact, and the weights
+// arrived at 2.7 TB/s (the guide's TA-bound fragment-shaped load; 32 KB per wave in flight and 1 / 2 / 3 workgroups per CU changed
+// nothing).  With 4-row x 256-byte DMA instructions they arrive at ~3.6 - 4.8 TB/s - still short of the skinny kernel's 7 (a deeper ring
+// does not help; 256-byte runs of rows 4 - 11 KB apart are what the memory sees), which is why this kernel only wins where the skinny
+// one is ALU-bound: profiles/r04_gemv_mfma.txt - 8 sequences 2208 -> 2318 tokens/s, 6: 1829 -> 1920, 5: 1593 -> 1697, 4: 1604 -> 1455 (so: from 5 on).
 //
 // Arithmetic = gemv_impl.h's, stage by stage (same RMSNorm summation order, same rounding points, exact integer sums), so the
 // results are bit-identical to the skinny kernel's - tests/test_gpu_plugins.py::test_mfma_skinny_gemm_equals_the_valu_kernel.
@@ -29,6 +28,7 @@
 #include "kernels.h"
 #include <atomic>
 #include <cstdlib>
+#include <type_traits>
 
 namespace tllm
 {
@@ -50,46 +50,66 @@ __device__ __forceinline__ float silu_mul_fp16_(float g, float u)
     return h2f(f2h(a * u16));
 }
 
-// NXV = 0: int8 activations as given (PRO_NONE); else RMSNorm + static quantiser, a thread keeps NXV 16-byte vectors of a row
-template <int NXV, bool SWIGLU>
+// one LDS-DMA instruction: 64 lanes x 16 bytes, global (wave-uniform base + per-lane 32-bit offset) -> LDS [lds_byte + lane * 16]
+__device__ __forceinline__ void glds16(const char* base, uint32_t off, uint32_t lds_byte)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
+}
+
+// NXV = 0: int8 activations as given (PRO_NONE); else RMSNorm + static quantiser, a thread keeps NXV 16-byte vectors of a row.
+// D = slots of a wave's weight ring.  A slot = one 256-byte K block of the wave's 16 rows (4 KB; SwiGLU: gate + up, 8 KB), filled by
+// LDS-DMA instructions of 4 rows x 256 contiguous bytes (whole 128-byte lines - the register form's 16 rows x 64 bytes per instruction
+// streamed at 2.7 TB/s); lane l of instruction i fetches piece ((l & 15) + row) & 15 of row = 4 i + (l >> 4): the 16-byte pieces of a row
+// are ROTATED by the row index, so that the fragment read of the 16 rows at one k position (piece c: slot (c - row) & 15) falls on
+// 16 different bank groups.
+template <int NXV, bool SWIGLU, int D>
 __global__ __launch_bounds__(256) void gemv_mfma_sq_kernel(const GemvParams p, int pitch, int ngroups)
 {
-    // 64-byte k-steps per register batch: 16 KB per wave in flight per batch either way (one matrix x 16 loads, or two x 8), double-buffered
-    constexpr int kNB = SWIGLU ? 8 : 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NACC = SWIGLU ? 2 : 1;
+    constexpr int NI = SWIGLU ? 8 : 4;       // DMA instructions per block
+    constexpr int SLOT = NI * 1024;          // bytes
     float* red = reinterpret_cast<float*>(smem);
     i32x4* racc = reinterpret_cast<i32x4*>(smem + kRedBytes); // [parity][NACC][4 waves][64 lanes]
-    char* xs = smem + kRedBytes + 2 * NACC * 4 * 64 * 16;      // [kRows + 1][pitch] s8
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int RING_OFF = kRedBytes + 2 * NACC * 4 * 64 * 16;
+    char* xs = smem + RING_OFF + 4 * D * SLOT;                 // [kRows + 1][pitch] s8
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: M0 and DMA bases
     const int K = p.K, M = p.M;
 
-    // ---- this wave's weight stream: row group g(i) = blockIdx.x + i * gridDim.x, batches of kNB k-steps
+    // ---- this wave's weight stream: row group g(i) = blockIdx.x + i * gridDim.x; of a group's K / 256 blocks this wave takes w, w + 4, ..
     const int r16 = lane & 15, g4 = lane >> 4;
-    const int steps = K / 256;                  // k-steps per wave
-    const int nb = (steps + kNB - 1) / kNB;     // batches per group
+    const int KB = K / 256;
+    const int nblk = (KB - wid + 3) / 4; // may be 0 (K < 1024): the wave still meets the others at the group's barrier
     const int ngroups_mine = (int) blockIdx.x < ngroups ? (ngroups - (int) blockIdx.x + (int) gridDim.x - 1) / (int) gridDim.x : 0;
-    const int nbatches = ngroups_mine * nb;
+    const int total = ngroups_mine * nblk;
     const char* wbase = reinterpret_cast<const char*>(p.w);
     const char* ubase = p.w_up ? reinterpret_cast<const char*>(p.w_up) : wbase + (int64_t) p.N * p.ldw;
-    const int64_t lane_off = (int64_t) r16 * p.ldw + g4 * 16;
-    uint4 wa[kNB], wb[kNB], ua[SWIGLU ? kNB : 1], ub[SWIGLU ? kNB : 1];
-    auto issue = [&](int t, uint4 (&wv)[kNB], uint4 (&uv)[SWIGLU ? kNB : 1]) {
-        const int gi = t / nb, b = t - gi * nb;
-        const int64_t row0 = (int64_t) ((int) blockIdx.x + gi * (int) gridDim.x) * 16 * p.ldw + lane_off;
+    const int ring_off = RING_OFF + wid * D * SLOT; // this wave's ring inside the dynamic LDS
+    const uint32_t ring = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void*) (smem + ring_off); // its LDS byte address (M0)
+    // DMA source of this lane inside an instruction: row (lane >> 4) of the instruction's four, piece rotated by the row
+    uint32_t dma_off[4];
 #pragma unroll
-        for (int i = 0; i < kNB; ++i)
+    for (int i = 0; i < 4; ++i)
+    {
+        const int row = 4 * i + (lane >> 4);
+        dma_off[i] = (uint32_t) row * (uint32_t) p.ldw + (uint32_t) (((lane & 15) + row) & 15) * 16u;
+    }
+    auto issue = [&](int q) {
+        const int gi = q / nblk, j = q - gi * nblk;
+        const int64_t goff = (int64_t) ((int) blockIdx.x + gi * (int) gridDim.x) * 16 * p.ldw + (int64_t) (j * 4 + wid) * 256;
+        const uint32_t slot = ring + (uint32_t) (q % D) * SLOT;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            glds16(wbase + goff, dma_off[i], slot + i * 1024);
+        if constexpr (SWIGLU)
         {
-            int s = b * kNB + i;
-            s = s < steps ? s : steps - 1; // clamped: a valid address, met by a zero activation fragment below
-            const int64_t off = row0 + (int64_t) (s * 4 + wid) * 64;
-            wv[i] = ld_nt16(wbase + off);
-            if constexpr (SWIGLU)
-                uv[i] = ld_nt16(ubase + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                glds16(ubase + goff, dma_off[i], slot + 4096 + i * 1024);
         }
     };
-    if (nbatches > 0)
-        issue(0, wa, ua); // before the prologue: the first weights do not depend on x
+    for (int q = 0; q < D - 1 && q < total; ++q)
+        issue(q); // before the prologue: the first weights do not depend on x
 
     // ---- prologue: the activation rows (and a zero row) into LDS
     for (int k = tid * 16; k < pitch; k += 256 * 16)
@@ -187,24 +207,9 @@ __global__ __launch_bounds__(256) void gemv_mfma_sq_kernel(const GemvParams p, i
     const float epi_q = (SWIGLU && p.epi == EPI_SWIGLU_QSTATIC) ? p.epi_scale[0] : 1.f;
     int par = 0;
 
-    auto consume = [&](int t, const uint4 (&wv)[kNB], const uint4 (&uv)[SWIGLU ? kNB : 1]) {
-        const int gi = t / nb, b = t - gi * nb;
-#pragma unroll
-        for (int i = 0; i < kNB; ++i)
-        {
-            const int s = b * kNB + i;
-            const bool ok = s < steps;
-            const int sc_ = ok ? s : steps - 1;
-            const uint4 xr = *reinterpret_cast<const uint4*>(xlane + (size_t) (sc_ * 4 + wid) * 64);
-            const i32x4 xa = {(int) (ok ? xr.x : 0u), (int) (ok ? xr.y : 0u), (int) (ok ? xr.z : 0u), (int) (ok ? xr.w : 0u)};
-            const i32x4 wf = {(int) wv[i].x, (int) wv[i].y, (int) wv[i].z, (int) wv[i].w};
-            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, xa, acc, 0, 0, 0);
-            if constexpr (SWIGLU)
-            {
-                const i32x4 uf = {(int) uv[i].x, (int) uv[i].y, (int) uv[i].z, (int) uv[i].w};
-                accu = __builtin_amdgcn_mfma_i32_16x16x64_i8(uf, xa, accu, 0, 0, 0);
-            }
-        }
+    // fragment read of this lane inside a slot: row r16 lives in instruction r16 >> 2 at row-in-instruction r16 & 3; piece c at slot (c - r16) & 15
+    const char* wfrag = smem + ring_off + (r16 >> 2) * 1024 + (r16 & 3) * 256;
+    auto finish_group = [&](int gi) {
         // hipcc (ROCm 7.2) copies the accumulator out of the AGPRs at the head of the NEXT basic block (v_accvgpr_read, a phi of the
         // batch loop) and, when that block is entered by the branch below, places the wait states its hazard recogniser owes the last
         // MFMA BEHIND the first of those reads: component 0 came back stale - every 4th output wrong whenever a group had more than
@@ -213,8 +218,6 @@ __global__ __launch_bounds__(256) void gemv_mfma_sq_kernel(const GemvParams p, i
         asm volatile("; accumulator out of the matrix pipe" : "+v"(acc));
         if constexpr (SWIGLU)
             asm volatile("; accumulator out of the matrix pipe" : "+v"(accu));
-        if (b != nb - 1)
-            return;
         // the four K-quarters of the workgroup meet in LDS; wave 0 finishes the group, the others go on streaming
         racc[((par * NACC + 0) * 4 + wid) * 64 + lane] = acc;
         acc = i32x4{0, 0, 0, 0};
@@ -289,24 +292,49 @@ __global__ __launch_bounds__(256) void gemv_mfma_sq_kernel(const GemvParams p, i
         par ^= 1;
     };
 
-    for (int t = 0; t < nbatches;)
+    int q = 0;
+    for (int gi = 0; gi < ngroups_mine; ++gi)
     {
-        if (t + 1 < nbatches)
-            issue(t + 1, wb, ub);
-        consume(t, wa, ua);
-        if (++t >= nbatches)
-            break;
-        if (t + 1 < nbatches)
-            issue(t + 1, wa, ua);
-        consume(t, wb, ub);
-        ++t;
+        for (int j = 0; j < nblk; ++j, ++q)
+        {
+            // keep D - 1 blocks in flight; then block q has landed when at most the younger ones are outstanding (in-order counter;
+            // anything the compiler has in flight on top only makes the wait longer)
+            if (q + D - 1 < total)
+            {
+                issue(q + D - 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");
+            }
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char* slot = wfrag + (q % D) * SLOT;
+            const char* xk = xlane + (size_t) (j * 4 + wid) * 256;
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4)
+            {
+                const int c = c4 * 4 + g4; // 16-byte piece of the 256-byte block = this lane's share of k-step c4
+                const uint4 xr = *reinterpret_cast<const uint4*>(xk + c4 * 64);
+                const uint4 wr = *reinterpret_cast<const uint4*>(slot + ((c - r16) & 15) * 16);
+                const i32x4 xa = {(int) xr.x, (int) xr.y, (int) xr.z, (int) xr.w};
+                const i32x4 wf = {(int) wr.x, (int) wr.y, (int) wr.z, (int) wr.w};
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, xa, acc, 0, 0, 0);
+                if constexpr (SWIGLU)
+                {
+                    const uint4 ur = *reinterpret_cast<const uint4*>(slot + 4096 + ((c - r16) & 15) * 16);
+                    const i32x4 uf = {(int) ur.x, (int) ur.y, (int) ur.z, (int) ur.w};
+                    accu = __builtin_amdgcn_mfma_i32_16x16x64_i8(uf, xa, accu, 0, 0, 0);
+                }
+            }
+            // the slot is free for the DMA of the next iteration only once its fragments are in registers
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        finish_group(gi);
     }
 }
 
-template <int NXV, bool SWIGLU>
+template <int NXV, bool SWIGLU, int D>
 int launch_inst(const GemvParams& p, int pitch, int ngroups, int grid, size_t smem, hipStream_t stream)
 {
-    auto kfn = gemv_mfma_sq_kernel<NXV, SWIGLU>;
+    auto kfn = gemv_mfma_sq_kernel<NXV, SWIGLU, D>;
     static std::atomic<size_t> attr_set{0};
     if (smem > 48 * 1024 && attr_set.load() < smem)
     {
@@ -327,6 +355,31 @@ int launch_inst(const GemvParams& p, int pitch, int ngroups, int grid, size_t sm
     return 0;
 }
 
+template <int NXV, bool SWIGLU>
+int launch_depth(const GemvParams& p, int pitch, int ngroups, int cus, hipStream_t stream)
+{
+    // the deepest ring the LDS holds next to the activation rows: 4 slots (SwiGLU's double slots: 3), else 3, else 2
+    constexpr int SLOT = (SWIGLU ? 8 : 4) * 1024;
+    const size_t fixed = kRedBytes + 2 * (SWIGLU ? 2 : 1) * 4 * 64 * 16 + (size_t) (kRows + 1) * pitch;
+    auto go = [&](auto d) {
+        constexpr int D = decltype(d)::value;
+        const size_t smem = fixed + (size_t) 4 * D * SLOT;
+        const int grid = ngroups < cus ? ngroups : cus;
+        return launch_inst<NXV, SWIGLU, D>(p, pitch, ngroups, grid, smem, stream);
+    };
+    // (7 slots where they fit were measured too: QKV 15.9 us against 14.5 with 4 - depth is not what bounds the stream)
+    if constexpr (!SWIGLU)
+    {
+        if (fixed + 4 * 4 * SLOT <= 160 * 1024)
+            return go(std::integral_constant<int, 4>());
+    }
+    if (fixed + 4 * 3 * SLOT <= 160 * 1024)
+        return go(std::integral_constant<int, 3>());
+    if (fixed + 4 * 2 * SLOT <= 160 * 1024)
+        return go(std::integral_constant<int, 2>());
+    return 1;
+}
+
 } // namespace
 
 int gemv_mfma_min_rows = -1; // -1: environment / default on first use; rows from which launch_gemv takes this kernel (0 = never)
@@ -337,7 +390,7 @@ int launch_gemv_mfma_sq(const GemvParams& p, hipStream_t stream)
     if (gemv_mfma_min_rows < 0)
     {
         const char* e = getenv("TLLM_GEMV_MFMA_ROWS");
-        gemv_mfma_min_rows = e ? atoi(e) : 0; // off unless asked for: measured equal at 8 rows, slower below (header)
+        gemv_mfma_min_rows = e ? atoi(e) : 5; // measured: +5 - 6 % tokens/s at 5 - 8 sequences (the skinny kernel runs 5 rows in its 8-row bucket), -9 % at 4 (header)
     }
     if (gemv_mfma_min_rows <= 0 || p.M < gemv_mfma_min_rows || p.M > kRows || p.wtype != W_INT8_SQ)
         return 1;
@@ -367,9 +420,6 @@ int launch_gemv_mfma_sq(const GemvParams& p, hipStream_t stream)
     else if ((reinterpret_cast<uintptr_t>(p.x) & 15) || (p.ldx & 15))
         return 1;
     const int pitch = p.K + 16;
-    const size_t smem = kRedBytes + 2 * (swiglu ? 2 : 1) * 4 * 64 * 16 + (size_t) (kRows + 1) * pitch;
-    if (smem > 160 * 1024)
-        return 1;
     static std::atomic<int> cus_cache{0};
     int cus = cus_cache.load();
     if (!cus)
@@ -380,19 +430,14 @@ int launch_gemv_mfma_sq(const GemvParams& p, hipStream_t stream)
             cus = 256;
         cus_cache.store(cus);
     }
+    if ((int64_t) 16 * p.ldw + 256 >= (1ll << 32))
+        return 1; // 32-bit DMA offsets inside a row group
     const int ngroups = p.N / 16;
-    // workgroups per CU: as many as the LDS holds, up to 2 (measured best of 1 / 2 / 3; each repeats the prologue)
-    static const int wgs_env = getenv("TLLM_GEMV_MFMA_WGS") ? atoi(getenv("TLLM_GEMV_MFMA_WGS")) : 2;
-    int wgs = (int) ((size_t) 160 * 1024 / smem);
-    wgs = wgs < 1 ? 1 : (wgs > wgs_env ? wgs_env : wgs);
-    const int grid = ngroups < cus * wgs ? ngroups : cus * wgs;
     if (!norm)
-        return swiglu ? launch_inst<0, true>(p, pitch, ngroups, grid, smem, stream) : launch_inst<0, false>(p, pitch, ngroups, grid, smem, stream);
+        return swiglu ? launch_depth<0, true>(p, pitch, ngroups, cus, stream) : launch_depth<0, false>(p, pitch, ngroups, cus, stream);
     if (p.K <= 256 * 8 * kNXVSmall)
-        return swiglu ? launch_inst<kNXVSmall, true>(p, pitch, ngroups, grid, smem, stream)
-                      : launch_inst<kNXVSmall, false>(p, pitch, ngroups, grid, smem, stream);
-    return swiglu ? launch_inst<kNXVMax, true>(p, pitch, ngroups, grid, smem, stream)
-                  : launch_inst<kNXVMax, false>(p, pitch, ngroups, grid, smem, stream);
+        return swiglu ? launch_depth<kNXVSmall, true>(p, pitch, ngroups, cus, stream) : launch_depth<kNXVSmall, false>(p, pitch, ngroups, cus, stream);
+    return swiglu ? launch_depth<kNXVMax, true>(p, pitch, ngroups, cus, stream) : launch_depth<kNXVMax, false>(p, pitch, ngroups, cus, stream);
 }
 
 } // namespace kernels
