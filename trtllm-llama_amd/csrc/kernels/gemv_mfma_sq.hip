@@ -17,7 +17,7 @@
 // arrived at 2.7 TB/s (the guide's TA-bound fragment-shaped load; 32 KB per wave in flight and 1 / 2 / 3 workgroups per CU changed
 // nothing).  With 4-row x 256-byte DMA instructions they arrive at ~3.6 - 4.8 TB/s - still short of the skinny kernel's 7 (a deeper ring
 // does not help; 256-byte runs of rows 4 - 11 KB apart are what the memory sees), which is why this kernel only wins where the skinny
-// one is ALU-bound: profiles/r04_gemv_mfma.txt - 8 sequences 2208 -> 2318 tokens/s, 6: 1829 -> 1920, 5: 1593 -> 1697, 4: 1604 -> 1455 (so: from 5 on).
+// one is ALU-bound: profiles/r04_gemv_mfma.txt - 8 sequences 2208 -> 2407 tokens/s, 6: 1829 -> 1963, 5: 1593 -> 1733, 4: 1604 -> 1462 (so: from 5 on).
 //
 // Arithmetic = gemv_impl.h's, stage by stage (same RMSNorm summation order, same rounding points, exact integer sums), so the
 // results are bit-identical to the skinny kernel's - tests/test_gpu_plugins.py::test_mfma_skinny_gemm_equals_the_valu_kernel.
@@ -133,65 +133,86 @@ __global__ __launch_bounds__(256) void gemv_mfma_sq_kernel(const GemvParams p, i
             const int k = (tid + j * 256) * 8;
             gv[j] = *reinterpret_cast<const uint4*>(gam + (k < K ? k : K - 8));
         }
-        for (int m = 0; m < M; ++m)
+        // RB rows at a time: all their loads in ONE round trip and one barrier for their sums of squares (a row at a time cost
+        // ~1.3 us per row and workgroup: a dependent L2 round trip + a barrier each).  Per-row arithmetic unchanged.
+        constexpr int RB = NXV <= 2 ? 8 : 4;
+        for (int m0 = 0; m0 < M; m0 += RB)
         {
-            const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * p.ldx;
-            uint4 xv[NXV];
+            uint4 xv[RB][NXV];
 #pragma unroll
-            for (int j = 0; j < NXV; ++j)
+            for (int r = 0; r < RB; ++r)
             {
-                const int k = (tid + j * 256) * 8;
-                xv[j] = *reinterpret_cast<const uint4*>(xg + (k < K ? k : K - 8));
-            }
+                const int mr = m0 + r < M ? m0 + r : M - 1; // rows beyond M: a valid row again, never used
+                const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) mr * p.ldx;
 #pragma unroll
-            for (int j = 0; j < NXV; ++j)
-            {
-                const bool ok = (tid + j * 256) * 8 < K;
-                xv[j] = make_uint4(ok ? xv[j].x : 0u, ok ? xv[j].y : 0u, ok ? xv[j].z : 0u, ok ? xv[j].w : 0u);
-            }
-            float ss = 0.f;
-#pragma unroll
-            for (int j = 0; j < NXV; ++j)
-            {
-                const uint32_t ws[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int j = 0; j < NXV; ++j)
                 {
-                    const h2_t h = u32_as_h2(ws[q]);
-                    const float f0 = (float) h.x, f1 = (float) h.y;
-                    ss += f0 * f0 + f1 * f1;
+                    const int k = (tid + j * 256) * 8;
+                    xv[r][j] = *reinterpret_cast<const uint4*>(xg + (k < K ? k : K - 8));
                 }
             }
-            ss = wave_sum(ss);
-            if (lane == 0)
-                red[m * 4 + wid] = ss;
-            __syncthreads();
-            ss = red[m * 4] + red[m * 4 + 1] + red[m * 4 + 2] + red[m * 4 + 3];
-            const float inv = 1.0f / sqrtf(ss / (float) K + p.eps);
 #pragma unroll
-            for (int j = 0; j < NXV; ++j)
+            for (int r = 0; r < RB; ++r)
             {
-                const int k = (tid + j * 256) * 8;
-                if (k < K)
+#pragma unroll
+                for (int j = 0; j < NXV; ++j)
                 {
-                    const uint32_t xs4[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-                    const uint32_t gs4[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
-                    uint32_t o[2] = {0, 0};
+                    const bool ok = (tid + j * 256) * 8 < K;
+                    xv[r][j] = make_uint4(ok ? xv[r][j].x : 0u, ok ? xv[r][j].y : 0u, ok ? xv[r][j].z : 0u, ok ? xv[r][j].w : 0u);
+                }
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < NXV; ++j)
+                {
+                    const uint32_t ws[4] = {xv[r][j].x, xv[r][j].y, xv[r][j].z, xv[r][j].w};
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                     {
-                        h2_t h = u32_as_h2(xs4[q]);
-                        const h2_t gg = u32_as_h2(gs4[q]);
-                        const float n0 = h2f(f2h((float) h.x * inv)), n1 = h2f(f2h((float) h.y * inv));
-                        h.x = (_Float16) (n0 * (float) gg.x);
-                        h.y = (_Float16) (n1 * (float) gg.y);
-                        const uint32_t b0 = (uint8_t) f2i8_rni_sat((float) h.x * pro_q);
-                        const uint32_t b1 = (uint8_t) f2i8_rni_sat((float) h.y * pro_q);
-                        o[q >> 1] |= (b0 | (b1 << 8)) << (16 * (q & 1));
+                        const h2_t h = u32_as_h2(ws[q]);
+                        const float f0 = (float) h.x, f1 = (float) h.y;
+                        ss += f0 * f0 + f1 * f1;
                     }
-                    *reinterpret_cast<uint2*>(xs + (size_t) m * pitch + k) = make_uint2(o[0], o[1]);
+                }
+                ss = wave_sum(ss);
+                if (lane == 0)
+                    red[r * 4 + wid] = ss;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+            {
+                const int m = m0 + r;
+                if (m >= M) // uniform
+                    continue;
+                const float ss = red[r * 4] + red[r * 4 + 1] + red[r * 4 + 2] + red[r * 4 + 3];
+                const float inv = 1.0f / sqrtf(ss / (float) K + p.eps);
+#pragma unroll
+                for (int j = 0; j < NXV; ++j)
+                {
+                    const int k = (tid + j * 256) * 8;
+                    if (k < K)
+                    {
+                        const uint32_t xs4[4] = {xv[r][j].x, xv[r][j].y, xv[r][j].z, xv[r][j].w};
+                        const uint32_t gs4[4] = {gv[j].x, gv[j].y, gv[j].z, gv[j].w};
+                        uint32_t o[2] = {0, 0};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                        {
+                            h2_t h = u32_as_h2(xs4[q]);
+                            const h2_t gg = u32_as_h2(gs4[q]);
+                            const float n0 = h2f(f2h((float) h.x * inv)), n1 = h2f(f2h((float) h.y * inv));
+                            h.x = (_Float16) (n0 * (float) gg.x);
+                            h.y = (_Float16) (n1 * (float) gg.y);
+                            const uint32_t b0 = (uint8_t) f2i8_rni_sat((float) h.x * pro_q);
+                            const uint32_t b1 = (uint8_t) f2i8_rni_sat((float) h.y * pro_q);
+                            o[q >> 1] |= (b0 | (b1 << 8)) << (16 * (q & 1));
+                        }
+                        *reinterpret_cast<uint2*>(xs + (size_t) m * pitch + k) = make_uint2(o[0], o[1]);
+                    }
                 }
             }
+            if (m0 + RB < M)
+                __syncthreads(); // `red` is rewritten by the next RB rows
         }
     }
     __syncthreads();
@@ -390,7 +411,7 @@ int launch_gemv_mfma_sq(const GemvParams& p, hipStream_t stream)
     if (gemv_mfma_min_rows < 0)
     {
         const char* e = getenv("TLLM_GEMV_MFMA_ROWS");
-        gemv_mfma_min_rows = e ? atoi(e) : 5; // measured: +5 - 6 % tokens/s at 5 - 8 sequences (the skinny kernel runs 5 rows in its 8-row bucket), -9 % at 4 (header)
+        gemv_mfma_min_rows = e ? atoi(e) : 5; // measured: +7 - 9 % tokens/s at 5 - 8 sequences (the skinny kernel runs 5 rows in its 8-row bucket), -9 % at 4 (header)
     }
     if (gemv_mfma_min_rows <= 0 || p.M < gemv_mfma_min_rows || p.M > kRows || p.wtype != W_INT8_SQ)
         return 1;
