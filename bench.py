@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prefill', dest='prefill', action='store_false', help='skip the prefill (TTFT) and SQ-GEMM MFMA reports')
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
+    ap.add_argument('--no-batch-sweep', dest='batch_sweep', action='store_false',
+                    help='skip the side report of decode tokens/s at 4 and 8 sequences (N = 1 only; not part of the metric)')
     ap.add_argument('--no-parity', dest='parity', action='store_false',
                     help='skip the 7B accuracy report (GPU engines vs HF fp32 on the host CPU on identical weights)')
     ap.add_argument('--parity-new-tokens', type=int, default=128, help='new tokens per prompt of the accuracy report (SURVEY 8d: 128)')
@@ -196,6 +198,22 @@ def run_config(torch, dist, args, mode, rank, world, dev):
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t1)
         res['prefill_ms'] = min(ts) * 1e3
+    # side report (not the metric, which is batch 1): the same step with 4 and 8 sequences - the weights are read once per step
+    # whatever the batch, so this is what a serving deployment of the path gets per GPU (profiles/r04_batch_sweep.txt)
+    if getattr(args, 'batch_sweep', False) and mode == args.config and world == 1:
+        res['batch'] = {}
+        for B in (4, 8):
+            kb = 32
+            sess.setup(B, args.context, 2 * kb + 16)
+            sess.fake_context(args.context, seed=1, stream=stream)
+            sess.step(2, use_graph=False, stream=stream)
+            sess.step(4, use_graph=True, stream=stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            sess.step(kb, use_graph=True, stream=stream)
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t1
+            res['batch'][str(B)] = {'ms_per_step': dtb * 1e3 / kb, 'tokens_per_s': B * kb / dtb}
     sess.close()
     del weights
     torch.cuda.empty_cache()
@@ -620,6 +638,9 @@ def main():
                            # (T/benchmarks/gpt_benchmark.py:339) - derived from the two measured phases
                            'reference_definition_tokens_per_s': out_len / ((res['prefill_ms'] + out_len * res['ms_per_step']) * 1e-3),
                            'reference_definition_output_len': out_len}
+    if 'batch' in res:
+        line['decode_over_batch'] = {'note': 'side report, same step with B sequences (graph replay); the metric above is batch 1',
+                                     'context': args.context, **res['batch']}
     if args.prefill and args.config == 'sq' and world == 1:
         try:
             line['sq_gemm_mfma'] = sq_gemm_mfma_report(torch, dev)
