@@ -171,6 +171,40 @@ def test_prefill_epilogue_fusions_are_bit_identical(mode, monkeypatch):
         np.testing.assert_array_equal(l0, l1)
 
 
+@pytest.mark.parametrize('B', [5, 8])
+def test_several_sequences_on_the_matrix_pipe_equal_the_skinny_kernel(B, lib):
+    """Decode with 5 - 8 sequences runs the SmoothQuant layer GEMMs on the matrix pipe (kernels/gemv_mfma_sq.hip, the default from 5
+    rows on); tllm_gemv_set_mfma_rows(0) keeps the skinny vector-ALU kernel.  The two are bit-identical stage by stage, so a whole
+    generation - prefill, eager first step, graph-replayed steps, ragged prompt lengths - must give IDENTICAL tokens and logits at the
+    7B layer dimensions."""
+    import ctypes
+    lib.tllm_gemv_set_mfma_rows.argtypes = [ctypes.c_int32]
+    lib.tllm_gemv_set_mfma_rows.restype = None
+    cfg = dict(bench.LLAMA_7B, num_layers=3)
+    dev = torch.device('cuda', 0)
+    w = bench.synth_weights(torch, cfg, 'sq', True, 1, 0, dev)
+    rng = np.random.default_rng(B)
+    S, NEW = 96, 12
+    lens = rng.integers(S // 2, S + 1, B).astype(np.int32)
+    ids = rng.integers(3, cfg['vocab_size'], (B, S)).astype(np.int32)
+    outs = []
+    try:
+        for rows_from in (0, -1):
+            lib.tllm_gemv_set_mfma_rows(rows_from)
+            s = NativeSession(dict(cfg, quant_mode=bench.QM['sq'] | bench.INT8_KV, tp_size=1, tp_rank=0))
+            for k, v in w.items():
+                s.set_tensor(k, v)
+            s.finalize()
+            s.setup(B, S, NEW)
+            toks = s.generate(ids, lens, NEW)
+            outs.append((toks.copy(), s.logits().copy()))
+            s.close()
+    finally:
+        lib.tllm_gemv_set_mfma_rows(-1)
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 def test_in_launch_attention_merge_beyond_eight_partials():
     """More than 8 split partials (a cache of more than 2048 slots at head size 128): the in-launch merge takes up to 16, the
     prologue form stops at 8 and hands over to the finest split + combine launch - a different split, so fp32 summation order
