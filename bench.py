@@ -40,6 +40,8 @@ def parse():
     ap.add_argument('--context', type=int, default=1024)
     ap.add_argument('--layers', type=int, default=32, help='debug only: fewer layers (the result line says so)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--two-launch-attention', action='store_true',
+                    help='A/B: QKV projection and attention as two launches (session key fuse_qkv_attention = 0)')
     ap.add_argument('--no-prefill', dest='prefill', action='store_false', help='skip the prefill (TTFT) and SQ-GEMM MFMA reports')
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
     ap.add_argument('--no-batch-sweep', dest='batch_sweep', action='store_false',
@@ -114,7 +116,7 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     cfg = dict(LLAMA_7B, num_layers=args.layers)
     int8_kv = mode != 'fp16'  # BASELINE.json configs: fp16 + fp16 KV; every int8 config with int8 KV
     qm = QM[mode] | (INT8_KV if int8_kv else 0)
-    sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=world, tp_rank=rank))
+    sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=world, tp_rank=rank, fuse_qkv_attention=0 if args.two_launch_attention else -1))
     weights = synth_weights(torch, cfg, mode, int8_kv, world, rank, dev)
     for k, v in weights.items():
         sess.set_tensor(k, v)

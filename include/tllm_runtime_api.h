@@ -116,6 +116,10 @@ int32_t tllm_session_get_logits(tllm_session_t s, float* logits /* [B, vocab] */
 int32_t tllm_session_get_output_ids(tllm_session_t s, int32_t* ids /* [B, max_in + max_new] */, tllm_stream_t stream);
 /* Device pointer of a layer's KV cache (layout [B,2,H/tp,Smax,Dh]) for inspection. */
 void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer);
+/* Diagnostic: with the session key fused_timeline = 1, the device buffer [heads * 8 workgroups][16] of 100 MHz clock ticks the
+ * last fused QKV-projection + attention launch stamped at its stages (kernels/qkv_attn_fused.hip; tools/fused_timeline.py);
+ * NULL when the session does not run that launch. */
+void* tllm_session_fused_timeline_ptr(tllm_session_t s);
 /* The step-dependent tensors the reference's Python loop builds on the host every step (PY/runtime/generation.py:556-579,
  * :686-689, :735-750, :812-821) live in device memory here and are advanced by the sampler kernel; this copies them out so
  * that tests can pin them to the reference's values (any pointer may be NULL):

@@ -1,0 +1,60 @@
+"""Stage clock of the fused QKV + attention launch (GPU box): where the 256 workgroups are at which microsecond.
+   python tools/fused_timeline.py [context]"""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'trtllm-llama_amd'))
+import bench
+from tensorrt_llm.runtime.native import NativeSession, _lib
+cfg = dict(bench.LLAMA_7B)
+dev = torch.device('cuda', 0)
+w = bench.synth_weights(torch, cfg, 'sq', True, 1, 0, dev)
+s = NativeSession(dict(cfg, quant_mode=bench.QM['sq'] | bench.INT8_KV, tp_size=1, tp_rank=0, fused_timeline=1))
+for k, v in w.items():
+    s.set_tensor(k, v)
+s.finalize()
+ctx = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+s.setup(1, ctx, 64)
+s.fake_context(ctx, seed=1)
+s.step(4)
+lib = _lib()
+lib.tllm_session_fused_timeline_ptr.argtypes = [ctypes.c_void_p]
+lib.tllm_session_fused_timeline_ptr.restype = ctypes.c_void_p
+hip = ctypes.CDLL('libamdhip64.so')
+hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+names = {0: 'start', 1: 'prologue done', 2: 'q rows done', 3: 'k rows done', 4: 'barrier C (q in LDS)', 5: 'barrier D (attention math)',
+         6: 'v rows done', 7: 'merger end', 8: 'gather: start', 9: 'gather: q swept', 10: 'gather(m0): k + partials', 11: 'gather(m0): v'}
+for rnd in range(3):
+    us, n = s.time_kernel('qkv', sweeps=4)
+    torch.cuda.synchronize()
+    t = np.zeros((256, 16), np.uint64)
+    assert hip.hipMemcpy(t.ctypes.data, lib.tllm_session_fused_timeline_ptr(s._h), t.nbytes, 2) == 0
+    t = t.astype(np.int64)
+    t0 = t[:, 0].min()
+    print(f'--- round {rnd}: {us:.2f} us per launch; last launch, us since the first workgroup started (min / median / max over workgroups)')
+    for k in range(12):
+        col = t[:, k] if k not in (7, 10, 11) else t[:32, k]
+        col = col[col > 0]
+        if len(col):
+            r = (col - t0) / 100.0
+            print(f'   {names[k]:30s} {r.min():7.2f} {np.median(r):7.2f} {r.max():7.2f}')
+    # per head: the q hand-off = (the slowest member's "q rows done") -> (each member's "q swept")
+    H = 32
+    qd = t[:, 2].reshape(8, H)      # [member, head]
+    sw = t[:, 9].reshape(8, H)
+    lastq = qd.max(0)
+    ho = (sw - lastq[None, :]) / 100.0
+    print(f'   q hand-off (last member published -> member has q in LDS): min {ho.min():.2f} median {np.median(ho):.2f} max {ho.max():.2f} us; '
+          f'spread of "q rows done" inside a head: median {np.median((qd.max(0) - qd.min(0)) / 100.0):.2f} us')
+    sp = t[:, 12]
+    print(f'   q polls per gather wave: median {np.median(sp):.0f} (min {sp.min()}, max {sp.max()}); polling time / polls: '
+          f'{np.median((t[:, 9] - t[:, 8]) / 100.0 / np.maximum(sp + 1, 1)):.2f} us per poll')
+    pd = t[:, 5].reshape(8, H)      # barrier D of every member (partials published right behind it)
+    kp = t[:H, 10]
+    print(f'   partial hand-off (last member past barrier D -> merger has all partials): median {np.median((kp - pd.max(0)) / 100.0):.2f} us')
+    vd = t[:, 6].reshape(8, H)
+    print(f'   v hand-off (last member v rows done -> merger has v): median {np.median((t[:H, 11] - vd.max(0)) / 100.0):.2f} us; '
+          f'merger end - that: median {np.median((t[:H, 7] - t[:H, 11]) / 100.0):.2f} us')
+for k in ('o_proj', 'gate_up', 'down'):
+    print(k, s.time_kernel(k, sweeps=8))

@@ -191,6 +191,48 @@ int launch_mmha(const MmhaParams& p, hipStream_t stream);
 // re-arms them): plugins call this per enqueue, the session once per setup.
 int mmha_reset_workspace(void* workspace, int32_t batch, int32_t num_heads, hipStream_t stream);
 
+// ---------------------------------------------------------------------------------------------
+// Decode step, batch 1: the QKV projection (SmoothQuant int8, RMSNorm + quantiser prologue) of head h, RoPE, the cache append
+// and the masked attention of head h in ONE launch (kernels/qkv_attn_fused.hip).  8 workgroups per head; the projection outputs
+// and the split partials travel between them as 8-byte {tag, value} granules through `xchg`.
+// ---------------------------------------------------------------------------------------------
+struct FusedQkvAttnParams
+{
+    int32_t K = 0, num_heads = 0, head_size = 0;
+    const void* x = nullptr;     // fp16 [K]: the layer's input row
+    const void* gamma = nullptr; // fp16 [K]: input_layernorm
+    float eps = 1e-6f;
+    const void* w = nullptr; // s8 [3 * num_heads * head_size, ldw]: q | k | v rows
+    int64_t ldw = 0;         // bytes
+    const float* scale_col = nullptr; // f32 [3 * H * Dh] (per_channel) or [1]
+    int32_t per_channel = 0;
+    const float* act_quant_scale = nullptr;   // f32 [1]: static quantiser of the normalised row; null -> per-token (amax / 127)
+    const float* act_dequant_scale = nullptr; // f32 [1]: the static activation scale of the dequantisation
+    int32_t int8_kv = 0, max_seq_len = 0;
+    float inv_sqrt_dh = 1.f;
+    void* kv_cache = nullptr;                 // [2, H, Smax, Dh] fp16 or s8 (batch 1)
+    const int32_t* sequence_length = nullptr; // [1] device: slots in use
+    const int32_t* masked_tokens = nullptr;   // [Smax] device or null
+    const float* kv_scale_orig_quant = nullptr;
+    const float* kv_scale_quant_orig = nullptr;
+    const float* rope_row = nullptr; // f32 [Dh / 2, 2]: this step's (cos, sin) row (NeoX pairs), prepared by the sampler
+    uint64_t* xchg = nullptr;        // qkv_attn_fused_xchg_bytes(), zero before the first launch
+    const uint32_t* epoch = nullptr; // device word advanced once per generation step
+    uint32_t tag_mul = 1, tag_add = 1; // tag of this launch = epoch * tag_mul + tag_add (never 0, unique per launch)
+    uint32_t tag_host = 0;             // non-zero: the tag itself (eager launches outside a step, e.g. kernel timing)
+    uint32_t* error = nullptr;         // device word: non-zero after a bounded wait expired
+    int32_t max_spins = 400000;
+    void* qkv_out = nullptr; // optional fp16 [3 * H * Dh]: the projection's output (before RoPE)
+    void* out = nullptr;     // fp16 [H * Dh]: the attention context
+    void* out_q8 = nullptr;  // optional s8 [H * Dh] = sat(rni(float(out) * out_quant_scale[0])) (the O-projection's static quantiser)
+    const float* out_quant_scale = nullptr;
+    void* x_pro_out = nullptr; // optional s8 [K]: the quantised operand (tap)
+    uint64_t* timing = nullptr; // optional [workgroups][16] stage clock (100 MHz ticks): tools/fused_timeline.py
+};
+size_t qkv_attn_fused_xchg_bytes(int32_t num_heads);
+bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int32_t max_seq_len, int32_t int8_kv);
+int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream);
+
 // RoPE table builder (host -> device buffer owned by caller): cos/sin(pos / 10000^(2j/rot)) in fp32,
 // formula of K/decoderMaskedMultiheadAttentionUtils.h:1511-1515.
 void fill_rope_table_host(float* table, int32_t max_pos, int32_t rotary_dim);
@@ -344,6 +386,7 @@ struct GreedyParams
     const void* emb_table = nullptr; // fp16 [vocab, hidden]
     void* x_out = nullptr;
     int32_t hidden = 0;
+    uint32_t* step_epoch = nullptr; // optional device word, += 1 per call (tags of the in-launch hand-offs of the next step)
 };
 int launch_greedy_step(const GreedyParams& p, hipStream_t stream);
 // teacher forcing for parity tests: overwrite the sampler's last choice (output slot seq_len[b], step input id, next input row)

@@ -616,6 +616,8 @@ __global__ __launch_bounds__(1024) void greedy_step_kernel(const GreedyParams p)
             p.out_ids[(int64_t) b * p.out_stride + sl] = id;
         p.cur_ids[b] = id;
         si[0] = id;
+        if (b == 0 && p.step_epoch)
+            *p.step_epoch += 1;
     }
     if (p.emb_table) // uniform: the next step's input row, gathered here instead of by an embedding launch of its own
     {

@@ -1,0 +1,759 @@
+// Decode step, batch 1: the QKV projection of head h, RoPE, the KV-cache append and the masked attention of head h in ONE launch
+// (SURVEY §8a rows A5 + A11 + A10 -> A1 / A2 / A3).  gfx950, SmoothQuant int8 weights.
+//
+// Reference: the generation phase of Attention.forward (PY/layers/attention.py: qkv = self.qkv(hidden) -> gpt_attention plugin) =
+// SmoothQuantGemm [1, D] x [3 D, D]^T, then masked_multihead_attention_kernel (MM/decoderMaskedMultiheadAttentionTemplate.h:
+// 1352-1389 RoPE, 1493-1549 cache append / current-token score, 1553-1800 the loops over the cache, 2019-2181 the multi-block
+// reduction).  The reference runs them as two graph nodes; so did rounds 1 - 4 here (gemv_kernel<.., PK_NORM, EK_PLAIN> 9.8 us +
+// mmha_partial_kernel 9.2 us per layer at the 7B shape).  This is the one seam of the decoder layer that is NOT all-to-all:
+// head h's attention needs exactly the 3 x 128 projection outputs of head h.
+//
+// Structure (32 heads x 8 members = 256 workgroups of 8 waves, one per CU; member m of head h is workgroup m * H + h, so the
+// eight members of a head share an XCD - for speed only, nothing depends on it):
+//   t = 0   every wave requests EVERYTHING that does not depend on another workgroup, in one go: x and gamma, its 6 weight
+//           rows (2 q rows, 2 k rows, 2 v rows of the member's 3 x 16: 24 KB per wave, 59 MB on the chip - the whole stream is in
+//           flight at once, the memory system drains it at its own rate), the member's 1/8 of the head's cache range (NIT rows of K
+//           and of V per lane group, 16 bytes per lane), masks, RoPE row, scales.  The cache round trip that stood alone in its
+//           own launch at ~1 TB/s now hides under the weight stream.
+//   1       RMSNorm + int8 quantiser of x in registers -> LDS (the arithmetic of gemv_impl.h's PK_NORM prologue, same summation
+//           order: the int8 operand is bit-identical to the unfused launch's).
+//   2       q rows -> dot (v_dot4_i32_i8, exact) -> per-channel x per-tensor dequantisation -> ONE 8-byte {tag, 2 x fp16} granule
+//           per wave, written through (sc1): the data is the flag (guide G16 R2).  Then the k rows, then the v rows.
+//   3       wave 0 of every member sweeps the head's 64 q granules (RoPE applied in the sweeping lanes), everyone computes the
+//           scores / softmax / P.V of its cache rows against q, merges its 64 lane groups (DPP inside a wave, LDS across) and
+//           publishes ONE partial {m, l, o[128]} as tagged granules.
+//   4       member 0 of the head sweeps the k and v granules and the eight partials, adds the CURRENT token as a ninth partial
+//           (score q.k_new with the un-quantised k, weight exp(.), value v_new: MM/...Template.h:1517-1549), normalises, writes the
+//           context row (fp16 + its static int8 image for the O-projection) and appends k_new / v_new to the cache.
+// Two in-launch hand-offs (q inside the head; partials + k, v to the head's merger), no ticket, no drain, no kernel boundary
+// between the projection and the attention.  Every wait is bounded; a time-out raises the error word and the launch ends.
+//
+// Tags: tag = step_epoch * tag_mul + tag_add (tag_add = layer + 1), step_epoch a device word the sampler advances once per
+// generation step - unique per launch, never 0, valid under graph replay (a kernel argument would be frozen).  The exchange
+// buffer is shared by all layers (the kernel boundary between two layers orders reuse) and zeroed at session setup.
+//
+// Numerics: SURVEY Appendix A.1 as in mmha_decode.hip (RoPE fp32 -> fp16; int8 cache = sat(rni(fp16 * s)); cached K / V as exact
+// integers with the scale folded into the sums; p rounded to fp16 before P.V; fp32 partials; 1 / (sum + 1e-6); one fp16 rounding).
+// The current token enters as its own partial (p = 1 exactly) instead of inside a lane group's partial: a re-association of the
+// fp32 merge, nothing else.
+#include "dev_utils.h"
+#include "kernels.h"
+#include <math.h>
+
+namespace tllm
+{
+namespace kernels
+{
+using namespace dev;
+
+namespace
+{
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+constexpr int kDH = 128;       // head size
+constexpr int kMembers = 8;    // workgroups per head
+constexpr int kWavesF = 8;     // waves per workgroup
+constexpr int kKChunks = 4;    // K = 4096 int8 = 4 x 1 KiB per weight row
+constexpr int kPartStride = 136; // granules per published partial: o[128], m, l (+ pad)
+constexpr int kHeadGranules = 3 * 64 + kMembers * kPartStride;
+
+__device__ __forceinline__ void st_granule(gu64* g, uint32_t tag, uint32_t value)
+{
+    __hip_atomic_store(g, ((unsigned long long) tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_granule(const gu64* g)
+{
+    return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// RoPE (NeoX pairs (d, d + 64)) of the element pair (2l, 2l + 1) this lane of the sweeping wave holds: the partner pair sits in
+// lane l ^ 32.  cs = {cos(2l'), sin(2l'), cos(2l' + 1), sin(2l' + 1)}, l' = l & 31.  Rounding: fp32 -> fp16 (...Utils.h:1517-1531)
+__device__ __forceinline__ uint32_t rope_pair(uint32_t raw, const float4& cs, bool second)
+{
+    const h2_t v = u32_as_h2(raw);
+    const float x0 = (float) v.x, x1 = (float) v.y;
+    const float p0 = __shfl_xor(x0, 32, 64), p1 = __shfl_xor(x1, 32, 64);
+    const float s0 = second ? cs.y : -cs.y, s1 = second ? cs.w : -cs.w;
+    const uint32_t lo = f2h(cs.x * x0 + s0 * p0), hi = f2h(cs.z * x1 + s1 * p1);
+    return lo | (hi << 16);
+}
+
+// workgroup barrier with the LDS visibility of __syncthreads(), callable from wave-uniform branches (every wave of the workgroup
+// executes the same NUMBER of barriers; a wave that has returned no longer counts)
+__device__ __forceinline__ void wg_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// optional stage clock (FusedQkvAttnParams::timing, tools/fused_timeline.py): the 100 MHz constant counter, one row per workgroup
+#define TLLM_STAMP(slot)                                                                                               \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        if (p.timing && lane == 0 && (wid == 0 || wid == kWavesF))                                                     \
+            p.timing[(size_t) blockIdx.x * 16 + (slot)] = wall_clock64();                                              \
+    } while (0)
+
+template <int NIT, bool INT8KV>
+__global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnParams p)
+{
+    constexpr int EPL = INT8KV ? 16 : 8; // cache elements per lane (16 bytes)
+    constexpr int LPR = kDH / EPL;       // lanes per cache row
+    constexpr int RPW = 64 / LPR;        // rows per wave instruction = lane groups per wave
+    constexpr int NGRP = kWavesF * RPW;  // lane groups per workgroup
+    constexpr int TCHUNK = NGRP * NIT;   // cache slots per member
+    constexpr int ESZ = INT8KV ? 1 : 2;
+    constexpr int NQW = EPL / 2;         // 32-bit words of q per lane
+
+    __shared__ __attribute__((aligned(16))) char smem[4096 /* x s8 */ + 256 /* red */ + 3 * 256 /* q', k', v as fp16 */
+        + 3 * 256 /* raw q, k, v */ + kWavesF * (kDH + 8) * 4 /* wave partials */ + kMembers * (kDH + 8) * 4 /* head partials */ + 64];
+    char* xs = smem;
+    float* red = reinterpret_cast<float*>(smem + 4096);
+    uint32_t* rot = reinterpret_cast<uint32_t*>(smem + 4096 + 256);        // [3][64]: q', k' (RoPE applied), v
+    uint32_t* raw = rot + 3 * 64;                                          // [3][64]: q, k, v as projected
+    float* wpart = reinterpret_cast<float*>(raw + 3 * 64);                 // [8][136]: o[128], m, l per wave
+    float* hpart = wpart + kWavesF * (kDH + 8);                            // [8][136]: the head's partials (member 0)
+    float* misc = hpart + kMembers * (kDH + 8);                            // [0] score of the current token, [1] give-up flag
+
+    const int H = p.num_heads;
+    const int h = blockIdx.x % H, mem = blockIdx.x / H;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid) >> 6; // scalar: the role branches below are s_cbranch, not exec masks
+    const int K = p.K;
+    const uint32_t ep = p.epoch[0];
+    const uint32_t tag = p.tag_host ? p.tag_host : ep * p.tag_mul + p.tag_add;
+    const int tl = p.sequence_length[0]; // slots in use; the current token goes to slot tl
+    const int Smax = p.max_seq_len;
+    const bool q_dyn = p.act_quant_scale == nullptr;
+    gu64* gx = (gu64*) p.xchg + (size_t) h * kHeadGranules;
+    gu64* gp = gx + 3 * 64;
+
+    // =================================================================== the gather wave (wave 8): every wait for another
+    // workgroup lives here, so that no compute wave ever has a hand-off load queued behind (or in front of) its weight stream -
+    // the load counter is in order.  It polls with write-through-visible (sc1) loads and sleeps between passes.
+    if (wid == kWavesF)
+    {
+        const float4 cs = reinterpret_cast<const float4*>(p.rope_row)[lane & 31]; // coefficients of elements 2 l', 2 l' + 1
+        TLLM_STAMP(8);
+        wg_barrier(); // the prologue's barriers
+        if (q_dyn)
+            wg_barrier();
+        wg_barrier();
+        bool gave_up = false;
+        unsigned long long g;
+        int spins = 0;
+        // q of the whole head: one granule per lane.  A poll takes ~2.2 us while the CU streams (measured: 3 sequential polls per
+        // launch, the hand-off = visibility + the rest of the poll in flight + one more poll = 4.8 - 5.3 us): so EIGHT polls are
+        // kept in flight, a new one requested each time the oldest comes back - the first poll issued after the last sibling's
+        // store is visible is never more than ~0.3 us away
+        {
+            unsigned long long r0 = ld_granule(gx + lane), r1, r2, r3, r4, r5, r6, r7;
+            __builtin_amdgcn_s_sleep(2);
+            r1 = ld_granule(gx + lane);
+            __builtin_amdgcn_s_sleep(2);
+            r2 = ld_granule(gx + lane);
+            __builtin_amdgcn_s_sleep(2);
+            r3 = ld_granule(gx + lane);
+            __builtin_amdgcn_s_sleep(2);
+            r4 = ld_granule(gx + lane);
+            __builtin_amdgcn_s_sleep(2);
+            r5 = ld_granule(gx + lane);
+            __builtin_amdgcn_s_sleep(2);
+            r6 = ld_granule(gx + lane);
+            __builtin_amdgcn_s_sleep(2);
+            r7 = ld_granule(gx + lane);
+#define TLLM_POLL_STEP(R)                                                                                              \
+    if (__all((uint32_t) (R >> 32) == tag))                                                                            \
+    {                                                                                                                  \
+        g = R;                                                                                                         \
+        break;                                                                                                         \
+    }                                                                                                                  \
+    if (++spins > p.max_spins)                                                                                         \
+    {                                                                                                                  \
+        g = R;                                                                                                         \
+        gave_up = true;                                                                                                \
+        break;                                                                                                         \
+    }                                                                                                                  \
+    R = ld_granule(gx + lane);
+            for (;;)
+            {
+                TLLM_POLL_STEP(r0)
+                TLLM_POLL_STEP(r1)
+                TLLM_POLL_STEP(r2)
+                TLLM_POLL_STEP(r3)
+                TLLM_POLL_STEP(r4)
+                TLLM_POLL_STEP(r5)
+                TLLM_POLL_STEP(r6)
+                TLLM_POLL_STEP(r7)
+            }
+#undef TLLM_POLL_STEP
+        }
+        if (p.timing && lane == 0)
+            p.timing[(size_t) blockIdx.x * 16 + 12] = (uint64_t) spins;
+        const uint32_t q2 = (uint32_t) g;
+        const uint32_t qrot = rope_pair(q2, cs, lane >= 32);
+        raw[lane] = q2;
+        rot[lane] = qrot;
+        if (lane == 0)
+            misc[1] = gave_up ? 1.f : 0.f;
+        wg_barrier(); // C: q' is in LDS
+        TLLM_STAMP(9);
+        if (mem != 0 || gave_up)
+            return;
+        wg_barrier(); // D (the compute waves' wave partials)
+        // member 0: k and the eight partials (published long before the weight stream ends), then v (published at its end)
+        unsigned long long gk, gpart[kMembers][3];
+        for (;;)
+        {
+            gk = ld_granule(gx + 64 + lane);
+#pragma unroll
+            for (int i = 0; i < kMembers; ++i)
+            {
+                gpart[i][0] = ld_granule(gp + i * kPartStride + lane);
+                gpart[i][1] = ld_granule(gp + i * kPartStride + 64 + lane);
+                gpart[i][2] = ld_granule(gp + i * kPartStride + 128 + (lane & 1)); // m, l
+            }
+            __builtin_amdgcn_sched_barrier(0); // all 25 requests of a pass in flight before the first tag is looked at
+            uint32_t bad = (uint32_t) (gk >> 32) ^ tag; // (no short-circuit: a branch per tag serialises the loads)
+#pragma unroll
+            for (int i = 0; i < kMembers; ++i)
+                bad |= ((uint32_t) (gpart[i][0] >> 32) ^ tag) | ((uint32_t) (gpart[i][1] >> 32) ^ tag) | ((uint32_t) (gpart[i][2] >> 32) ^ tag);
+            if (__all(bad == 0))
+                break;
+            if (++spins > p.max_spins)
+            {
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        const uint32_t k2 = (uint32_t) gk;
+        const uint32_t krot = rope_pair(k2, cs, lane >= 32);
+        raw[64 + lane] = k2;
+        rot[64 + lane] = krot;
+#pragma unroll
+        for (int i = 0; i < kMembers; ++i)
+        {
+            hpart[i * (kDH + 8) + lane] = __uint_as_float((uint32_t) gpart[i][0]);
+            hpart[i * (kDH + 8) + 64 + lane] = __uint_as_float((uint32_t) gpart[i][1]);
+            if (lane < 2)
+                hpart[i * (kDH + 8) + 128 + lane] = __uint_as_float((uint32_t) gpart[i][2]);
+        }
+        // score of the current token: the un-quantised q'.k' (MM/...Template.h:1517-1549)
+        const float dn = wave_sum(dot2(qrot, krot, 0.f)) * p.inv_sqrt_dh;
+        TLLM_STAMP(10);
+        for (;;)
+        {
+            g = ld_granule(gx + 128 + lane);
+            if (__all((uint32_t) (g >> 32) == tag))
+                break;
+            if (++spins > p.max_spins)
+            {
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        raw[128 + lane] = (uint32_t) g;
+        rot[128 + lane] = (uint32_t) g;
+        if (lane == 0)
+        {
+            misc[0] = dn;
+            misc[1] = gave_up ? 2.f : 0.f;
+        }
+        TLLM_STAMP(11);
+        wg_barrier(); // E: everything the final merge needs is in LDS
+        return;
+    }
+
+    // =================================================================== the eight compute waves
+    // ------------------------------------------------------------------ t = 0: every request that depends on nobody
+    // (a) x: vectors t and t + 256 of the 256-thread prologue this one restates (threads >= 256 repeat the first half's work so
+    //     that no load sits behind a branch); gamma for the vector this thread normalises
+    const int t2 = tid & 255;
+    TLLM_STAMP(0);
+    const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x);
+    const uint4 xa = *reinterpret_cast<const uint4*>(xg + t2 * 8);
+    const uint4 xb = *reinterpret_cast<const uint4*>(xg + (t2 + 256) * 8);
+    const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.gamma) + tid * 8);
+    // the per-channel scales of the wave's 6 rows: consumed right behind the first tile's dots, and the load counter is in
+    // order - requested behind the weights they would be waited for behind the whole stream
+    int wrow[3];
+    float cscale[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+        wrow[i] = (i * H + h) * kDH + mem * 16 + 2 * wid;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            cscale[i][r] = p.scale_col[p.per_channel ? wrow[i] + r : 0];
+    }
+    __builtin_amdgcn_sched_barrier(0); // issue order = consumption order (hipcc sank the gamma load below the weight loads)
+    // (b) the wave's q rows: rows 2 wid, 2 wid + 1 of the member's 16 (the k rows follow behind the prologue, the v rows into
+    //     the q rows' registers)
+    const char* wbase = reinterpret_cast<const char*>(p.w);
+    uint4 wa[kKChunks][2], wb[kKChunks][2];
+#pragma unroll
+    for (int u = 0; u < kKChunks; ++u)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            wa[u][r] = ld_nt16(wbase + (int64_t) (wrow[0] + r) * p.ldw + u * 1024 + lane * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    float pro_q = 1.f, deq = 1.f;
+    if (!q_dyn) // uniform
+    {
+        pro_q = p.act_quant_scale[0];
+        deq = p.act_dequant_scale[0];
+    }
+    float s_oq = 1.f, s_qo = 1.f;
+    if constexpr (INT8KV)
+    {
+        s_oq = p.kv_scale_orig_quant[0];
+        s_qo = p.kv_scale_quant_orig[0];
+    }
+
+    // ------------------------------------------------------------------ 1. RMSNorm + quantiser -> LDS (gemv_impl.h PK_NORM, MB = 1)
+    {
+        float ss = 0.f;
+        const uint32_t w8[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+        {
+            const h2_t hh = u32_as_h2(w8[q]);
+            const float f0 = (float) hh.x, f1 = (float) hh.y;
+            ss += f0 * f0 + f1 * f1;
+        }
+        ss = wave_sum(ss);
+        if (lane == 0 && wid < 4)
+            red[wid] = ss;
+        wg_barrier();
+        ss = red[0] + red[1] + red[2] + red[3];
+        const float inv = 1.0f / sqrtf(ss / (float) K + p.eps);
+        // this thread's own vector: tid * 8 (threads < 256: vector a, the others: vector b)
+        uint32_t xs4[4] = {tid < 256 ? xa.x : xb.x, tid < 256 ? xa.y : xb.y, tid < 256 ? xa.z : xb.z, tid < 256 ? xa.w : xb.w};
+        const uint32_t gs4[4] = {gv.x, gv.y, gv.z, gv.w};
+        float amax = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+            h2_t hh = u32_as_h2(xs4[q]);
+            const h2_t gg = u32_as_h2(gs4[q]);
+            const float n0 = h2f(f2h((float) hh.x * inv)), n1 = h2f(f2h((float) hh.y * inv));
+            hh.x = (_Float16) (n0 * (float) gg.x);
+            hh.y = (_Float16) (n1 * (float) gg.y);
+            xs4[q] = h2_as_u32(hh);
+            amax = fmaxf(amax, fmaxf(fabsf((float) hh.x), fabsf((float) hh.y)));
+        }
+        float qs = pro_q;
+        if (q_dyn) // uniform: per-token scale amax / 127 (K/quantization.cu:94-118)
+        {
+            amax = wave_max(amax);
+            if (lane == 0)
+                red[32 + wid] = amax;
+            wg_barrier();
+            amax = red[32];
+#pragma unroll
+            for (int w = 1; w < kWavesF; ++w)
+                amax = fmaxf(amax, red[32 + w]);
+            amax = fmaxf(amax, h2f(f2h(1e-6f)));
+            qs = 127.f / amax;
+            deq = amax / 127.f;
+        }
+        uint32_t o[2] = {0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+        {
+            const h2_t hh = u32_as_h2(xs4[q]);
+            const uint32_t b0 = (uint8_t) f2i8_rni_sat((float) hh.x * qs);
+            const uint32_t b1 = (uint8_t) f2i8_rni_sat((float) hh.y * qs);
+            o[q >> 1] |= (b0 | (b1 << 8)) << (16 * (q & 1));
+        }
+        *reinterpret_cast<uint2*>(xs + tid * 8) = make_uint2(o[0], o[1]);
+    }
+    wg_barrier();
+    TLLM_STAMP(1);
+    // (b2) the k rows and the member's cache rows - requested when the q rows have ARRIVED, not before.  A CU drains its load
+    // queue in order at ~25 GB/s, and everything that has to pass through that queue later - the instruction fetch of the code
+    // below, above all the gather wave's polls - waits behind what is already in it.  Measured with the stage clock
+    // (tools/fused_timeline.py): the whole stream requested at t = 0 (230 KB per CU): prologue done 6.6 us after the launch;
+    // q rows at t = 0, k rows + cache rows behind the prologue, v rows behind the q rows' dots (134 KB queued when q becomes
+    // visible): the q hand-off takes 5.2 us (the partial hand-off, behind a nearly empty queue: 1.5).  One tile (+ the cache rows)
+    // per wave in flight = 64 - 98 KB per CU keeps the memory as busy (> latency x rate ~ 50 KB) and a poll waits 2 - 2.5 us.
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the q rows are here
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < kKChunks; ++u)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            wb[u][r] = ld_nt16(wbase + (int64_t) (wrow[1] + r) * p.ldw + u * 1024 + lane * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    // (c) the member's cache rows: behind the q and k rows and AHEAD of the v rows in the queue - they are consumed between
+    //     the k rows and the v rows, under the rest of the stream
+    const int li = lane % LPR, grp = lane / LPR, gid = wid * RPW + grp;
+    const int t0 = mem * TCHUNK;
+    char* kbase = reinterpret_cast<char*>(p.kv_cache) + ((int64_t) 0 * H + h) * Smax * kDH * ESZ;
+    char* vbase = reinterpret_cast<char*>(p.kv_cache) + ((int64_t) 1 * H + h) * Smax * kDH * ESZ;
+    uint4 kreg[NIT], vreg[NIT];
+    int mk[NIT];
+    const bool has_mask = p.masked_tokens != nullptr;
+    const int32_t* mask_ptr = has_mask ? p.masked_tokens : p.sequence_length;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+    {
+        const int t = min(t0 + i * NGRP + gid, Smax - 1); // clamped, dropped by the validity mask: no branch around a load
+        const int64_t off = ((int64_t) t * kDH + li * EPL) * ESZ;
+        kreg[i] = *reinterpret_cast<const uint4*>(kbase + off);
+        vreg[i] = *reinterpret_cast<const uint4*>(vbase + off);
+        // unconditional (a load inside a conditional block ends in a full s_waitcnt - here: behind the whole weight stream):
+        // without a mask the word read is sequence_length[0], valid and ignored
+        mk[i] = mask_ptr[has_mask ? t : 0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (blockIdx.x == 0 && p.x_pro_out) // tap: the int8 operand exactly as the projection consumes it
+        for (int k = tid; k < K / 4; k += 512)
+            reinterpret_cast<uint32_t*>(p.x_pro_out)[k] = reinterpret_cast<const uint32_t*>(xs)[k];
+
+    // ------------------------------------------------------------------ 2. the projections, one granule per wave and matrix
+    auto project = [&](const uint4 (&wt)[kKChunks][2], int i) {
+        int a0 = 0, a1 = 0;
+#pragma unroll
+        for (int u = 0; u < kKChunks; ++u)
+        {
+            const uint4 xr = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * 16);
+            a0 = sdot4(wt[u][0].x, xr.x, a0);
+            a0 = sdot4(wt[u][0].y, xr.y, a0);
+            a0 = sdot4(wt[u][0].z, xr.z, a0);
+            a0 = sdot4(wt[u][0].w, xr.w, a0);
+            a1 = sdot4(wt[u][1].x, xr.x, a1);
+            a1 = sdot4(wt[u][1].y, xr.y, a1);
+            a1 = sdot4(wt[u][1].z, xr.z, a1);
+            a1 = sdot4(wt[u][1].w, xr.w, a1);
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        // epilogue of the SmoothQuant GEMM: fp16(float(acc) * (scale_col * scale_row))
+        const uint32_t v = (uint32_t) f2h((float) a0 * (cscale[i][0] * deq)) | ((uint32_t) f2h((float) a1 * (cscale[i][1] * deq)) << 16);
+        if (lane == 0)
+            st_granule(gx + i * 64 + mem * 8 + wid, tag, v);
+    };
+    project(wa, 0);
+    TLLM_STAMP(2);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the k rows and the cache rows are here
+    __builtin_amdgcn_sched_barrier(0);
+    // the v rows, into the registers the q rows have left
+#pragma unroll
+    for (int u = 0; u < kKChunks; ++u)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            wa[u][r] = ld_nt16(wbase + (int64_t) (wrow[2] + r) * p.ldw + u * 1024 + lane * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    project(wb, 1);
+    TLLM_STAMP(3);
+
+    // ------------------------------------------------------------------ 3. q' of the whole head is in LDS (the gather wave)
+    wg_barrier(); // C
+    TLLM_STAMP(4);
+    if (misc[1] != 0.f) // uniform: a sibling never published (a workgroup that is not resident: see the launcher's residency rule)
+    {
+        if (tid == 0)
+            atomicOr(p.error, 1u);
+        return;
+    }
+
+    // ------------------------------------------------------------------ 4. scores, softmax partial and P.V of this member's rows
+    //                                                                       (the v rows of the weights are still in flight)
+    uint32_t q16[NQW];
+#pragma unroll
+    for (int j = 0; j < NQW; ++j)
+        q16[j] = rot[li * NQW + j];
+    const float kscale = INT8KV ? s_qo * p.inv_sqrt_dh : p.inv_sqrt_dh;
+    float s[NIT];
+    float m_g = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+    {
+        const int t = t0 + i * NGRP + gid;
+        float d = 0.f;
+        if constexpr (INT8KV)
+        {
+            const uint32_t magic = 0x64646464u;
+            const h2_t bias = {(_Float16) 1152.f, (_Float16) 1152.f};
+            const uint32_t kw[4] = {kreg[i].x ^ 0x80808080u, kreg[i].y ^ 0x80808080u, kreg[i].z ^ 0x80808080u, kreg[i].w ^ 0x80808080u};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                d = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, kw[j], 0x04010400u)) - bias, u32_as_h2(q16[2 * j]), d, false);
+                d = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, kw[j], 0x04030402u)) - bias, u32_as_h2(q16[2 * j + 1]), d, false);
+            }
+        }
+        else
+        {
+            d = dot2(q16[0], kreg[i].x, d);
+            d = dot2(q16[1], kreg[i].y, d);
+            d = dot2(q16[2], kreg[i].z, d);
+            d = dot2(q16[3], kreg[i].w, d);
+        }
+        d = group_sum<LPR>(d) * kscale;
+        const bool valid = t < tl && t < Smax && (mk[i] == 0 || !has_mask); // the current token (slot tl) is member 0's ninth partial
+        s[i] = valid ? d : -INFINITY;
+        m_g = fmaxf(m_g, s[i]);
+    }
+    float l_g = 0.f, l16 = 0.f;
+    float o[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j)
+        o[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+    {
+        const float pr = (s[i] == -INFINITY) ? 0.f : __expf(s[i] - m_g);
+        l_g += pr;
+        const float p16 = h2f(f2h(pr));
+        if constexpr (INT8KV)
+        {
+            const uint32_t vw[4] = {vreg[i].x ^ 0x80808080u, vreg[i].y ^ 0x80808080u, vreg[i].z ^ 0x80808080u, vreg[i].w ^ 0x80808080u};
+            l16 += p16;
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o[4 * w + j] = fmaf(p16, (float) ((vw[w] >> (8 * j)) & 0xffu), o[4 * w + j]);
+        }
+        else
+        {
+            const uint32_t vw[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+            {
+                const h2_t hv = u32_as_h2(vw[w]);
+                o[2 * w] = fmaf(p16, (float) hv.x, o[2 * w]);
+                o[2 * w + 1] = fmaf(p16, (float) hv.y, o[2 * w + 1]);
+            }
+        }
+    }
+    if constexpr (INT8KV)
+    {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            o[j] = s_qo * (o[j] - 128.f * l16); // sum p (u - 128) = sum p u - 128 sum p
+    }
+    // the lane groups of a wave: lanes li, li + LPR, ... hold the same elements of different rows
+    {
+        float m_w = m_g;
+#pragma unroll
+        for (int sft = LPR; sft < 64; sft <<= 1)
+            m_w = fmaxf(m_w, __shfl_xor(m_w, sft, 64));
+        const float e = (m_g == -INFINITY) ? 0.f : __expf(m_g - m_w);
+        float l_w = l_g * e;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j)
+            o[j] *= e;
+#pragma unroll
+        for (int sft = LPR; sft < 64; sft <<= 1)
+        {
+            l_w += __shfl_xor(l_w, sft, 64);
+#pragma unroll
+            for (int j = 0; j < EPL; ++j)
+                o[j] += __shfl_xor(o[j], sft, 64);
+        }
+        float* wp = wpart + wid * (kDH + 8);
+        if (grp == 0)
+        {
+#pragma unroll
+            for (int j = 0; j < EPL; j += 4)
+                *reinterpret_cast<float4*>(wp + li * EPL + j) = make_float4(o[j], o[j + 1], o[j + 2], o[j + 3]);
+            if (li == 0)
+            {
+                wp[kDH] = m_w;
+                wp[kDH + 1] = l_w;
+            }
+        }
+    }
+    wg_barrier(); // D
+    TLLM_STAMP(5);
+    // the eight waves -> the member's partial, published as tagged granules: o[d] by thread d, m by thread 128, l by thread 129
+    if (tid < kDH + 2)
+    {
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < kWavesF; ++w)
+            M = fmaxf(M, wpart[w * (kDH + 8) + kDH]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < kWavesF; ++w)
+        {
+            const float mw = wpart[w * (kDH + 8) + kDH];
+            const float e = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+            L += wpart[w * (kDH + 8) + kDH + 1] * e;
+            O += wpart[w * (kDH + 8) + (tid < kDH ? tid : 0)] * e;
+        }
+        const float val = tid < kDH ? O : (tid == kDH ? M : L);
+        st_granule(gp + mem * kPartStride + tid, tag, __float_as_uint(val));
+    }
+    // ------------------------------------------------------------------ 5. the v rows: the end of the weight stream
+    project(wa, 2);
+    TLLM_STAMP(6);
+    if (mem != 0)
+        return;
+
+    // ------------------------------------------------------------------ 6. member 0: the eight partials + the current token
+    wg_barrier(); // E: the gather wave has k', v, the partials and the current token's score in LDS
+    if (misc[1] != 0.f)
+    {
+        if (tid == 0)
+            atomicOr(p.error, 2u);
+        return;
+    }
+    const bool has_new = tl < Smax;
+    if (tid < kDH)
+    {
+        const int d = tid;
+        const float s_new = misc[0];
+        float Mx = has_new ? s_new : -INFINITY;
+#pragma unroll
+        for (int i = 0; i < kMembers; ++i)
+            Mx = fmaxf(Mx, hpart[i * (kDH + 8) + kDH]);
+        float Lt = 0.f, Ot = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMembers; ++i)
+        {
+            const float mi = hpart[i * (kDH + 8) + kDH];
+            const float e = (mi == -INFINITY) ? 0.f : __expf(mi - Mx);
+            Lt += hpart[i * (kDH + 8) + kDH + 1] * e;
+            Ot += hpart[i * (kDH + 8) + d] * e;
+        }
+        if (has_new)
+        {
+            const float e = __expf(s_new - Mx);
+            const uint32_t vw = rot[128 + (d >> 1)];
+            Lt += e; // p = exp(0) = 1, exactly representable in fp16
+            Ot += e * h2f((uint16_t) ((d & 1) ? (vw >> 16) : (vw & 0xffffu)));
+        }
+        const uint16_t h16 = f2h(Ot * (1.f / (Lt + 1.e-6f)));
+        const int64_t oi = (int64_t) h * kDH + d;
+        reinterpret_cast<uint16_t*>(p.out)[oi] = h16;
+        if (p.out_q8)
+            reinterpret_cast<int8_t*>(p.out_q8)[oi] = f2i8_rni_sat(h2f(h16) * p.out_quant_scale[0]);
+    }
+    else if (tid < kDH + 16)
+    {
+        // append the current token: 8 elements per thread, K row then V row of slot tl (bit-exact row A3)
+        const int j = tid - kDH;
+        if (has_new)
+        {
+            const uint4 k8 = *reinterpret_cast<const uint4*>(rot + 64 + j * 4);
+            const uint4 v8 = *reinterpret_cast<const uint4*>(rot + 128 + j * 4);
+            const int64_t off = ((int64_t) tl * kDH + j * 8) * ESZ;
+            if constexpr (INT8KV)
+            {
+                const uint32_t kw[4] = {k8.x, k8.y, k8.z, k8.w}, vw[4] = {v8.x, v8.y, v8.z, v8.w};
+                uint32_t ko[2] = {0, 0}, vo[2] = {0, 0};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                {
+                    const uint16_t kh = (uint16_t) ((e & 1) ? (kw[e >> 1] >> 16) : (kw[e >> 1] & 0xffffu));
+                    const uint16_t vh = (uint16_t) ((e & 1) ? (vw[e >> 1] >> 16) : (vw[e >> 1] & 0xffffu));
+                    ko[e >> 2] |= ((uint32_t) (uint8_t) f2i8_rni_sat(h2f(kh) * s_oq)) << (8 * (e & 3));
+                    vo[e >> 2] |= ((uint32_t) (uint8_t) f2i8_rni_sat(h2f(vh) * s_oq)) << (8 * (e & 3));
+                }
+                *reinterpret_cast<uint2*>(kbase + off) = make_uint2(ko[0], ko[1]);
+                *reinterpret_cast<uint2*>(vbase + off) = make_uint2(vo[0], vo[1]);
+            }
+            else
+            {
+                *reinterpret_cast<uint4*>(kbase + off) = k8;
+                *reinterpret_cast<uint4*>(vbase + off) = v8;
+            }
+        }
+    }
+    else if (tid >= 192 && tid < 192 + 192 && p.qkv_out)
+    {
+        // the projection's output as the unfused launch leaves it (q | k | v, before RoPE): parity tests read it back
+        const int c = tid - 192, i = c >> 6, g = c & 63;
+        reinterpret_cast<uint32_t*>(p.qkv_out)[((int64_t) (i * H + h) * kDH) / 2 + g] = raw[c];
+    }
+    TLLM_STAMP(7);
+}
+#undef TLLM_STAMP
+
+template <bool INT8KV>
+int launch_i8(const FusedQkvAttnParams& p, int nit, hipStream_t stream)
+{
+    const dim3 grid(p.num_heads * kMembers), block(64 * (kWavesF + 1));
+#define TLLM_FUSED_LAUNCH(N) hipLaunchKernelGGL((qkv_attn_fused_kernel<N, INT8KV>), grid, block, 0, stream, p)
+    switch (nit)
+    {
+    case 1: TLLM_FUSED_LAUNCH(1); break;
+    case 2: TLLM_FUSED_LAUNCH(2); break;
+    case 3: TLLM_FUSED_LAUNCH(3); break;
+    default: TLLM_FUSED_LAUNCH(4); break;
+    }
+#undef TLLM_FUSED_LAUNCH
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+        set_error("fused QKV + attention launch failed: %s", hipGetErrorString(e));
+        return -1;
+    }
+    return 0;
+}
+
+int pick_nit(int max_seq_len, bool int8_kv)
+{
+    const int ngrp = kWavesF * (int8_kv ? 8 : 4);
+    const int need = (max_seq_len + kMembers * ngrp - 1) / (kMembers * ngrp);
+    for (int n : {1, 2, 3, 4}) // nine waves per CU leave 168 registers per lane: 4 rows of K and of V per lane group at most
+        if (need <= n)
+            return n;
+    return 0;
+}
+
+} // namespace
+
+size_t qkv_attn_fused_xchg_bytes(int32_t num_heads)
+{
+    return (size_t) num_heads * kHeadGranules * sizeof(uint64_t);
+}
+
+bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int32_t max_seq_len, int32_t int8_kv)
+{
+    if (K != kKChunks * 1024 || head_size != kDH || pick_nit(max_seq_len, int8_kv != 0) == 0)
+        return false;
+    // every workgroup of a head waits for its siblings: the whole grid must be resident at once - one 512-thread workgroup per
+    // CU is always admitted, so the grid may not exceed the CU count (and the launch only pays when it fills most of the chip)
+    static int cus = 0;
+    if (!cus)
+    {
+        int dev = 0;
+        (void) hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 1;
+    }
+    const int grid = num_heads * kMembers;
+    return grid <= cus && grid * 4 >= cus * 3;
+}
+
+int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream)
+{
+    if (!qkv_attn_fused_serves(p.K, p.num_heads, p.head_size, p.max_seq_len, p.int8_kv))
+    {
+        set_error("fused QKV + attention: shape not served (K %d, heads %d x %d, cache %d)", p.K, p.num_heads, p.head_size, p.max_seq_len);
+        return -1;
+    }
+    if (!p.x || !p.gamma || !p.w || !p.scale_col || !p.kv_cache || !p.sequence_length || !p.rope_row || !p.xchg || !p.error || !p.out
+        || !p.epoch || (p.act_quant_scale && !p.act_dequant_scale) || (p.out_q8 && !p.out_quant_scale)
+        || (p.int8_kv && (!p.kv_scale_orig_quant || !p.kv_scale_quant_orig)) || p.ldw % 16)
+    {
+        set_error("fused QKV + attention: missing operand");
+        return -1;
+    }
+    const int nit = pick_nit(p.max_seq_len, p.int8_kv != 0);
+    return p.int8_kv ? launch_i8<true>(p, nit, stream) : launch_i8<false>(p, nit, stream);
+}
+
+} // namespace kernels
+} // namespace tllm

@@ -213,6 +213,16 @@ struct tllm_session
     // brings the r01 - r03 path back (every O-projection workgroup merges all partials in its prologue)
     bool attn_tail = false;
     uint32_t* attn_tickets = nullptr;
+    // r05: batch-1 greedy decode of a SmoothQuant engine runs the QKV projection, RoPE, the cache append and the attention of a head
+    // in ONE launch (kernels/qkv_attn_fused.hip); session key fuse_qkv_attention = 0 keeps the two launches (A/B, parity tests)
+    int fuse_qkv_cfg = -1;          // -1 auto, 0 off
+    bool qkv_attn_fused = false;    // decided at setup
+    uint64_t* fused_xchg = nullptr; // granule exchange, shared by all layers
+    uint32_t* step_epoch = nullptr; // advanced by the sampler once per generation step (the granule tags derive from it)
+    uint32_t* fused_err = nullptr;  // raised by a bounded wait that expired
+    uint32_t timing_tag = 0;        // explicit tags of eager launches outside a step (tllm_session_time_kernel)
+    uint64_t* fused_timing = nullptr; // session key fused_timeline = 1: stage clock of the fused launch, [Hr * 8][16] ticks
+    bool fused_timeline = false;
     void* ctx_q8 = nullptr;
     int end_id = -1;
     hipGraphExec_t graph = nullptr;
@@ -849,6 +859,7 @@ struct tllm_session
         gp.advance = advance;
         gp.rope_row_out = rope_row;
         gp.rope_pos_out = rope_pos;
+        gp.step_epoch = step_epoch;
         gp.rope_table = rope;
         gp.rope_half = Dh / 2;
         gp.rope_table_len = rope_len;
@@ -902,7 +913,53 @@ struct tllm_session
             const bool taps = debug_taps && ok < 0;
             if (taps)
                 HIP_OK(hipMemcpyAsync(tap_ptr(4, li), x, (size_t) B * D * 2, hipMemcpyDeviceToDevice, st));
-            if (ok < 0 || ok == 1)
+            if (qkv_attn_fused)
+            {
+                // K1 + K2 + K3 in one launch (kernels/qkv_attn_fused.hip)
+                if (ok < 0 || ok == 1)
+                {
+                    FusedQkvAttnParams f;
+                    f.K = D;
+                    f.num_heads = Hr;
+                    f.head_size = Dh;
+                    f.x = x;
+                    f.gamma = L.ln1;
+                    f.eps = eps;
+                    f.w = L.qkv.w;
+                    f.ldw = L.qkv.ldw;
+                    f.scale_col = static_cast<const float*>(L.qkv.scale_col);
+                    f.per_channel = L.qkv.per_channel;
+                    f.act_quant_scale = per_token ? nullptr : L.ln1_scale;
+                    f.act_dequant_scale = per_token ? nullptr : L.qkv.act_scale;
+                    f.int8_kv = int8_kv;
+                    f.max_seq_len = Smax;
+                    f.inv_sqrt_dh = 1.f / sqrtf((float) Dh);
+                    f.kv_cache = L.kv;
+                    f.sequence_length = seq_len;
+                    f.masked_tokens = masked;
+                    f.kv_scale_orig_quant = L.kv_oq;
+                    f.kv_scale_quant_orig = L.kv_qo;
+                    f.rope_row = rope_row;
+                    f.xchg = fused_xchg;
+                    f.epoch = step_epoch;
+                    f.tag_mul = (uint32_t) num_layers + 1;
+                    f.tag_add = (uint32_t) li + 1;
+                    if (ok >= 0) // eager launches outside a step: the epoch does not advance between them
+                        f.tag_host = 0x40000000u + (++timing_tag & 0x3fffffffu);
+                    f.error = fused_err;
+                    f.qkv_out = qkv;
+                    f.out = ctx;
+                    if (sq && !per_token)
+                    {
+                        f.out_q8 = ctx_q8;
+                        f.out_quant_scale = L.attn_qscale;
+                    }
+                    f.x_pro_out = taps ? tap_ptr(0, li) : nullptr;
+                    f.timing = fused_timing;
+                    RUN(timed(PC_ATTENTION, st, [&] { return launch_qkv_attn_fused(f, st) ? 1 : 0; }));
+                }
+            }
+            else if (ok < 0 || ok == 1)
             {
                 int rc1;
                 if (fused_ar && li > 0)
@@ -963,7 +1020,7 @@ struct tllm_session
             }
             m.out = ctx;
             m.workspace = mmha_ws;
-            if (ok < 0 || ok == 2)
+            if (!qkv_attn_fused && (ok < 0 || ok == 2))
                 RUN(timed(PC_ATTENTION, st, [&] { return launch_mmha(m, st); }));
             // K4: x <- x + O(ctx)     (TP: rank 0 carries the residual into the all-reduce)
             const int pro_o = !attn_fused ? pro_q : (!sq ? PRO_ATTN : (per_token ? PRO_ATTN_QDYN : PRO_ATTN_QSTATIC));
@@ -1097,6 +1154,8 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->neox = geti("neox_rotary_style", 1);
     s->force_comm = geti("force_comm", 0) != 0;
     s->debug_taps = geti("debug_taps", 0) != 0;
+    s->fuse_qkv_cfg = geti("fuse_qkv_attention", -1);
+    s->fused_timeline = geti("fused_timeline", 0) != 0;
     if (kv.count("gemm_tactics") && !kv["gemm_tactics"].empty())
     {
         // the prefill GEMM kernels the builder's on-device profile chose (engine header; Builder.build_engine)
@@ -1571,6 +1630,33 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
         s->attn_ns = ns;
         s->attn_o_off = off;
     }
+    // the one-launch QKV projection + attention: batch 1, greedy, linear cache, SmoothQuant weights, the geometry the kernel is
+    // built for (K = 4096, head size 128, heads x 8 workgroups = one per CU), NeoX rotary over the whole head
+    RUN(s->dalloc(&s->step_epoch, 64));
+    HIP_OK(hipMemset(s->step_epoch, 0, 64));
+    s->fused_err = s->step_epoch + 8;
+    s->qkv_attn_fused = false;
+    s->fused_xchg = nullptr;
+    if (s->fuse_qkv_cfg != 0 && s->attn_tail && B == 1 && s->beam == 1 && !s->paged_kv && s->tp == 1 && s->sq && s->neox
+        && qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0))
+    {
+        bool ok = true;
+        for (auto& L : s->layers)
+            ok = ok && L.qkv.wtype == W_INT8_SQ && L.qkv.K == D && L.qkv.ldw == D && L.qkv.N == 3 * s->Dr;
+        if (ok)
+        {
+            const size_t xb = qkv_attn_fused_xchg_bytes(s->Hr);
+            RUN(s->dalloc(&s->fused_xchg, xb));
+            HIP_OK(hipMemset(s->fused_xchg, 0, xb));
+            s->qkv_attn_fused = true;
+            s->fused_timing = nullptr;
+            if (s->fused_timeline)
+            {
+                RUN(s->dalloc(&s->fused_timing, (size_t) s->Hr * 8 * 16 * 8));
+                HIP_OK(hipMemset(s->fused_timing, 0, (size_t) s->Hr * 8 * 16 * 8));
+            }
+        }
+    }
     return 0;
 }
 
@@ -1580,6 +1666,30 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
 // service, so that later sessions of this process fall back to RCCL.
 static int check_comm(tllm_session_t s)
 {
+    if (s->qkv_attn_fused && s->fused_err)
+    {
+        // the fused projection + attention launch waits (bounded) for sibling workgroups of the same launch; an expired wait means
+        // the grid was not resident at once - the rows behind it are not attention outputs
+        uint32_t e = 0;
+        if (hipMemcpy(&e, s->fused_err, 4, hipMemcpyDeviceToHost) != hipSuccess)
+        {
+            set_error("session: cannot read the fused-attention error word");
+            return 1;
+        }
+        if (e)
+        {
+            (void) hipMemset(s->fused_err, 0, 4);
+            s->qkv_attn_fused = false; // later steps take the two-launch path
+            if (s->graph)
+            {
+                (void) hipGraphExecDestroy(s->graph);
+                s->graph = nullptr;
+            }
+            set_error("session: the fused QKV + attention launch timed out waiting for a sibling workgroup (code %u); the results of "
+                      "this call are invalid, later steps run the projection and the attention as two launches", e);
+            return 1;
+        }
+    }
     // only while the transport is IN SERVICE: once a time-out has taken it out (below), later calls run over RCCL and the
     // words that recorded the failure must not fail them (disable_after_error clears them as well)
     if (s->tp == 1 && !s->force_comm)
@@ -2033,6 +2143,11 @@ int32_t tllm_session_get_tap_ex(tllm_session_t s, int32_t layer, int32_t which, 
 int32_t tllm_session_get_tap(tllm_session_t s, int32_t layer, void* host, size_t nbytes, tllm_stream_t stream)
 {
     return tllm_session_get_tap_ex(s, layer, 1, host, nbytes, stream);
+}
+
+void* tllm_session_fused_timeline_ptr(tllm_session_t s)
+{
+    return s ? s->fused_timing : nullptr;
 }
 
 void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer)
