@@ -23,8 +23,8 @@ lib.tllm_session_fused_timeline_ptr.argtypes = [ctypes.c_void_p]
 lib.tllm_session_fused_timeline_ptr.restype = ctypes.c_void_p
 hip = ctypes.CDLL('libamdhip64.so')
 hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-names = {0: 'start', 1: 'prologue done', 2: 'q rows done', 3: 'k rows done', 4: 'barrier C (q in LDS)', 5: 'barrier D (attention math)',
-         6: 'v rows done', 7: 'merger end', 8: 'gather: start', 9: 'gather: q swept', 10: 'gather(m0): k + partials', 11: 'gather(m0): v'}
+names = {0: 'start', 1: 'prologue done', 2: 'q rows done', 3: 'k rows done', 6: 'v rows done', 4: 'barrier C (q in LDS)',
+         5: 'barrier D (attention math)', 11: 'member 0: k, v, partials in LDS', 7: 'member 0: end'}
 for rnd in range(3):
     us, n = s.time_kernel('qkv', sweeps=4)
     torch.cuda.synchronize()
@@ -33,28 +33,14 @@ for rnd in range(3):
     t = t.astype(np.int64)
     t0 = t[:, 0].min()
     print(f'--- round {rnd}: {us:.2f} us per launch; last launch, us since the first workgroup started (min / median / max over workgroups)')
-    for k in range(12):
-        col = t[:, k] if k not in (7, 10, 11) else t[:32, k]
+    for k in (0, 1, 2, 3, 6, 4, 5, 11, 7):
+        col = t[:, k] if k not in (7, 11) else t[:32, k]
         col = col[col > 0]
         if len(col):
             r = (col - t0) / 100.0
             print(f'   {names[k]:30s} {r.min():7.2f} {np.median(r):7.2f} {r.max():7.2f}')
-    # per head: the q hand-off = (the slowest member's "q rows done") -> (each member's "q swept")
     H = 32
-    qd = t[:, 2].reshape(8, H)      # [member, head]
-    sw = t[:, 9].reshape(8, H)
-    lastq = qd.max(0)
-    ho = (sw - lastq[None, :]) / 100.0
-    print(f'   q hand-off (last member published -> member has q in LDS): min {ho.min():.2f} median {np.median(ho):.2f} max {ho.max():.2f} us; '
-          f'spread of "q rows done" inside a head: median {np.median((qd.max(0) - qd.min(0)) / 100.0):.2f} us')
-    sp = t[:, 12]
-    print(f'   q polls per gather wave: median {np.median(sp):.0f} (min {sp.min()}, max {sp.max()}); polling time / polls: '
-          f'{np.median((t[:, 9] - t[:, 8]) / 100.0 / np.maximum(sp + 1, 1)):.2f} us per poll')
     pd = t[:, 5].reshape(8, H)      # barrier D of every member (partials published right behind it)
-    kp = t[:H, 10]
-    print(f'   partial hand-off (last member past barrier D -> merger has all partials): median {np.median((kp - pd.max(0)) / 100.0):.2f} us')
-    vd = t[:, 6].reshape(8, H)
-    print(f'   v hand-off (last member v rows done -> merger has v): median {np.median((t[:H, 11] - vd.max(0)) / 100.0):.2f} us; '
-          f'merger end - that: median {np.median((t[:H, 7] - t[:H, 11]) / 100.0):.2f} us')
+    print(f'   partial hand-off (last member past barrier D -> member 0 has everything in LDS): median {np.median((t[:H, 11] - pd.max(0)) / 100.0):.2f} us')
 for k in ('o_proj', 'gate_up', 'down'):
     print(k, s.time_kernel(k, sweeps=8))

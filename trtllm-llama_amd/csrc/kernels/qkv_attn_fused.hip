@@ -79,25 +79,80 @@ __device__ __forceinline__ uint32_t rope_pair(uint32_t raw, const float4& cs, bo
     return lo | (hi << 16);
 }
 
-// workgroup barrier with the LDS visibility of __syncthreads(), callable from wave-uniform branches (every wave of the workgroup
-// executes the same NUMBER of barriers; a wave that has returned no longer counts)
-__device__ __forceinline__ void wg_barrier()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
 // optional stage clock (FusedQkvAttnParams::timing, tools/fused_timeline.py): the 100 MHz constant counter, one row per workgroup
 #define TLLM_STAMP(slot)                                                                                               \
     do                                                                                                                 \
     {                                                                                                                  \
-        if (p.timing && lane == 0 && (wid == 0 || wid == kWavesF))                                                     \
+        if (p.timing && lane == 0 && wid == 0)                                                                         \
             p.timing[(size_t) blockIdx.x * 16 + (slot)] = wall_clock64();                                              \
     } while (0)
 
+// v + (the value 8 / 16 / 32 lanes away), on the VALU: row rotate inside a 16-lane row, v_permlane16_swap / v_permlane32_swap of
+// the value with itself (rows 1 <-> 0 and 3 <-> 2; halves) - no LDS crossbar round trip, no wait
+__device__ __forceinline__ float add_xor8(float v)
+{
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+}
+// (inline asm, pads inside the string: with the builtin hipcc (ROCm 7.2) loses the swap's SECOND result when both operands
+// carry the same value - `v_permlane16_swap v1, v2 ; v_add_f32 v1, v1, v1` for r[0] + r[1], even behind an opaque copy)
+__device__ __forceinline__ void swap16(float v, float& a, float& b)
+{
+    a = v;
+    b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap32(float v, float& a, float& b)
+{
+    a = v;
+    b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float add_xor16(float v)
+{
+    float a, b;
+    swap16(v, a, b);
+    return a + b;
+}
+__device__ __forceinline__ float add_xor32(float v)
+{
+    float a, b;
+    swap32(v, a, b);
+    return a + b;
+}
+__device__ __forceinline__ float max_xor8(float v)
+{
+    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false)));
+}
+__device__ __forceinline__ float max_xor16(float v)
+{
+    float a, b;
+    swap16(v, a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float max_xor32(float v)
+{
+    float a, b;
+    swap32(v, a, b);
+    return fmaxf(a, b);
+}
+// over the lane groups of a wave (lanes with the same lane % LPR), LPR = 8 or 16
+template <int LPR>
+__device__ __forceinline__ float groups_sum(float v)
+{
+    if constexpr (LPR == 8)
+        v = add_xor8(v);
+    return add_xor32(add_xor16(v));
+}
+template <int LPR>
+__device__ __forceinline__ float groups_max(float v)
+{
+    if constexpr (LPR == 8)
+        v = max_xor8(v);
+    return max_xor32(max_xor16(v));
+}
+
 template <int NIT, bool INT8KV>
-__global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnParams p)
+__global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnParams p)
 {
     constexpr int EPL = INT8KV ? 16 : 8; // cache elements per lane (16 bytes)
     constexpr int LPR = kDH / EPL;       // lanes per cache row
@@ -129,178 +184,8 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
     const bool q_dyn = p.act_quant_scale == nullptr;
     gu64* gx = (gu64*) p.xchg + (size_t) h * kHeadGranules;
     gu64* gp = gx + 3 * 64;
-
-    // =================================================================== the gather wave (wave 8): every wait for another
-    // workgroup lives here, so that no compute wave ever has a hand-off load queued behind (or in front of) its weight stream -
-    // the load counter is in order.  It polls with write-through-visible (sc1) loads and sleeps between passes.
-    if (wid == kWavesF)
-    {
-        const float4 cs = reinterpret_cast<const float4*>(p.rope_row)[lane & 31]; // coefficients of elements 2 l', 2 l' + 1
-        TLLM_STAMP(8);
-        wg_barrier(); // the prologue's barriers
-        if (q_dyn)
-            wg_barrier();
-        wg_barrier();
-        bool gave_up = false;
-        unsigned long long g;
-        int spins = 0;
-        // q of the whole head: one granule per lane.  A poll takes ~2.2 us while the CU streams (measured: 3 sequential polls per
-        // launch, the hand-off = visibility + the rest of the poll in flight + one more poll = 4.8 - 5.3 us): so EIGHT polls are
-        // kept in flight, a new one requested each time the oldest comes back - the first poll issued after the last sibling's
-        // store is visible is never more than ~0.3 us away
-        {
-            unsigned long long r0 = ld_granule(gx + lane), r1, r2, r3, r4, r5, r6, r7;
-            __builtin_amdgcn_s_sleep(2);
-            r1 = ld_granule(gx + lane);
-            __builtin_amdgcn_s_sleep(2);
-            r2 = ld_granule(gx + lane);
-            __builtin_amdgcn_s_sleep(2);
-            r3 = ld_granule(gx + lane);
-            __builtin_amdgcn_s_sleep(2);
-            r4 = ld_granule(gx + lane);
-            __builtin_amdgcn_s_sleep(2);
-            r5 = ld_granule(gx + lane);
-            __builtin_amdgcn_s_sleep(2);
-            r6 = ld_granule(gx + lane);
-            __builtin_amdgcn_s_sleep(2);
-            r7 = ld_granule(gx + lane);
-#define TLLM_POLL_STEP(R)                                                                                              \
-    if (__all((uint32_t) (R >> 32) == tag))                                                                            \
-    {                                                                                                                  \
-        g = R;                                                                                                         \
-        break;                                                                                                         \
-    }                                                                                                                  \
-    if (++spins > p.max_spins)                                                                                         \
-    {                                                                                                                  \
-        g = R;                                                                                                         \
-        gave_up = true;                                                                                                \
-        break;                                                                                                         \
-    }                                                                                                                  \
-    R = ld_granule(gx + lane);
-            for (;;)
-            {
-                TLLM_POLL_STEP(r0)
-                TLLM_POLL_STEP(r1)
-                TLLM_POLL_STEP(r2)
-                TLLM_POLL_STEP(r3)
-                TLLM_POLL_STEP(r4)
-                TLLM_POLL_STEP(r5)
-                TLLM_POLL_STEP(r6)
-                TLLM_POLL_STEP(r7)
-            }
-#undef TLLM_POLL_STEP
-        }
-        if (p.timing && lane == 0)
-            p.timing[(size_t) blockIdx.x * 16 + 12] = (uint64_t) spins;
-        const uint32_t q2 = (uint32_t) g;
-        const uint32_t qrot = rope_pair(q2, cs, lane >= 32);
-        raw[lane] = q2;
-        rot[lane] = qrot;
-        if (lane == 0)
-            misc[1] = gave_up ? 1.f : 0.f;
-        wg_barrier(); // C: q' is in LDS
-        TLLM_STAMP(9);
-        if (mem != 0 || gave_up)
-            return;
-        wg_barrier(); // D (the compute waves' wave partials)
-        // member 0: k and the eight partials (published long before the weight stream ends), then v (published at its end)
-        unsigned long long gk, gpart[kMembers][3];
-        for (;;)
-        {
-            gk = ld_granule(gx + 64 + lane);
-#pragma unroll
-            for (int i = 0; i < kMembers; ++i)
-            {
-                gpart[i][0] = ld_granule(gp + i * kPartStride + lane);
-                gpart[i][1] = ld_granule(gp + i * kPartStride + 64 + lane);
-                gpart[i][2] = ld_granule(gp + i * kPartStride + 128 + (lane & 1)); // m, l
-            }
-            __builtin_amdgcn_sched_barrier(0); // all 25 requests of a pass in flight before the first tag is looked at
-            uint32_t bad = (uint32_t) (gk >> 32) ^ tag; // (no short-circuit: a branch per tag serialises the loads)
-#pragma unroll
-            for (int i = 0; i < kMembers; ++i)
-                bad |= ((uint32_t) (gpart[i][0] >> 32) ^ tag) | ((uint32_t) (gpart[i][1] >> 32) ^ tag) | ((uint32_t) (gpart[i][2] >> 32) ^ tag);
-            if (__all(bad == 0))
-                break;
-            if (++spins > p.max_spins)
-            {
-                gave_up = true;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        const uint32_t k2 = (uint32_t) gk;
-        const uint32_t krot = rope_pair(k2, cs, lane >= 32);
-        raw[64 + lane] = k2;
-        rot[64 + lane] = krot;
-#pragma unroll
-        for (int i = 0; i < kMembers; ++i)
-        {
-            hpart[i * (kDH + 8) + lane] = __uint_as_float((uint32_t) gpart[i][0]);
-            hpart[i * (kDH + 8) + 64 + lane] = __uint_as_float((uint32_t) gpart[i][1]);
-            if (lane < 2)
-                hpart[i * (kDH + 8) + 128 + lane] = __uint_as_float((uint32_t) gpart[i][2]);
-        }
-        // score of the current token: the un-quantised q'.k' (MM/...Template.h:1517-1549)
-        const float dn = wave_sum(dot2(qrot, krot, 0.f)) * p.inv_sqrt_dh;
-        TLLM_STAMP(10);
-        for (;;)
-        {
-            g = ld_granule(gx + 128 + lane);
-            if (__all((uint32_t) (g >> 32) == tag))
-                break;
-            if (++spins > p.max_spins)
-            {
-                gave_up = true;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        raw[128 + lane] = (uint32_t) g;
-        rot[128 + lane] = (uint32_t) g;
-        if (lane == 0)
-        {
-            misc[0] = dn;
-            misc[1] = gave_up ? 2.f : 0.f;
-        }
-        TLLM_STAMP(11);
-        wg_barrier(); // E: everything the final merge needs is in LDS
-        return;
-    }
-
-    // =================================================================== the eight compute waves
-    // ------------------------------------------------------------------ t = 0: every request that depends on nobody
-    // (a) x: vectors t and t + 256 of the 256-thread prologue this one restates (threads >= 256 repeat the first half's work so
-    //     that no load sits behind a branch); gamma for the vector this thread normalises
-    const int t2 = tid & 255;
-    TLLM_STAMP(0);
-    const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x);
-    const uint4 xa = *reinterpret_cast<const uint4*>(xg + t2 * 8);
-    const uint4 xb = *reinterpret_cast<const uint4*>(xg + (t2 + 256) * 8);
-    const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.gamma) + tid * 8);
-    // the per-channel scales of the wave's 6 rows: consumed right behind the first tile's dots, and the load counter is in
-    // order - requested behind the weights they would be waited for behind the whole stream
-    int wrow[3];
-    float cscale[3][2];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-    {
-        wrow[i] = (i * H + h) * kDH + mem * 16 + 2 * wid;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-            cscale[i][r] = p.scale_col[p.per_channel ? wrow[i] + r : 0];
-    }
-    __builtin_amdgcn_sched_barrier(0); // issue order = consumption order (hipcc sank the gamma load below the weight loads)
-    // (b) the wave's q rows: rows 2 wid, 2 wid + 1 of the member's 16 (the k rows follow behind the prologue, the v rows into
-    //     the q rows' registers)
-    const char* wbase = reinterpret_cast<const char*>(p.w);
-    uint4 wa[kKChunks][2], wb[kKChunks][2];
-#pragma unroll
-    for (int u = 0; u < kKChunks; ++u)
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-            wa[u][r] = ld_nt16(wbase + (int64_t) (wrow[0] + r) * p.ldw + u * 1024 + lane * 16);
-    __builtin_amdgcn_sched_barrier(0);
+    // launch constants, requested before anything else (and before the kernel's first store: behind one hipcc no longer uses the
+    // scalar path for them, and as vector loads behind the q rows they held the prologue until the q rows had arrived)
     float pro_q = 1.f, deq = 1.f;
     if (!q_dyn) // uniform
     {
@@ -313,6 +198,42 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
         s_oq = p.kv_scale_orig_quant[0];
         s_qo = p.kv_scale_quant_orig[0];
     }
+
+    // ------------------------------------------------------------------ t = 0: x, gamma, the scales and the q rows
+    // (a) x: vectors t and t + 256 of the 256-thread prologue this one restates (threads >= 256 repeat the first half's work so
+    //     that no load sits behind a branch); gamma for the vector this thread normalises
+    const int t2 = tid & 255;
+    const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x);
+    const uint4 xa = *reinterpret_cast<const uint4*>(xg + t2 * 8);
+    const uint4 xb = *reinterpret_cast<const uint4*>(xg + (t2 + 256) * 8);
+    const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.gamma) + tid * 8);
+    // the per-channel scales of the wave's 6 rows (wave-uniform addresses: scalar loads)
+    int wrow[3];
+    float cscale[3][2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+        wrow[i] = (i * H + h) * kDH + mem * 16 + 2 * wid;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            cscale[i][r] = p.scale_col[p.per_channel ? wrow[i] + r : 0];
+    }
+    const float4 cs = reinterpret_cast<const float4*>(p.rope_row)[lane & 31]; // RoPE coefficients of elements 2 l', 2 l' + 1
+    __builtin_amdgcn_sched_barrier(0); // issue order = consumption order (hipcc sank the gamma load below the weight loads)
+    // (b) the wave's q rows: rows 2 wid, 2 wid + 1 of the member's 16.  The k rows follow behind the prologue, the v rows into
+    //     the q rows' registers behind their dots: two 8 KB tiles per wave = 128 KB per CU in flight.  NOT the whole stream at
+    //     t = 0 (r05 first form, 230 KB per CU): a CU drains its load queue in order at ~25 GB/s, and what has to pass through it
+    //     later - the instruction fetch of the code below, x itself - waited: the prologue finished 6.6 us after the launch
+    //     instead of 3.4 (tools/fused_timeline.py).
+    const char* wbase = reinterpret_cast<const char*>(p.w);
+    uint4 wa[kKChunks][2], wb[kKChunks][2];
+#pragma unroll
+    for (int u = 0; u < kKChunks; ++u)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            wa[u][r] = ld_nt16(wbase + (int64_t) (wrow[0] + r) * p.ldw + u * 1024 + lane * 16);
+    __builtin_amdgcn_sched_barrier(0);
+    TLLM_STAMP(0);
 
     // ------------------------------------------------------------------ 1. RMSNorm + quantiser -> LDS (gemv_impl.h PK_NORM, MB = 1)
     {
@@ -328,7 +249,7 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
         ss = wave_sum(ss);
         if (lane == 0 && wid < 4)
             red[wid] = ss;
-        wg_barrier();
+        __syncthreads();
         ss = red[0] + red[1] + red[2] + red[3];
         const float inv = 1.0f / sqrtf(ss / (float) K + p.eps);
         // this thread's own vector: tid * 8 (threads < 256: vector a, the others: vector b)
@@ -352,7 +273,7 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
             amax = wave_max(amax);
             if (lane == 0)
                 red[32 + wid] = amax;
-            wg_barrier();
+            __syncthreads();
             amax = red[32];
 #pragma unroll
             for (int w = 1; w < kWavesF; ++w)
@@ -372,17 +293,9 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
         }
         *reinterpret_cast<uint2*>(xs + tid * 8) = make_uint2(o[0], o[1]);
     }
-    wg_barrier();
+    __syncthreads();
     TLLM_STAMP(1);
-    // (b2) the k rows and the member's cache rows - requested when the q rows have ARRIVED, not before.  A CU drains its load
-    // queue in order at ~25 GB/s, and everything that has to pass through that queue later - the instruction fetch of the code
-    // below, above all the gather wave's polls - waits behind what is already in it.  Measured with the stage clock
-    // (tools/fused_timeline.py): the whole stream requested at t = 0 (230 KB per CU): prologue done 6.6 us after the launch;
-    // q rows at t = 0, k rows + cache rows behind the prologue, v rows behind the q rows' dots (134 KB queued when q becomes
-    // visible): the q hand-off takes 5.2 us (the partial hand-off, behind a nearly empty queue: 1.5).  One tile (+ the cache rows)
-    // per wave in flight = 64 - 98 KB per CU keeps the memory as busy (> latency x rate ~ 50 KB) and a poll waits 2 - 2.5 us.
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the q rows are here
+    // (b2) the k rows, (c) the member's cache rows and masks
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < kKChunks; ++u)
@@ -390,8 +303,6 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
         for (int r = 0; r < 2; ++r)
             wb[u][r] = ld_nt16(wbase + (int64_t) (wrow[1] + r) * p.ldw + u * 1024 + lane * 16);
     __builtin_amdgcn_sched_barrier(0);
-    // (c) the member's cache rows: behind the q and k rows and AHEAD of the v rows in the queue - they are consumed between
-    //     the k rows and the v rows, under the rest of the stream
     const int li = lane % LPR, grp = lane / LPR, gid = wid * RPW + grp;
     const int t0 = mem * TCHUNK;
     char* kbase = reinterpret_cast<char*>(p.kv_cache) + ((int64_t) 0 * H + h) * Smax * kDH * ESZ;
@@ -442,8 +353,6 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
     project(wa, 0);
     TLLM_STAMP(2);
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the k rows and the cache rows are here
-    __builtin_amdgcn_sched_barrier(0);
     // the v rows, into the registers the q rows have left
 #pragma unroll
     for (int u = 0; u < kKChunks; ++u)
@@ -453,9 +362,45 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
     __builtin_amdgcn_sched_barrier(0);
     project(wb, 1);
     TLLM_STAMP(3);
+    // The first look at the head's q (and, member 0, k) granules is requested HERE, behind the v rows in this wave's in-order
+    // load queue: the siblings published them microseconds ago, the answer comes back with the v rows - when it is needed - and
+    // costs nothing.  (Polling for them while the weights stream does: a poll takes ~2.2 us under load and slows the stream,
+    // measured with a ninth "gather" wave: the q hand-off took 4.8 - 6.3 us and the launch 17 - 20 us.)
+    unsigned long long gq = 0, gk = 0;
+    if (wid == 0)
+    {
+        gq = ld_granule(gx + lane);
+        gk = ld_granule(gx + 64 + lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ------------------------------------------------------------------ 3. the v rows: the end of the weight stream
+    project(wa, 2);
+    TLLM_STAMP(6);
 
-    // ------------------------------------------------------------------ 3. q' of the whole head is in LDS (the gather wave)
-    wg_barrier(); // C
+    // ------------------------------------------------------------------ 4. q' of the whole head -> LDS (wave 0; RoPE in the sweep)
+    uint32_t qrot = 0;
+    if (wid == 0)
+    {
+        bool gave_up = false;
+        int spins = 0;
+        while (!__all((uint32_t) (gq >> 32) == tag))
+        {
+            if (++spins > p.max_spins)
+            {
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            gq = ld_granule(gx + lane);
+        }
+        const uint32_t q2 = (uint32_t) gq;
+        qrot = rope_pair(q2, cs, lane >= 32);
+        raw[lane] = q2;
+        rot[lane] = qrot;
+        if (lane == 0)
+            misc[1] = gave_up ? 1.f : 0.f;
+    }
+    __syncthreads(); // C
     TLLM_STAMP(4);
     if (misc[1] != 0.f) // uniform: a sibling never published (a workgroup that is not resident: see the launcher's residency rule)
     {
@@ -464,13 +409,24 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
         return;
     }
 
-    // ------------------------------------------------------------------ 4. scores, softmax partial and P.V of this member's rows
-    //                                                                       (the v rows of the weights are still in flight)
+    // ------------------------------------------------------------------ 5. scores, softmax partial and P.V of this member's rows
     uint32_t q16[NQW];
 #pragma unroll
     for (int j = 0; j < NQW; ++j)
         q16[j] = rot[li * NQW + j];
     const float kscale = INT8KV ? s_qo * p.inv_sqrt_dh : p.inv_sqrt_dh;
+    // int8 cache: the bytes are spliced into fp16 1024 + u (u = value + 128) and enter the dot product as they are; 1152 x (the sum
+    // of this lane's q) comes off once per row instead of 1152 off every element (gemv_impl.h dot_u8x4_raw: the same 16 : 1 ratio
+    // of bias to signal, fp32 sums)
+    float qsum1152 = 0.f;
+    if constexpr (INT8KV)
+    {
+        const h2_t ones = {(_Float16) 1.f, (_Float16) 1.f};
+#pragma unroll
+        for (int j = 0; j < NQW; ++j)
+            qsum1152 = __builtin_amdgcn_fdot2(u32_as_h2(q16[j]), ones, qsum1152, false);
+        qsum1152 *= 1152.f;
+    }
     float s[NIT];
     float m_g = -INFINITY;
 #pragma unroll
@@ -481,14 +437,14 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
         if constexpr (INT8KV)
         {
             const uint32_t magic = 0x64646464u;
-            const h2_t bias = {(_Float16) 1152.f, (_Float16) 1152.f};
             const uint32_t kw[4] = {kreg[i].x ^ 0x80808080u, kreg[i].y ^ 0x80808080u, kreg[i].z ^ 0x80808080u, kreg[i].w ^ 0x80808080u};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
             {
-                d = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, kw[j], 0x04010400u)) - bias, u32_as_h2(q16[2 * j]), d, false);
-                d = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, kw[j], 0x04030402u)) - bias, u32_as_h2(q16[2 * j + 1]), d, false);
+                d = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, kw[j], 0x04010400u)), u32_as_h2(q16[2 * j]), d, false);
+                d = __builtin_amdgcn_fdot2(u32_as_h2(__builtin_amdgcn_perm(magic, kw[j], 0x04030402u)), u32_as_h2(q16[2 * j + 1]), d, false);
             }
+            d -= qsum1152;
         }
         else
         {
@@ -535,31 +491,17 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
             }
         }
     }
-    if constexpr (INT8KV)
+    // the lane groups of a wave (lanes li, li + LPR, ... hold the same elements of different rows): one weight per group, the
+    // int8 scale and offset folded into it, sums on the VALU cross-lane network
     {
-#pragma unroll
-        for (int j = 0; j < EPL; ++j)
-            o[j] = s_qo * (o[j] - 128.f * l16); // sum p (u - 128) = sum p u - 128 sum p
-    }
-    // the lane groups of a wave: lanes li, li + LPR, ... hold the same elements of different rows
-    {
-        float m_w = m_g;
-#pragma unroll
-        for (int sft = LPR; sft < 64; sft <<= 1)
-            m_w = fmaxf(m_w, __shfl_xor(m_w, sft, 64));
+        const float m_w = groups_max<LPR>(m_g);
         const float e = (m_g == -INFINITY) ? 0.f : __expf(m_g - m_w);
-        float l_w = l_g * e;
+        const float l_w = groups_sum<LPR>(l_g * e);
+        const float es = INT8KV ? e * s_qo : e;
+        const float off = INT8KV ? -128.f * l16 : 0.f; // sum p (u - 128) = sum p u - 128 sum p
 #pragma unroll
         for (int j = 0; j < EPL; ++j)
-            o[j] *= e;
-#pragma unroll
-        for (int sft = LPR; sft < 64; sft <<= 1)
-        {
-            l_w += __shfl_xor(l_w, sft, 64);
-#pragma unroll
-            for (int j = 0; j < EPL; ++j)
-                o[j] += __shfl_xor(o[j], sft, 64);
-        }
+            o[j] = groups_sum<LPR>((o[j] + off) * es);
         float* wp = wpart + wid * (kDH + 8);
         if (grp == 0)
         {
@@ -573,7 +515,7 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
             }
         }
     }
-    wg_barrier(); // D
+    __syncthreads(); // D
     TLLM_STAMP(5);
     // the eight waves -> the member's partial, published as tagged granules: o[d] by thread d, m by thread 128, l by thread 129
     if (tid < kDH + 2)
@@ -594,14 +536,71 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
         const float val = tid < kDH ? O : (tid == kDH ? M : L);
         st_granule(gp + mem * kPartStride + tid, tag, __float_as_uint(val));
     }
-    // ------------------------------------------------------------------ 5. the v rows: the end of the weight stream
-    project(wa, 2);
-    TLLM_STAMP(6);
     if (mem != 0)
         return;
 
-    // ------------------------------------------------------------------ 6. member 0: the eight partials + the current token
-    wg_barrier(); // E: the gather wave has k', v, the partials and the current token's score in LDS
+    // ------------------------------------------------------------------ 6. member 0: k, v, the eight partials -> context row
+    if (wid == 0)
+    {
+        bool gave_up = false;
+        int spins = 0;
+        unsigned long long gvv = ld_granule(gx + 128 + lane);
+        while (!__all((uint32_t) (gk >> 32) == tag && (uint32_t) (gvv >> 32) == tag))
+        {
+            if (++spins > p.max_spins)
+            {
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            gk = ld_granule(gx + 64 + lane);
+            gvv = ld_granule(gx + 128 + lane);
+        }
+        const uint32_t k2 = (uint32_t) gk, v2 = (uint32_t) gvv;
+        const uint32_t krot = rope_pair(k2, cs, lane >= 32);
+        raw[64 + lane] = k2;
+        raw[128 + lane] = v2;
+        rot[64 + lane] = krot;
+        rot[128 + lane] = v2;
+        // score of the current token: the un-quantised q'.k' (MM/...Template.h:1517-1549)
+        const float dn = wave_sum(dot2(qrot, krot, 0.f)) * p.inv_sqrt_dh;
+        if (lane == 0)
+        {
+            misc[0] = dn;
+            if (gave_up)
+                misc[1] = 1.f;
+        }
+    }
+    else if (wid <= 3 && tid - 64 < kDH + 2) // waves 1 - 3: column c of the eight partials
+    {
+        const int c = tid - 64;
+        unsigned long long g[kMembers];
+        int spins = 0;
+        for (;;)
+        {
+#pragma unroll
+            for (int i = 0; i < kMembers; ++i)
+                g[i] = ld_granule(gp + i * kPartStride + c);
+            __builtin_amdgcn_sched_barrier(0);
+            uint32_t bad = 0;
+#pragma unroll
+            for (int i = 0; i < kMembers; ++i)
+                bad |= (uint32_t) (g[i] >> 32) ^ tag;
+            if (__all(bad == 0))
+                break;
+            if (++spins > p.max_spins)
+            {
+                misc[1] = 1.f;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int i = 0; i < kMembers; ++i)
+            hpart[i * (kDH + 8) + c] = __uint_as_float((uint32_t) g[i]);
+    }
+    __syncthreads(); // E
+    TLLM_STAMP(11);
     if (misc[1] != 0.f)
     {
         if (tid == 0)
@@ -683,14 +682,16 @@ __global__ __launch_bounds__(576) void qkv_attn_fused_kernel(const FusedQkvAttnP
 template <bool INT8KV>
 int launch_i8(const FusedQkvAttnParams& p, int nit, hipStream_t stream)
 {
-    const dim3 grid(p.num_heads * kMembers), block(64 * (kWavesF + 1));
+    const dim3 grid(p.num_heads * kMembers), block(64 * kWavesF);
 #define TLLM_FUSED_LAUNCH(N) hipLaunchKernelGGL((qkv_attn_fused_kernel<N, INT8KV>), grid, block, 0, stream, p)
     switch (nit)
     {
     case 1: TLLM_FUSED_LAUNCH(1); break;
     case 2: TLLM_FUSED_LAUNCH(2); break;
     case 3: TLLM_FUSED_LAUNCH(3); break;
-    default: TLLM_FUSED_LAUNCH(4); break;
+    case 4: TLLM_FUSED_LAUNCH(4); break;
+    case 6: TLLM_FUSED_LAUNCH(6); break;
+    default: TLLM_FUSED_LAUNCH(8); break;
     }
 #undef TLLM_FUSED_LAUNCH
     const hipError_t e = hipGetLastError();
@@ -706,7 +707,7 @@ int pick_nit(int max_seq_len, bool int8_kv)
 {
     const int ngrp = kWavesF * (int8_kv ? 8 : 4);
     const int need = (max_seq_len + kMembers * ngrp - 1) / (kMembers * ngrp);
-    for (int n : {1, 2, 3, 4}) // nine waves per CU leave 168 registers per lane: 4 rows of K and of V per lane group at most
+    for (int n : {1, 2, 3, 4, 6, 8})
         if (need <= n)
             return n;
     return 0;
