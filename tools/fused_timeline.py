@@ -40,6 +40,8 @@ for rnd in range(3):
             r = (col - t0) / 100.0
             print(f'   {names[k]:30s} {r.min():7.2f} {np.median(r):7.2f} {r.max():7.2f}')
     H = 32
+    print(f'   extra q polls of the sweeping wave: {np.bincount(t[:, 12].astype(np.int64)).tolist()} (workgroups with 0, 1, 2, .. re-polls); '
+          f'q in LDS - v rows done, by re-polls: ' + ', '.join(f'{k}: {np.median((t[:, 4] - t[:, 6])[t[:, 12] == k]) / 100.0:.2f} us' for k in sorted(set(t[:, 12].tolist()))))
     pd = t[:, 5].reshape(8, H)      # barrier D of every member (partials published right behind it)
     print(f'   partial hand-off (last member past barrier D -> member 0 has everything in LDS): median {np.median((t[:H, 11] - pd.max(0)) / 100.0):.2f} us')
 for k in ('o_proj', 'gate_up', 'down'):

@@ -107,6 +107,19 @@ __device__ __forceinline__ void swap32(float v, float& a, float& b)
     b = v;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
+// TWO values per swap: with a = X, b = Y the swap leaves X's row pairs in a's even rows / b's even rows and Y's in the odd ones, so
+// a' + b' holds (X + X^16) in rows 0, 2 and (Y + Y^16) in rows 1, 3 - one swap and one add reduce two values, no copies
+__device__ __forceinline__ float pair_xor16(float x, float y)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+// likewise over the wave's halves: the result holds (X + X^32) in lanes 0 - 31 and (Y + Y^32) in lanes 32 - 63
+__device__ __forceinline__ float pair_xor32(float x, float y)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
 __device__ __forceinline__ float add_xor16(float v)
 {
     float a, b;
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     float* wpart = reinterpret_cast<float*>(raw + 3 * 64);                 // [8][136]: o[128], m, l per wave
     float* hpart = wpart + kWavesF * (kDH + 8);                            // [8][136]: the head's partials (member 0)
     float* misc = hpart + kMembers * (kDH + 8);                            // [0] score of the current token, [1] give-up flag
+    uint32_t* qflag = reinterpret_cast<uint32_t*>(misc + 2);               // set by wave 0 once q' is in `rot`
 
     const int H = p.num_heads;
     const int h = blockIdx.x % H, mem = blockIdx.x / H;
@@ -249,6 +263,11 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         ss = wave_sum(ss);
         if (lane == 0 && wid < 4)
             red[wid] = ss;
+        if (tid == 0)
+        {
+            misc[1] = 0.f;
+            *qflag = 0u;
+        }
         __syncthreads();
         ss = red[0] + red[1] + red[2] + red[3];
         const float inv = 1.0f / sqrtf(ss / (float) K + p.eps);
@@ -366,9 +385,16 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     // load queue: the siblings published them microseconds ago, the answer comes back with the v rows - when it is needed - and
     // costs nothing.  (Polling for them while the weights stream does: a poll takes ~2.2 us under load and slows the stream,
     // measured with a ninth "gather" wave: the q hand-off took 4.8 - 6.3 us and the launch 17 - 20 us.)
+    // (Every wave sweeping for itself - no workgroup barrier behind the sweep - was measured: 64 waves per head polling the same
+    // four lines with write-through loads made every poll slower, the launch 16.9 -> 18.7 us.  One sweeping wave per workgroup,
+    // the others wait on an LDS flag.)
     unsigned long long gq = 0, gk = 0;
     if (wid == 0)
     {
+        // (not at once: the load EXECUTES soon after it is issued - only its return is ordered behind the v rows - and the slowest
+        // sibling's q granule is ~1 us behind this wave's k rows; the v rows are ~2 us away, so the pause costs nothing.  Without
+        // it the first look missed often and the second took 1.8 us)
+        __builtin_amdgcn_s_sleep(64);
         gq = ld_granule(gx + lane);
         gk = ld_granule(gx + 64 + lane);
     }
@@ -377,37 +403,41 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     project(wa, 2);
     TLLM_STAMP(6);
 
-    // ------------------------------------------------------------------ 4. q' of the whole head -> LDS (wave 0; RoPE in the sweep)
+    // ------------------------------------------------------------------ 4. q' of the whole head -> LDS (wave 0; RoPE in the sweep).
+    //          No workgroup barrier: the other waves wait on an LDS flag, each from the moment ITS v rows are done (the eight waves'
+    //          v rows arrive up to ~2 us apart; a barrier would hold all of them for the last)
     uint32_t qrot = 0;
     if (wid == 0)
     {
-        bool gave_up = false;
         int spins = 0;
         while (!__all((uint32_t) (gq >> 32) == tag))
         {
-            if (++spins > p.max_spins)
+            if (++spins > p.max_spins) // a sibling never published (a workgroup that is not resident: see the launcher's residency rule)
             {
-                gave_up = true;
+                if (lane == 0)
+                    misc[1] = 1.f;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
             gq = ld_granule(gx + lane);
         }
+        if (p.timing && lane == 0)
+            p.timing[(size_t) blockIdx.x * 16 + 12] = (uint64_t) spins;
         const uint32_t q2 = (uint32_t) gq;
         qrot = rope_pair(q2, cs, lane >= 32);
         raw[lane] = q2;
         rot[lane] = qrot;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0)
-            misc[1] = gave_up ? 1.f : 0.f;
+            __hip_atomic_store(qflag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    __syncthreads(); // C
-    TLLM_STAMP(4);
-    if (misc[1] != 0.f) // uniform: a sibling never published (a workgroup that is not resident: see the launcher's residency rule)
+    else
     {
-        if (tid == 0)
-            atomicOr(p.error, 1u);
-        return;
+        while (__hip_atomic_load(qflag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u)
+            __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    TLLM_STAMP(4);
 
     // ------------------------------------------------------------------ 5. scores, softmax partial and P.V of this member's rows
     uint32_t q16[NQW];
@@ -492,7 +522,8 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         }
     }
     // the lane groups of a wave (lanes li, li + LPR, ... hold the same elements of different rows): one weight per group, the
-    // int8 scale and offset folded into it, sums on the VALU cross-lane network
+    // int8 scale and offset folded into it; the sums on the VALU cross-lane network, two values per swap: after the 16-lane and
+    // the 32-lane level the 16-lane row r of the wave holds the totals of elements 4 m + r (m = 0 ..), which is where it stores them
     {
         const float m_w = groups_max<LPR>(m_g);
         const float e = (m_g == -INFINITY) ? 0.f : __expf(m_g - m_w);
@@ -501,22 +532,37 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         const float off = INT8KV ? -128.f * l16 : 0.f; // sum p (u - 128) = sum p u - 128 sum p
 #pragma unroll
         for (int j = 0; j < EPL; ++j)
-            o[j] = groups_sum<LPR>((o[j] + off) * es);
+        {
+            o[j] = (o[j] + off) * es;
+            if constexpr (LPR == 8)
+                o[j] = add_xor8(o[j]);
+        }
+        float y[EPL / 4];
+#pragma unroll
+        for (int m = 0; m < EPL / 4; ++m)
+            y[m] = pair_xor32(pair_xor16(o[4 * m], o[4 * m + 1]), pair_xor16(o[4 * m + 2], o[4 * m + 3]));
         float* wp = wpart + wid * (kDH + 8);
-        if (grp == 0)
+        const int row = lane >> 4;
+        if (LPR == 16 || (lane & 8) == 0)
         {
 #pragma unroll
-            for (int j = 0; j < EPL; j += 4)
-                *reinterpret_cast<float4*>(wp + li * EPL + j) = make_float4(o[j], o[j + 1], o[j + 2], o[j + 3]);
-            if (li == 0)
-            {
-                wp[kDH] = m_w;
-                wp[kDH + 1] = l_w;
-            }
+            for (int m = 0; m < EPL / 4; ++m)
+                wp[li * EPL + 4 * m + row] = y[m];
+        }
+        if (lane == 0)
+        {
+            wp[kDH] = m_w;
+            wp[kDH + 1] = l_w;
         }
     }
     __syncthreads(); // D
     TLLM_STAMP(5);
+    if (misc[1] != 0.f) // uniform
+    {
+        if (tid == 0)
+            atomicOr(p.error, 1u);
+        return;
+    }
     // the eight waves -> the member's partial, published as tagged granules: o[d] by thread d, m by thread 128, l by thread 129
     if (tid < kDH + 2)
     {
