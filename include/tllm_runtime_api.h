@@ -209,7 +209,7 @@ int32_t tllm_gemv(const tllm_gemv_params_t* p, tllm_stream_t stream);
 void tllm_gemv_set_blocks_per_cu(int32_t n);
 /* Test/bench knob: number of rows (sequences) from which the SmoothQuant decode GEMM runs on the matrix pipe
  * (kernels/gemv_mfma_sq.hip, static activation scales) instead of the skinny vector-ALU kernel: 0 = never, -1 = the default
- * (environment TLLM_GEMV_MFMA_ROWS, else 5).  Both kernels give bit-identical results. */
+ * (5).  Both kernels give bit-identical results. */
 void tllm_gemv_set_mfma_rows(int32_t n);
 /* Test/bench knob: kernel id of the prefill GEMM (0 = tactic table, else the static rule).  1..12: lock-step tile shapes of
  * kernels/gemm_glds.hip (8 = 128x128, 6 = 256x192, 2 = 256x256, 4 = 128x256 are the production ones); 13..42: the phased

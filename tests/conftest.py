@@ -15,8 +15,15 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    # a -m gpu run on a box without a GPU must fail loudly, not skip silently
-    pass
+    # a -m gpu run on a box without a GPU must fail loudly, not skip silently: the gpu-marked tests that were SELECTED need one
+    expr = config.getoption('-m') or ''
+    if 'gpu' not in expr or 'not gpu' in expr:
+        return
+    if not any(it.get_closest_marker('gpu') for it in items):
+        return
+    import torch
+    if not torch.cuda.is_available():
+        pytest.exit('pytest -m gpu: no GPU is visible to torch - the gpu-marked tests cannot run here (they do not skip)', returncode=3)
 
 
 @pytest.fixture(scope='session')

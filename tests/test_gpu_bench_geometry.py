@@ -2,11 +2,12 @@
 so far): one decoder layer at LLaMA-7B dimensions (D = 4096, 32 heads of 128, I = 11008) behind a real 1150-token prefill,
 then four generation steps - two eager, two replayed from the step's hipGraph.
 
-What runs that the small-shape tests do not reach together: `mmha_partial_kernel<128, 12, int8 | fp16>` with a cache
-capacity of 1156 slots (7 split slots; 6 of them active at lengths 1150 / 1151, all 7 at 1152 / 1153), the 7-slot split-KV
-merge in the O-projection's prologue (`gemv_kernel<.., PK_ATTN, ..>`, K = 4096) with the static SmoothQuant quantiser behind
-it, the K-split down-projection at K = 11008, and the prefill GEMMs at M = 1150 (256 x 192 / 128 x 128 MFMA tiles with a
-ragged last row tile).
+What runs that the small-shape tests do not reach together: for SmoothQuant at the 7B dimensions the one-launch QKV projection
++ RoPE + cache append + attention (`qkv_attn_fused_kernel<3, int8>`: 8 workgroups per head, a cache capacity of 1156 slots, 6 of
+the 8 members holding used slots; the 13B rows take the two launches); for the other modes `mmha_partial_kernel<128, 12, int8 |
+fp16>` with 7 split slots (6 active at lengths 1150 / 1151, all 7 at 1152 / 1153) and the merge by the last split of a head to
+arrive inside that launch; the static SmoothQuant quantiser behind either, the K-split down-projection at K = 11008, and the
+prefill GEMMs at M = 1150 (256 x 192 / 128 x 128 MFMA tiles with a ragged last row tile).
 
 Checked per step: the O-projection's INPUT (the merged attention context, `tllm_session_get_tap`) at the reference's
 generation-attention tolerance atol 2e-3 (T/tests/attention/test_gpt_attention.py:828-831) - for SmoothQuant the tap is the

@@ -1,6 +1,6 @@
 """Weight-only prefill GEMM (gemm_woq.hip: dequantisation in the main loop) at the LLaMA-7B prefill shapes: every requested
-tile id (101 = 256 x 192, 102 = 128 x 128, 103 = 256 x 192 two stages ahead, 104 = 256 x 192 on 4 waves, 0 = the launcher's rule;
--1 = the r02 path when run with TLLM_WOQ_EXPAND=1) timed interleaved in one process, plus the fp16 kernel on the same shapes.
+tile id (101 = 256 x 192, 102 = 128 x 128, 103 = 256 x 192 two stages ahead, 104 = 256 x 192 on 4 waves, 0 = the launcher's rule)
+timed interleaved in one process, plus the fp16 kernel on the same shapes.
     python tools/woq_gemm_sweep.py [M] [bits] cfg [cfg ...]"""
 import ctypes
 import os

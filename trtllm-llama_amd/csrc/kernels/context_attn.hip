@@ -6,7 +6,7 @@
 // Here: (1) one pass applies RoPE to q,k in place in the packed QKV buffer (the reference rewrites it too,
 // K/unfusedAttentionKernels.cu:1401-1403) and writes RoPE'd K and raw V into the cache [B,2,H,Smax,Dh]
 // (int8: sat(rni(x * s)); padded rows are written as zero); (2) a flash-style pass, online softmax, no score matrix:
-// MFMA tiles for head sizes 64 / 128 when the caller provides the V^T scratch (see context_attn_mfma_kernel), else
+// MFMA tiles for head sizes 64 / 128 when the caller provides the V^T scratch (see context_attn_mfma_ks_kernel), else
 // one wave per query row reading K/V straight from the packed buffer.
 // Numerics as the decode kernel: fp32 dot / softmax / accumulation, probabilities rounded to fp16, one
 // rounding to fp16 at the end; keys j > i or j >= input_len[b] are excluded (the reference adds -10000, whose
@@ -385,253 +385,8 @@ __device__ __forceinline__ int swz128(int row, int c16)
     return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4);
 }
 
-// V [B, S, 3*H*DH] (the v part of the packed QKV buffer) -> V^T scratch [B, H, DH, spad]; keys >= S are zero.
-// grid (spad / 64, H, B), 256 threads.
-template <int DH>
-__global__ __launch_bounds__(256) void v_transpose_kernel(const ContextAttnParams p, int spad)
-{
-    constexpr int PITCH = DH + 2; // halfs; odd number of dwords -> the column reads below are conflict-free
-    __shared__ uint16_t tile[64 * PITCH];
-    const int kv0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const int H = p.num_heads, S = p.seq;
-    const uint16_t* vb = reinterpret_cast<const uint16_t*>(p.qkv) + seq_row0(p, b) * 3 * H * DH + (int64_t) (2 * H + h) * DH;
-    const int nrows = p.cu_seqlens ? p.input_lengths[b] : S; // rows that exist (padded: rows >= len were zeroed in place)
-    constexpr int CPR = DH / 8; // 16-byte pieces per key row
-    for (int i = threadIdx.x; i < 64 * CPR; i += 256)
-    {
-        const int key = i / CPR, c = i % CPR;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (kv0 + key < nrows)
-            v = *reinterpret_cast<const uint4*>(vb + (int64_t) (kv0 + key) * 3 * H * DH + c * 8);
-        uint32_t* d = reinterpret_cast<uint32_t*>(tile + key * PITCH + c * 8);
-        d[0] = v.x;
-        d[1] = v.y;
-        d[2] = v.z;
-        d[3] = v.w;
-    }
-    __syncthreads();
-    uint16_t* vt = reinterpret_cast<uint16_t*>(p.workspace) + ((int64_t) (b * H + h) * DH) * spad + kv0;
-    for (int i = threadIdx.x; i < DH * 8; i += 256)
-    {
-        const int d = i % DH, g = i / DH; // 8 keys g * 8 .. + 8 of column d
-        uint32_t w[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            w[j] = (uint32_t) tile[(g * 8 + 2 * j) * PITCH + d] | ((uint32_t) tile[(g * 8 + 2 * j + 1) * PITCH + d] << 16);
-        *reinterpret_cast<uint4*>(vt + (int64_t) d * spad + g * 8) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-}
 
-// grid (ceil(S / 128), H, B), 256 threads; heavy (late) query blocks first.
-// Waves 0 - 3 compute (32 queries each); waves 4 - 7 only issue the LDS-DMA of the K / V^T tiles: an LDS-DMA instruction holds
-// its issuer for 100 - 185 cycles, and with ONE compute wave per SIMD nothing covered the 8 of them per key block (r02:
-// ~1/4 of the time per block).  The loaders share the SIMDs with the compute waves (2 x ~180 VGPRs fit) and run one block ahead.
-template <int DH>
-__global__ __launch_bounds__(512) void context_attn_mfma_kernel(const ContextAttnParams p, int spad)
-{
-    constexpr int NSUB = DH / 64;              // 128-byte sub-tiles of a K row
-    constexpr int KST = DH / 16;               // k-steps of the QK product
-    constexpr int DT = DH / 32;                // 32-row tiles of O^T / V^T
-    constexpr int K_BYTES = 64 * DH * 2;       // K tile  [NSUB][64][128 B]
-    constexpr int STAGE = K_BYTES + DH * 128;  // + V^T tile [DH][128 B]
-    constexpr int CHUNKS = STAGE / 1024, CPW = CHUNKS / 4;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool loader = wave >= 4;
-    const int wid = wave & 3; // query quarter (compute waves) / chunk set (loaders)
-    const int qb = gridDim.x - 1 - blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int H = p.num_heads, S = p.seq;
-    const int q0 = qb * 128 + wid * 32; // first query of this wave
-    const int ql = lane & 31, hf = lane >> 5;
-    const int q = q0 + ql;
-    const int len = p.input_lengths[b];
-    const int64_t rs = (int64_t) 3 * H * DH * 2; // bytes per token row of the fused QKV buffer
-    const char* qkv = reinterpret_cast<const char*>(p.qkv) + seq_row0(p, b) * rs;
-    const int nrows = p.cu_seqlens ? len : S; // token rows of this sequence that exist in the buffers
-    const char* vt = reinterpret_cast<const char*>(p.workspace) + ((int64_t) (b * H + h) * DH) * spad * 2;
-
-    // Q fragments (B operand): lane (q, half) holds d = 16 s + 8 half .. + 8 for every k-step s
-    uint4 qf[KST];
-    {
-        const char* qrow = qkv + (int64_t) (q < nrows ? q : nrows - 1) * rs + (int64_t) h * DH * 2;
-#pragma unroll
-        for (int s = 0; s < KST; ++s)
-            qf[s] = *reinterpret_cast<const uint4*>(qrow + (16 * s + 8 * hf) * 2);
-    }
-
-    if (qb * 128 >= nrows) // packed inputs: this query block lies entirely beyond the sequence (block-uniform)
-        return;
-    const int kv_end = (qb * 128 + 128 < nrows ? qb * 128 + 128 : nrows); // causal: keys <= the block's last query
-    const int nkb = (kv_end + 63) / 64;
-    const uint32_t lds_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void*) lds;
-    auto issue = [&](int t) {
-        const int kv0 = t * 64;
-#pragma unroll
-        for (int i = 0; i < CPW; ++i)
-        {
-            const int c = i * 4 + wid;
-            const int r8 = lane >> 3;
-            const char* src;
-            if (c < 8 * NSUB)
-            {
-                const int sub = c / 8, row = (c % 8) * 8 + r8;
-                const int col = (lane & 7) ^ ((row >> 1) & 7);
-                const int key = kv0 + row < nrows ? kv0 + row : nrows - 1;
-                src = qkv + (int64_t) key * rs + (int64_t) (H + h) * DH * 2 + sub * 128 + col * 16;
-            }
-            else
-            {
-                const int d = (c - 8 * NSUB) * 8 + r8;
-                const int col = (lane & 7) ^ ((d >> 1) & 7);
-                src = vt + ((int64_t) d * spad + kv0) * 2 + col * 16;
-            }
-            glds16(src, lds_base + (t & 1) * STAGE + c * 1024);
-        }
-    };
-
-    f32x16_t oacc[DT];
-#pragma unroll
-    for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            oacc[i][r] = 0.f;
-    float m = -INFINITY, l = 0.f;
-    const int krow = (ql & ~12) | ((ql & 4) << 1) | ((ql & 8) >> 1); // pi(ql): bits 2 and 3 swapped
-
-    if (loader)
-        issue(0);
-    for (int t = 0; t < nkb; ++t)
-    {
-        if (loader)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads(); // block t is in LDS for everybody; the compute waves are done with block t - 1
-        if (loader)
-        {
-            if (t + 1 < nkb)
-                issue(t + 1); // into the stage block t - 1 occupied (a third stage with a counted wait: no gain, 40.2 vs 41.0 us)
-            continue;
-        }
-        const int kv0 = t * 64;
-        if (kv0 > q0 + 31) // every key of this block is in the future of every query of this wave (wave-uniform)
-            continue;
-        const char* Ks = lds + (t & 1) * STAGE;
-        const char* Vs = Ks + K_BYTES;
-        f32x16_t sacc[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sacc[nt][r] = 0.f;
-#pragma unroll
-        for (int s = 0; s < KST; ++s)
-        {
-            f16x8_t bq;
-            __builtin_memcpy(&bq, &qf[s], 16);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-            {
-                const uint4 kk = *reinterpret_cast<const uint4*>(
-                    Ks + (s >> 2) * (64 * 128) + swz128(nt * 32 + krow, (2 * s + hf) & 7));
-                f16x8_t ak;
-                __builtin_memcpy(&ak, &kk, 16);
-                sacc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ak, bq, sacc[nt], 0, 0, 0);
-            }
-        }
-        // scale, causal mask, block max
-        float mt = -INFINITY;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-            {
-                const int key = kv0 + nt * 32 + 16 * (r >> 3) + 8 * hf + (r & 7);
-                const float v = key <= q ? sacc[nt][r] * p.inv_sqrt_dh : -INFINITY;
-                sacc[nt][r] = v;
-                mt = fmaxf(mt, v);
-            }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float mn = fmaxf(m, mt);
-        const float alpha = (m == -INFINITY) ? 0.f : __expf(m - mn);
-        m = mn;
-        l *= alpha;
-#pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                oacc[i][r] *= alpha;
-        // probabilities -> fp16 B fragments (8 consecutive keys per register octet), PV product
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2)
-        {
-            f16x8_t bp;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-            {
-                const float sv = sacc[s2 >> 1][8 * (s2 & 1) + j];
-                const float pr = (sv == -INFINITY) ? 0.f : __expf(sv - m);
-                l += pr;
-                bp[j] = (_Float16) pr;
-            }
-#pragma unroll
-            for (int i = 0; i < DT; ++i)
-            {
-                const uint4 vv = *reinterpret_cast<const uint4*>(Vs + swz128(i * 32 + ql, 2 * s2 + hf));
-                f16x8_t av;
-                __builtin_memcpy(&av, &vv, 16);
-                oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bp, oacc[i], 0, 0, 0);
-            }
-        }
-    }
-
-    // ---- normalise, transpose through LDS, store whole rows.  oacc[i][r]: d = 32 i + 8 (r >> 2) + 4 half + (r & 3)
-    l += __shfl_xor(l, 32, 64);
-    const float inv = (q < len) ? 1.f / (l + 1.e-6f) : 0.f; // padding queries produce zero rows
-    constexpr int PITCH = DH * 2 + 16;
-    __syncthreads(); // every wave is done with the operand stages
-    if (loader)
-        return;
-    char* scr = lds + wid * (32 * PITCH);
-#pragma unroll
-    for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-        {
-            const uint32_t w0 = pack_h2(oacc[i][4 * g] * inv, oacc[i][4 * g + 1] * inv);
-            const uint32_t w1 = pack_h2(oacc[i][4 * g + 2] * inv, oacc[i][4 * g + 3] * inv);
-            *reinterpret_cast<uint2*>(scr + ql * PITCH + (32 * i + 8 * g + 4 * hf) * 2) = make_uint2(w0, w1);
-        }
-    constexpr int PPR = DH / 8; // 16-byte pieces per output row
-    uint16_t* outp = reinterpret_cast<uint16_t*>(p.out) + seq_row0(p, b) * H * DH + (int64_t) h * DH;
-#pragma unroll
-    for (int i = lane; i < 32 * PPR; i += 64)
-    {
-        const int row = i / PPR, pc = i % PPR;
-        const uint4 v = *reinterpret_cast<const uint4*>(scr + row * PITCH + pc * 16);
-        if (q0 + row < nrows)
-        {
-            if (p.out_q8) // uniform: the static quantiser of the O-projection's input, on the fp16-rounded values
-            {
-                const float qs = p.out_q_scale[0];
-                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-                uint32_t o2[2] = {0, 0};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                {
-                    const uint32_t b0 = (uint8_t) f2i8_rni_sat(h2f((uint16_t) (w4[e] & 0xffffu)) * qs);
-                    const uint32_t b1 = (uint8_t) f2i8_rni_sat(h2f((uint16_t) (w4[e] >> 16)) * qs);
-                    o2[e >> 1] |= (b0 | (b1 << 8)) << (16 * (e & 1));
-                }
-                int8_t* qp = p.out_q8 + (seq_row0(p, b) + q0 + row) * (int64_t) H * DH + (int64_t) h * DH + pc * 8;
-                *reinterpret_cast<uint2*>(qp) = make_uint2(o2[0], o2[1]);
-            }
-            else
-                *reinterpret_cast<uint4*>(outp + (int64_t) (q0 + row) * H * DH + pc * 8) = v;
-        }
-    }
-}
-
-// Key-split variant of the kernel above, the one launch_dh uses: 2 NQ compute waves (NQ = 4: two per SIMD), no loader waves.
+// The MFMA kernel launch_dh uses (key-split; r01's 4 compute + 4 loader wave form was removed in r05): 2 NQ compute waves (NQ = 4: two per SIMD), no loader waves.
 // Waves w and w + NQ serve the same 32 queries and split every 64-key block between them (keys 32 kh .. 32 kh + 31, kh = w / NQ):
 // per block each wave runs half the QK^T MFMAs, the softmax of 16 scores per lane and half the PV MFMAs on its own running
 // (m, l, O), so that one wave's MFMAs run under the other's softmax arithmetic on the same SIMD - with one compute wave per SIMD
@@ -969,39 +724,22 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
     bool mfma = false;
     if constexpr (DH == 64 || DH == 128)
     {
-        if (p.workspace && p.seq >= 64)
+        if (p.workspace && p.seq >= 64 && p.inv_sqrt_dh > 0.f)
         {
             mfma = true;
             const int spad = (p.seq + 63) / 64 * 64;
-            static const bool unfused_vt = getenv("TLLM_CTX_ATTN_UNFUSED_VT") != nullptr; // A/B switch
-            if (unfused_vt)
-            {
-                hipLaunchKernelGGL((rope_kv_write_kernel<DH>), dim3(p.seq, (p.num_heads + HG - 1) / HG, p.batch), dim3(256), 0, stream, p);
-                hipLaunchKernelGGL((v_transpose_kernel<DH>), dim3(spad / 64, p.num_heads, p.batch), dim3(256), 0, stream, p, spad);
-            }
-            else
-                hipLaunchKernelGGL((rope_kv_vt_kernel<DH>), dim3(spad / 64, p.num_heads, p.batch), dim3(256), 0, stream, p, spad);
-            static const bool old_kernel = getenv("TLLM_CTX_ATTN_OLD") != nullptr; // A/B switch: the 4 + 4 wave kernel
+            // RoPE + KV write (+ int8 quantisation) + the V^T image in one launch
+            hipLaunchKernelGGL((rope_kv_vt_kernel<DH>), dim3(spad / 64, p.num_heads, p.batch), dim3(256), 0, stream, p, spad);
             static std::atomic<bool> attr_done{false};
-            if (old_kernel || !(p.inv_sqrt_dh > 0.f))
             {
-                constexpr size_t smem = 2 * (size_t) (64 * DH * 2 + DH * 128);
-                auto kfn = context_attn_mfma_kernel<DH>;
-                hipLaunchKernelGGL(kfn, dim3((p.seq + 127) / 128, p.num_heads, p.batch), dim3(512), smem, stream, p, spad);
-            }
-            else
-            {
-                // 64-query workgroups while 128-query ones would not fill the chip (TLLM_CTX_ATTN_NQ overrides: A/B switch)
-                static const int nq_env = getenv("TLLM_CTX_ATTN_NQ") ? atoi(getenv("TLLM_CTX_ATTN_NQ")) : 0;
-                bool narrow = nq_env ? nq_env == 2 : (int64_t) ((p.seq + 127) / 128) * p.num_heads * p.batch < 256;
+                // 64-query workgroups while 128-query ones would not fill the chip
+                bool narrow = (int64_t) ((p.seq + 127) / 128) * p.num_heads * p.batch < 256;
                 constexpr size_t stages = 2 * (size_t) (64 * DH * 2 + DH * 128), slab = (size_t) (2 + 16 * (DH / 32)) * 64 * 4;
                 // Paired 64-query blocks while the launch is at most ONE round of 128-query workgroups (32 heads, r02,
                 // profiles/r02_ctx_attn_pairing.txt: S = 1024, 256 workgroups on 256 CUs, 31.9 -> 26.8 us; S = 896 / 768 / 512 / 384 /
                 // 256, where the unpaired choice is the 64-query kernel, 28.0 -> 24.1, 24.5 -> 21.0, 18.5 -> 16.4, 15.8 -> 14.3,
                 // 12.5 -> 12.0): with more workgroups than CUs the dispatcher already back-fills the CUs of the short blocks and
                 // pairing only makes every workgroup long (S = 1536: 44 -> 58 us, S = 2048: 61.6 -> 72.4).
-                // TLLM_CTX_ATTN_UNPAIRED / TLLM_CTX_ATTN_PAIRED force either way (A/B, tests).
-                const bool unpaired = getenv("TLLM_CTX_ATTN_UNPAIRED") != nullptr, force_pair = getenv("TLLM_CTX_ATTN_PAIRED") != nullptr; // read per launch
                 static std::atomic<int> cus_cache{0};
                 int cus = cus_cache.load();
                 if (!cus)
@@ -1013,18 +751,17 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
                     cus_cache.store(cus);
                 }
                 const int64_t wg128 = (int64_t) ((p.seq + 127) / 128) * p.num_heads * p.batch;
-                const bool pair = !unpaired && !nq_env && (force_pair || (wg128 <= cus && 4 * wg128 >= cus));
+                const bool pair = wg128 <= cus && 4 * wg128 >= cus;
                 if (pair)
                     narrow = false;
                 // three operand stages only under the paired kernel (S = 1024: 28.1 -> 27.4 us; one block per workgroup loses with
                 // them: 30.4 -> 31.2 at S = 1024, 61.6 -> 63.0 at 2048 - the operand stream is bound by its rate, not by the latency
-                // of one block in flight).  TLLM_CTX_ATTN_NORING / TLLM_CTX_ATTN_RING force either way (A/B, read per launch).
-                const bool ring = getenv("TLLM_CTX_ATTN_RING") ? true : (getenv("TLLM_CTX_ATTN_NORING") ? false : pair);
+                // of one block in flight; profiles/r02_ctx_attn_pairing.txt)
+                const bool ring = pair;
                 const size_t stg = ring ? stages / 2 * 3 : stages;
                 const size_t smem = stg > (narrow ? 2 : 4) * slab ? stg : 4 * slab;
-                auto kfn = narrow ? (ring ? context_attn_mfma_ks_kernel<DH, 2, false, true> : context_attn_mfma_ks_kernel<DH, 2>)
-                    : (pair ? (ring ? context_attn_mfma_ks_kernel<DH, 4, true, true> : context_attn_mfma_ks_kernel<DH, 4, true>)
-                            : (ring ? context_attn_mfma_ks_kernel<DH, 4, false, true> : context_attn_mfma_ks_kernel<DH, 4>));
+                auto kfn = narrow ? context_attn_mfma_ks_kernel<DH, 2>
+                                  : (pair ? context_attn_mfma_ks_kernel<DH, 4, true, true> : context_attn_mfma_ks_kernel<DH, 4>);
                 if (!attr_done)
                 {
                     if (stages > 64 * 1024 || 4 * slab > 64 * 1024)
@@ -1032,12 +769,6 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
                         (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 2>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                         (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 2, false, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4, false, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                         (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);

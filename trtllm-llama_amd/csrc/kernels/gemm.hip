@@ -16,62 +16,7 @@ int launch_gemm_mfma(const GemmParams& p, hipStream_t stream); // gemm_mfma.hip;
 int launch_gemm_woq(const GemmParams& p, hipStream_t stream);  // gemm_woq.hip (weight-only, dequantisation in the main loop); same
 int launch_gemm_glds(const GemmParams& p, hipStream_t stream); // gemm_glds.hip (SQ / fp16, LDS-DMA staged); same convention
 
-namespace
-{
 using namespace dev;
-
-// u8 (q + 128) / nibble (q + 8) weights [N][ldw] -> fp16 q exactly, [N][K]; one thread per 16 bytes of weights
-template <int BITS>
-__global__ __launch_bounds__(256) void woq_expand_kernel(uint16_t* out, const char* w, int64_t ldw, int32_t N, int32_t K)
-{
-    constexpr int EPV = BITS == 8 ? 16 : 32; // elements per 16-byte vector
-    const int64_t vecs_per_row = K / EPV;
-    const int64_t total = (int64_t) N * vecs_per_row;
-    for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t) gridDim.x * blockDim.x)
-    {
-        const int64_t n = i / vecs_per_row, v = i % vecs_per_row;
-        const uint4 q = *reinterpret_cast<const uint4*>(w + n * ldw + v * 16);
-        uint16_t* o = out + n * K + v * EPV;
-        const uint32_t ws[4] = {q.x, q.y, q.z, q.w};
-        if constexpr (BITS == 8)
-        {
-            const uint32_t magic = 0x64646464u;
-            const h2_t bias = {(_Float16) 1152.f, (_Float16) 1152.f};
-            uint32_t r[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-            {
-                r[2 * j] = h2_as_u32(u32_as_h2(__builtin_amdgcn_perm(magic, ws[j], 0x04010400u)) - bias);
-                r[2 * j + 1] = h2_as_u32(u32_as_h2(__builtin_amdgcn_perm(magic, ws[j], 0x04030402u)) - bias);
-            }
-            *reinterpret_cast<uint4*>(o) = make_uint4(r[0], r[1], r[2], r[3]);
-            *reinterpret_cast<uint4*>(o + 8) = make_uint4(r[4], r[5], r[6], r[7]);
-        }
-        else
-        {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-            {
-                // nibble order of weight_layout.h: e0 e2 e4 e6 | e1 e3 e5 e7
-                const uint32_t m = 0x64006400u, w8 = ws[j] >> 8;
-                const h2_t b0 = {(_Float16) 1032.f, (_Float16) 1032.f};
-                const h2_t s1 = {(_Float16) 0.0625f, (_Float16) 0.0625f};
-                const h2_t b1 = {(_Float16) -72.f, (_Float16) -72.f};
-                const uint32_t e01 = h2_as_u32(u32_as_h2((ws[j] & 0x000f000fu) | m) - b0);
-                const uint32_t e23 = h2_as_u32(u32_as_h2((ws[j] & 0x00f000f0u) | m) * s1 + b1);
-                const uint32_t e45 = h2_as_u32(u32_as_h2((w8 & 0x000f000fu) | m) - b0);
-                const uint32_t e67 = h2_as_u32(u32_as_h2((w8 & 0x00f000f0u) | m) * s1 + b1);
-                *reinterpret_cast<uint4*>(o + 8 * j) = make_uint4(e01, e23, e45, e67);
-            }
-        }
-    }
-}
-} // namespace
-
-size_t gemm_woq_scratch_bytes(int32_t N, int32_t K)
-{
-    return (size_t) N * K * 2;
-}
 
 static int gemv_slab(const GemmParams& p, int m0, int rows, hipStream_t stream)
 {
@@ -115,6 +60,11 @@ int launch_gemm(const GemmParams& pin, hipStream_t stream)
     if (pin.silu_gate && pin.wtype == W_INT8_SQ)
     {
         // SmoothQuant has its own fused form (launch_gemm_swiglu); here: the plain product, then the pointwise pass
+        if (pin.ldc != pin.N) // the pointwise pass runs over M * N contiguous elements
+        {
+            set_error("gemm: a strided SwiGLU gate is not supported with SmoothQuant weights (ldc %lld != N %d)", (long long) pin.ldc, pin.N);
+            return -1;
+        }
         GemmParams q = pin;
         q.silu_gate = nullptr;
         const int rc = launch_gemm(q, stream);
@@ -123,34 +73,13 @@ int launch_gemm(const GemmParams& pin, hipStream_t stream)
     if (pin.M > 8)
     {
         const bool woq = pin.wtype == W_INT8_WOQ || pin.wtype == W_INT4_WOQ;
-        static const bool expand_only = getenv("TLLM_WOQ_EXPAND") != nullptr; // A/B switch: the r02 path (fp16 image in a scratch buffer)
-        if (woq && !expand_only)
+        if (woq)
         {
             // weight-only at prefill sizes: the u8 / nibble tile by LDS-DMA, dequantised between LDS and the MFMA fragments -
-            // no fp16 image of the weights, a third of the expanded path's HBM traffic
+            // no fp16 image of the weights (r01 / r02 expanded the matrix to fp16 in a scratch buffer on every call: 3 N K bytes
+            // of HBM traffic the algorithm does not have; removed in r05, profiles/r03_woq_gemm_sweep.txt).  Shapes it does not
+            // serve (K % 64 != 0, M < 32) take the register-staged kernel below.
             const int r = launch_gemm_woq(pin, stream);
-            if (r <= 0)
-                return r;
-        }
-        if (woq && pin.scratch && pin.M >= 32 && pin.K % (pin.wtype == W_INT8_WOQ ? 16 : 32) == 0 && pin.K % 64 == 0
-            && !(reinterpret_cast<uintptr_t>(pin.w) & 15) && !(pin.ldw & 15))
-        {
-            // weight-only at prefill sizes: integers -> fp16 once (exact), then the LDS-DMA staged fp16 MFMA kernel with
-            // the per-channel scale in its epilogue - the same arithmetic as the register-staged kernel, ~1.5x faster
-            const int64_t vecs = (int64_t) pin.N * (pin.K / (pin.wtype == W_INT8_WOQ ? 16 : 32));
-            const int grid = (int) ((vecs + 255) / 256 < 8192 ? (vecs + 255) / 256 : 8192);
-            if (pin.wtype == W_INT8_WOQ)
-                hipLaunchKernelGGL(woq_expand_kernel<8>, dim3(grid), dim3(256), 0, stream, static_cast<uint16_t*>(pin.scratch),
-                    static_cast<const char*>(pin.w), pin.ldw, pin.N, pin.K);
-            else
-                hipLaunchKernelGGL(woq_expand_kernel<4>, dim3(grid), dim3(256), 0, stream, static_cast<uint16_t*>(pin.scratch),
-                    static_cast<const char*>(pin.w), pin.ldw, pin.N, pin.K);
-            GemmParams e = pin;
-            e.wtype = W_FP16;
-            e.w = pin.scratch;
-            e.ldw = (int64_t) pin.K * 2;
-            e.scratch = nullptr;
-            const int r = launch_gemm_glds(e, stream);
             if (r <= 0)
                 return r;
         }

@@ -550,8 +550,10 @@ static bool glds_serves(const GemmParams& p)
         return false;
     if (!sq && p.out_dtype == DT_INT32)
         return false;
-    if (p.residual && (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)))
-        return false; // the fused residual lives in the vector epilogue
+    if (p.residual
+        && (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.residual) & 15)))
+        return false; // the fused residual lives in the vector epilogue (a mis-aligned residual: launch_gemm adds it in a pass)
     if (p.silu_gate
         && (sq || p.residual || p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
             || (reinterpret_cast<uintptr_t>(p.silu_gate) & 15)))

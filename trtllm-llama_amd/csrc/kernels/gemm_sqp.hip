@@ -667,8 +667,10 @@ int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
         return 1;
     if ((int64_t) p.M * p.lda >= (1ll << 31) || (int64_t) p.N * p.ldw >= (1ll << 31))
         return 1; // 32-bit DMA offsets
-    if (p.residual && p.out_dtype != DT_HALF)
-        return 1;
+    if (p.residual
+        && (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.residual) & 15)))
+        return 1; // the fused residual lives in the vector epilogue: a mis-aligned one is not served
     switch (cfg)
     {
     //                              waves  tiles/half  DMA after MFMA # (low / high waves)  setprio
@@ -716,8 +718,10 @@ int launch_gemm_f16p(const GemmParams& pin, int cfg, hipStream_t stream)
         return 1;
     if ((int64_t) p.M * p.lda * 2 >= (1ll << 31) || (int64_t) p.N * p.ldw >= (1ll << 31))
         return 1; // 32-bit DMA offsets
-    if (p.residual && p.out_dtype != DT_HALF)
-        return 1;
+    if (p.residual
+        && (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.residual) & 15)))
+        return 1; // the fused residual lives in the vector epilogue: a mis-aligned one is not served
     if (p.silu_gate
         && (p.residual || p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
             || (reinterpret_cast<uintptr_t>(p.silu_gate) & 15)))

@@ -21,7 +21,7 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     const bool sq = p.wtype == W_INT8_SQ;
     if (sq && p.M >= 2)
     {
-        // several sequences: from 5 rows on (TLLM_GEMV_MFMA_ROWS) the matrix-pipe kernel, whose time hardly grows with the rows
+        // several sequences: from 5 rows on (tllm_gemv_set_mfma_rows) the matrix-pipe kernel, whose time hardly grows with the rows
         // (gemv_mfma_sq.hip; bit-identical results) - returns 1 at once below its threshold or for a prologue it does not build
         const int r = launch_gemv_mfma_sq(p, stream);
         if (r <= 0)
@@ -44,14 +44,7 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
             {
                 GemvParams q = p;
                 q.M = p.M - m0 < fit ? p.M - m0 : fit;
-                if (p.pro < PRO_ATTN)
-                    q.x = static_cast<const char*>(p.x) + (int64_t) m0 * p.ldx * (raw_s8 ? 1 : 2);
-                else
-                {
-                    q.attn_ml = static_cast<const char*>(p.attn_ml) + (int64_t) m0 * p.attn_heads * p.attn_nsmax * 8;
-                    q.attn_o = p.attn_o + (int64_t) m0 * p.attn_heads * p.attn_nsmax * p.attn_dh;
-                    q.attn_seq_len = p.attn_seq_len + m0;
-                }
+                q.x = static_cast<const char*>(p.x) + (int64_t) m0 * p.ldx * (raw_s8 ? 1 : 2);
                 const int yes = p.out_dtype == DT_INT8 ? 1 : (p.out_dtype == DT_HALF ? 2 : 4);
                 q.y = static_cast<char*>(p.y) + (int64_t) m0 * p.ldy * yes;
                 if (p.residual)
@@ -69,8 +62,7 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
         }
     }
     const bool swiglu = p.epi == EPI_SWIGLU || p.epi == EPI_SWIGLU_QSTATIC;
-    const bool quant_pro = (p.pro >= PRO_RMSNORM_QSTATIC && p.pro <= PRO_QDYN) || p.pro == PRO_ATTN_QSTATIC
-        || p.pro == PRO_ATTN_QDYN;
+    const bool quant_pro = p.pro >= PRO_RMSNORM_QSTATIC && p.pro <= PRO_QDYN;
     if (!sq && quant_pro)
     {
         set_error("gemv: quantising prologue needs W_INT8_SQ");
@@ -85,21 +77,11 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     case PRO_RMSNORM_QDYN: pk = PK_NORM; break;
     case PRO_QSTATIC:
     case PRO_QDYN: pk = PK_QUANT; break;
-    case PRO_ATTN:
-    case PRO_ATTN_QSTATIC:
-    case PRO_ATTN_QDYN: pk = PK_ATTN; break;
     default: set_error("gemv: bad prologue %d", p.pro); return -1;
     }
-    if (sq && (p.pro == PRO_RMSNORM || p.pro == PRO_ATTN))
+    if (sq && p.pro == PRO_RMSNORM)
     {
         set_error("gemv: W_INT8_SQ needs a quantising prologue (or s8 activations with PRO_NONE)");
-        return -1;
-    }
-    if (pk == PK_ATTN
-        && (!p.attn_ml || !p.attn_o || !p.attn_seq_len || p.attn_heads * p.attn_dh != p.K || (p.attn_dh & 7)
-            || p.attn_tchunk <= 0 || p.attn_nsmax <= 0))
-    {
-        set_error("gemv: PRO_ATTN needs the split-KV partials (heads * dh == K, dh %% 8 == 0)");
         return -1;
     }
     if ((reinterpret_cast<uintptr_t>(p.w) & 15) || (p.ldw & 15))
@@ -125,7 +107,7 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
         set_error("gemv: K=%d must be a multiple of %d and <= %d", p.K, xvec, 256 * xvec * nxv_lim);
         return -1;
     }
-    if (pk != PK_ATTN && ((reinterpret_cast<uintptr_t>(p.x) & 15) || ((p.ldx * (raw_s8 ? 1 : 2)) & 15)))
+    if (((reinterpret_cast<uintptr_t>(p.x) & 15) || ((p.ldx * (raw_s8 ? 1 : 2)) & 15)))
     {
         set_error("gemv: activation pointer / row stride must be 16-byte aligned");
         return -1;
@@ -145,8 +127,7 @@ int launch_gemv(const GemvParams& p, hipStream_t stream)
     }
     a.nchunks = (a.Kp + 64 * vec - 1) / (64 * vec);
     a.ngroups = swiglu ? p.N : (p.N + R - 1) / R;
-    static const bool ksplit_off = getenv("TLLM_NO_KSPLIT") != nullptr; // A/B switch
-    if (!ksplit_off && gemv_ksplit_applies(a))
+    if (gemv_ksplit_applies(a))
         return launch_gemv_ksplit(a, stream);
     switch (p.wtype)
     {

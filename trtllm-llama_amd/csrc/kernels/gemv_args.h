@@ -22,8 +22,7 @@ enum ProKind
 {
     PK_COPY = 0,  // x already in the operand type
     PK_NORM = 1,  // RMSNorm (+ quant for SQ)
-    PK_QUANT = 2, // fp16 -> s8 (SQ)
-    PK_ATTN = 3   // split-KV merge (+ quant for SQ)
+    PK_QUANT = 2  // fp16 -> s8 (SQ)
 };
 enum EpiKind
 {
@@ -49,7 +48,7 @@ int launch_gemv_woq8(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream)
 int launch_gemv_woq4(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
 int launch_gemv_sq(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream);
 // SmoothQuant, several rows (2 <= M <= 8), static activation scales: the matrix-pipe kernel (gemv_mfma_sq.hip); 1 = not served
-extern int gemv_mfma_min_rows; // rows from which launch_gemv tries it (0 = never; -1 = TLLM_GEMV_MFMA_ROWS or the default 5, read on next use)
+extern int gemv_mfma_min_rows; // rows from which launch_gemv tries it (0 = never; -1 = the default 5)
 int launch_gemv_mfma_sq(const GemvParams& p, hipStream_t stream);
 // "few rows, long K" single-token projections, every weight type (gemv_ksplit.hip)
 bool gemv_ksplit_applies(const GemvArgs& a);

@@ -4,8 +4,8 @@
 //
 // One wave owns 2 weight rows per step and streams them with 16-byte non-temporal loads (1 KiB per wave
 // instruction, 4 k-chunks per row = an 8 KiB tile, double-buffered); pro(x) is built once per workgroup in
-// registers and published to LDS (RMSNorm and/or int8 quantisation and/or the split-KV attention merge fused in,
-// so the normalised / quantised activation never goes to HBM); the dot products use v_dot2_f32_f16
+// registers and published to LDS (RMSNorm and/or int8 quantisation fused in, so the normalised / quantised activation
+// never goes to HBM); the dot products use v_dot2_f32_f16
 // (fp16 x fp16 -> fp32) or v_dot4_i32_i8 (SmoothQuant, exact int32); reduction over the 64 lanes on the DPP
 // network; residual-add / SwiGLU / quantising epilogues fused.  Persistent grid (<= what the chip holds at once).
 //
@@ -203,8 +203,8 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     float* red = reinterpret_cast<float*>(smem);
     char* xs = smem + kRedBytes; // [MB][Kp] halfs, or [MB][Kp] s8 for SQ
     constexpr int XES = SQ ? 1 : 2;
-    const bool q_dyn = SQ && (p.pro == PRO_RMSNORM_QDYN || p.pro == PRO_QDYN || p.pro == PRO_ATTN_QDYN);
-    const bool q_static = SQ && (p.pro == PRO_RMSNORM_QSTATIC || p.pro == PRO_QSTATIC || p.pro == PRO_ATTN_QSTATIC);
+    const bool q_dyn = SQ && (p.pro == PRO_RMSNORM_QDYN || p.pro == PRO_QDYN);
+    const bool q_static = SQ && (p.pro == PRO_RMSNORM_QSTATIC || p.pro == PRO_QSTATIC);
 
     // ------------------------------------------------------------------ weight-tile helpers
     const char* wbase = reinterpret_cast<const char*>(p.w);
@@ -246,99 +246,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
     // ------------------------------------------------------------------ t = 0: every x-independent request
     uint4 xv[kNXV], gv[kNXV];
     auto load_x_row = [&](int m) {
-        if constexpr (PK == PK_ATTN)
-        {
-            // ctx[h, d] = sum_i e_i o_i[d] / (sum_i e_i l_i + 1e-6),  e_i = exp(m_i - max_i m_i)  (MM/...Template.h:1756)
-            // Every partial of every vector this thread owns is requested before the first value is looked at (one
-            // memory round trip); addresses do not depend on the sequence length, slots beyond the active count get
-            // weight 0 by a select.  NS = compile-time slot count (registers: NS x 10 per vector).
-            const float2* ml = reinterpret_cast<const float2*>(p.attn_ml);
-            const int seq = p.attn_seq_len[m];
-            auto merge = [&](auto ns_tag) {
-                constexpr int NS = decltype(ns_tag)::value;
-                constexpr int NV = kNXV < 2 ? kNXV : 2; // vectors merged together (K <= 4096: all of them)
-                const int nsm = p.attn_nsmax < NS ? p.attn_nsmax : NS;
-#pragma unroll
-                for (int j0 = 0; j0 < kNXV; j0 += NV)
-                {
-                    float2 mls[NV][NS];
-                    float4 oa[NV][NS], ob[NV][NS];
-#pragma unroll
-                    for (int jj = 0; jj < NV; ++jj)
-                    {
-                        const int j = j0 + jj;
-                        xv[j] = make_uint4(0, 0, 0, 0);
-                        if (j * 2048 < Kp) // uniform
-                        {
-                            const int k = (tid + j * 256) * 8;
-                            const int kc = k < K ? k : K - 8;
-                            const int hh = kc / p.attn_dh, d0 = kc % p.attn_dh;
-                            const int64_t base = ((int64_t) m * p.attn_heads + hh) * p.attn_nsmax;
-#pragma unroll
-                            for (int i = 0; i < NS; ++i)
-                            {
-                                const int ic = i < nsm ? i : 0; // uniform clamp
-                                // (m, l) as ONE 8-byte load: as two floats hipcc fetches l in a second, dependent round trip
-                                const uint64_t mlbits = *reinterpret_cast<const uint64_t*>(ml + base + ic);
-                                mls[jj][i].x = __uint_as_float((uint32_t) mlbits);
-                                mls[jj][i].y = __uint_as_float((uint32_t) (mlbits >> 32));
-                                oa[jj][i] = *reinterpret_cast<const float4*>(p.attn_o + (base + ic) * p.attn_dh + d0);
-                                ob[jj][i] = *reinterpret_cast<const float4*>(p.attn_o + (base + ic) * p.attn_dh + d0 + 4);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0); // all requests are in flight before any value is consumed
-                    const int ns = seq / p.attn_tchunk + 1; // active splits
-#pragma unroll
-                    for (int jj = 0; jj < NV; ++jj)
-                    {
-                        const int j = j0 + jj;
-                        if (j * 2048 < Kp) // uniform
-                        {
-                            const int k = (tid + j * 256) * 8;
-                            float Mx = -INFINITY;
-#pragma unroll
-                            for (int i = 0; i < NS; ++i)
-                                Mx = (i < ns && i < nsm) ? fmaxf(Mx, mls[jj][i].x) : Mx;
-                            float L = 0.f;
-                            float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                            for (int i = 0; i < NS; ++i)
-                            {
-                                const bool act = i < ns && i < nsm && mls[jj][i].x != -INFINITY;
-                                const float e = act ? __expf(mls[jj][i].x - Mx) : 0.f;
-                                L += act ? mls[jj][i].y * e : 0.f;
-                                o8[0] += act ? oa[jj][i].x * e : 0.f;
-                                o8[1] += act ? oa[jj][i].y * e : 0.f;
-                                o8[2] += act ? oa[jj][i].z * e : 0.f;
-                                o8[3] += act ? oa[jj][i].w * e : 0.f;
-                                o8[4] += act ? ob[jj][i].x * e : 0.f;
-                                o8[5] += act ? ob[jj][i].y * e : 0.f;
-                                o8[6] += act ? ob[jj][i].z * e : 0.f;
-                                o8[7] += act ? ob[jj][i].w * e : 0.f;
-                            }
-                            const float inv = (k < K) ? 1.f / (L + 1.e-6f) : 0.f;
-                            xv[j] = make_uint4(pack_h2(o8[0] * inv, o8[1] * inv), pack_h2(o8[2] * inv, o8[3] * inv),
-                                pack_h2(o8[4] * inv, o8[5] * inv), pack_h2(o8[6] * inv, o8[7] * inv));
-                        }
-                    }
-                }
-            };
-            // the slot count is exact (uniform switch): every slot is 40 bytes per thread and vector through L2 whether it is
-            // active or not - with 7 splits (the 1024-token bench context) the 7-slot variant takes 7.7 us, the 8-slot one 8.4
-            switch (p.attn_nsmax)
-            {
-            case 1:
-            case 2:
-            case 3:
-            case 4: merge(std::integral_constant<int, 4>()); break;
-            case 5: merge(std::integral_constant<int, 5>()); break;
-            case 6: merge(std::integral_constant<int, 6>()); break;
-            case 7: merge(std::integral_constant<int, 7>()); break;
-            default: merge(std::integral_constant<int, 8>()); break;
-            }
-        }
-        else if constexpr (X_HALF)
+        if constexpr (X_HALF)
         {
             const uint16_t* xg = reinterpret_cast<const uint16_t*>(p.x) + (int64_t) m * p.ldx;
 #pragma unroll
@@ -363,17 +271,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvArgs a)
             }
         }
     };
-    // zero the activation vectors beyond K (after the loads have been issued; PK_ATTN builds exact vectors itself)
+    // zero the activation vectors beyond K (after the loads have been issued)
     auto mask_x = [&]() {
-        if constexpr (PK != PK_ATTN)
-        {
-            constexpr int XVEC = X_HALF ? 8 : 16;
+        constexpr int XVEC = X_HALF ? 8 : 16;
 #pragma unroll
-            for (int j = 0; j < kNXV; ++j)
-            {
-                const bool ok = (tid + j * 256) * XVEC < K;
-                xv[j] = make_uint4(ok ? xv[j].x : 0u, ok ? xv[j].y : 0u, ok ? xv[j].z : 0u, ok ? xv[j].w : 0u);
-            }
+        for (int j = 0; j < kNXV; ++j)
+        {
+            const bool ok = (tid + j * 256) * XVEC < K;
+            xv[j] = make_uint4(ok ? xv[j].x : 0u, ok ? xv[j].y : 0u, ok ? xv[j].z : 0u, ok ? xv[j].w : 0u);
         }
     };
     load_x_row(0);
@@ -919,7 +824,6 @@ int launch_wt(const GemvArgs& a, int pk, bool swiglu, hipStream_t stream)
         if constexpr (SQ)
             return launch_nxv<WT, PK_QUANT, EK_PLAIN>(a, stream);
         break;
-    case PK_ATTN: return launch_nxv<WT, PK_ATTN, EK_PLAIN>(a, stream);
     default: break;
     }
     set_error("gemv: unsupported prologue for this weight type");

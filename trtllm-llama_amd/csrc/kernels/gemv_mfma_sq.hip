@@ -1,5 +1,5 @@
 // SmoothQuant decode GEMM for SEVERAL sequences (5 <= M <= 8 rows by default, static activation scales) on the matrix pipe.
-// TLLM_GEMV_MFMA_ROWS=<rows> / tllm_gemv_set_mfma_rows move the threshold (0 = never).
+// tllm_gemv_set_mfma_rows moves the threshold (0 = never).
 //
 //   y[m, n] = epi( float(sum_k x8[m, k] * W[n, k]) * (s_col[n] * s_row) )        x8 = the int8 rows, or sat(rni(RMSNorm(x) * s))
 //
@@ -403,16 +403,13 @@ int launch_depth(const GemvParams& p, int pitch, int ngroups, int cus, hipStream
 
 } // namespace
 
-int gemv_mfma_min_rows = -1; // -1: environment / default on first use; rows from which launch_gemv takes this kernel (0 = never)
+int gemv_mfma_min_rows = -1; // -1: the default on first use; rows from which launch_gemv takes this kernel (0 = never)
 
 // 0 launched, -1 error, 1 not served (launch_gemv goes on to the skinny kernel)
 int launch_gemv_mfma_sq(const GemvParams& p, hipStream_t stream)
 {
-    if (gemv_mfma_min_rows < 0)
-    {
-        const char* e = getenv("TLLM_GEMV_MFMA_ROWS");
-        gemv_mfma_min_rows = e ? atoi(e) : 5; // measured: +7 - 9 % tokens/s at 5 - 8 sequences (the skinny kernel runs 5 rows in its 8-row bucket), -9 % at 4 (header)
-    }
+    if (gemv_mfma_min_rows < 0) // (tllm_gemv_set_mfma_rows moves the threshold: tests, sweeps)
+        gemv_mfma_min_rows = 5; // measured: +7 - 9 % tokens/s at 5 - 8 sequences (the skinny kernel runs 5 rows in its 8-row bucket), -9 % at 4 (header)
     if (gemv_mfma_min_rows <= 0 || p.M < gemv_mfma_min_rows || p.M > kRows || p.wtype != W_INT8_SQ)
         return 1;
     const bool swiglu = p.epi == EPI_SWIGLU || p.epi == EPI_SWIGLU_QSTATIC;

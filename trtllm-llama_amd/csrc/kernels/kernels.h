@@ -45,12 +45,7 @@ enum Prologue : int32_t
     PRO_RMSNORM_QSTATIC = 2, // ... -> s8 with static scale act_scale[0]          (W_INT8_SQ)
     PRO_RMSNORM_QDYN = 3,    // ... -> s8 with per-token scale amax/127            (W_INT8_SQ)
     PRO_QSTATIC = 4,         // x fp16 -> s8 static                                (W_INT8_SQ)
-    PRO_QDYN = 5,            // x fp16 -> s8 per-token                             (W_INT8_SQ)
-    // x = the decode-attention context, merged here from the split-KV partials that launch_mmha(skip_combine = 1)
-    // left in its workspace (flash-decoding merge fused into the O-projection: one launch less per layer)
-    PRO_ATTN = 6,         // -> fp16
-    PRO_ATTN_QSTATIC = 7, // -> fp16 -> s8 static                                  (W_INT8_SQ)
-    PRO_ATTN_QDYN = 8     // -> fp16 -> s8 per-token                               (W_INT8_SQ)
+    PRO_QDYN = 5             // x fp16 -> s8 per-token                             (W_INT8_SQ)
 };
 
 enum Epilogue : int32_t
@@ -83,11 +78,6 @@ struct GemvParams
     void* x_pro_out = nullptr;        // optional [M, K]: the prologue's result (fp16 or s8), written by workgroup 0
     const void* residual = nullptr;   // fp16 [M, ldy]
     const float* epi_scale = nullptr; // EPI_SWIGLU_QSTATIC: f32 [1]
-    // PRO_ATTN*: split-KV partials (mmha_split_layout): {max,sum} float2 [M, heads, nsmax], out f32 [M, heads, nsmax, dh]
-    const void* attn_ml = nullptr;
-    const float* attn_o = nullptr;
-    const int32_t* attn_seq_len = nullptr; // [M] device: number of active splits = seq_len / tchunk + 1
-    int32_t attn_heads = 0, attn_dh = 0, attn_tchunk = 0, attn_nsmax = 0;
     void* y = nullptr;
     int64_t ldy = 0; // elements
 };
@@ -159,7 +149,7 @@ struct MmhaParams
     int32_t rope_table_len = 0;
     const float* rope_row = nullptr; // optional f32 [B, rotary_dim/2, 2]: this step's cos/sin row, prepared on the
                                      // device by the sampler (removes the length -> position -> table dependency)
-    int32_t rows_per_group = 0;      // cache rows per lane group and split: 4 (default, finest split), 12 or 16
+    int32_t rows_per_group = 0;      // cache rows per lane group and split: 4 (finest split), 12 or 16; 0 = chosen by the launcher
     // beam search (MM/...Template.h:1137-1146, :1624-1631): `batch` counts batch x beam sequences; sequence bb = b * beam_width
     // + k reads the K/V of timestep t from the cache rows of sequence b * beam_width + cache_indirection[bb, t]
     const int32_t* cache_indirection = nullptr; // int32 [batch, max_seq_len]
@@ -169,12 +159,9 @@ struct MmhaParams
     // t / tokens_per_block (tokens_per_block a power of two)
     const int64_t* block_pointers = nullptr;
     int32_t tokens_per_block = 0, max_blocks_per_seq = 0;
-    int32_t skip_combine = 0;        // 1: leave the split partials in the workspace (the consumer merges them:
-                                     // GemvParams::attn_*), no combine launch
-    // r04 experiment ("merge once, not per consumer workgroup"): when set (uint32 [B * H], zero before the
-    // first launch, self-resetting), the LAST split of a (sequence, head) to arrive merges all partials inside this launch and
-    // writes the normalised context to `out` (and, with tail_quant_scale, its static int8 image to tail_out_q8) - the
-    // O-projection then starts from a plain 8 KB / 4 KB vector instead of merging ns x 16 KB in each of its ~500 workgroups.
+    // The split merge: when set (uint32 [B * H], zero before the first launch, self-resetting), the LAST split of a (sequence,
+    // head) to arrive merges all partials (at most 16) inside this launch and writes the normalised context to `out` (and, with
+    // tail_quant_scale, its static int8 image to tail_out_q8); null: a combine launch follows the partial launch.
     uint32_t* tail_tickets = nullptr;
     const float* tail_quant_scale = nullptr; // f32 [1]: SmoothQuant static activation scale of the O-projection's input
     void* tail_out_q8 = nullptr;             // s8 [B, H*Dh]
@@ -186,6 +173,7 @@ struct MmhaParams
 int mmha_split_layout(int32_t head_size, int32_t max_seq_len, int32_t rows_per_group, int32_t batch, int32_t num_heads,
     int32_t* tchunk, int32_t* nsplit, size_t* out_offset);
 size_t mmha_workspace_size(int32_t batch, int32_t num_heads, int32_t head_size, int32_t max_seq_len);
+size_t mmha_ticket_bytes(int32_t batch, int32_t num_heads); // the merge tickets at the head of a plugin's workspace
 int launch_mmha(const MmhaParams& p, hipStream_t stream);
 // The split-merge tickets at the head of the workspace must be zero before the FIRST launch on it (every launch
 // re-arms them): plugins call this per enqueue, the session once per setup.
@@ -304,9 +292,6 @@ struct GemmParams
     const void* scale_col2 = nullptr;
     const float* scale_row2 = nullptr; // static dequantisation scale of the second GEMM [1] (null: scale_row)
     const float* swiglu_qscale = nullptr;
-    // weight-only types at M >= 32: scratch of gemm_woq_scratch_bytes(N, K) bytes lets the GEMM expand the integers to
-    // fp16 once (exact) and run the LDS-DMA staged fp16 kernel with the per-channel scale in its epilogue
-    void* scratch = nullptr;
     // microbench hook (tllm_gemm_set_clock_probe), set by the launchers only: 2 x uint64 per workgroup {shader cycles, 100 MHz ticks}
     void* clock_probe = nullptr;
 };
@@ -314,7 +299,6 @@ int launch_gemm(const GemmParams& p, hipStream_t stream);
 // fc and gate projections of the SmoothQuant MLP in one kernel with SwiGLU + static int8 quantisation in its epilogue
 // (gemm_sqp.hip); returns 1 when the problem is not served (caller runs the two GEMMs + launch_swiglu_quant instead)
 int launch_gemm_swiglu(const GemmParams& p, hipStream_t stream);
-size_t gemm_woq_scratch_bytes(int32_t N, int32_t K);
 // On-device tactic selection for the prefill GEMMs (gemm_tactics.hip; reference: int8_gemm_template.h:372-457 profileGemm +
 // smoothQuantGemmPlugin.cpp:253-282 mMNKProfileMap).  lookup: kernel id for the shape, 0 = nothing profiled (static rule).
 int gemm_tactic_lookup(int wtype, int M, int N, int K);

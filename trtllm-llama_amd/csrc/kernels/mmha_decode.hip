@@ -12,11 +12,11 @@
 // inside the lane group; the int8 cache is widened with a byte splice to exact integers and the scale is folded
 // into the dot product; an independent softmax partial {max, sum, out[Dh]} per lane group (no cross-group
 // shuffles), merged per workgroup through LDS and published per split as (m, l) + un-normalised fp32 o.
-// The splits of a (batch, head) are merged by mmha_combine_kernel (plugin path), or - the session's decode step since r04 - INSIDE
-// this launch by the last split of the head to arrive (step 6: write-through partials, one ticket per workgroup, agent-scope
-// loads; MmhaParams::tail_tickets), which leaves the O-projection a plain fp16 / int8 vector; r01 - r03 merged in the prologue of
-// every O-projection workgroup instead (gemv_impl.h PK_ATTN, TLLM_NO_ATTN_TAIL_MERGE=1): ~60 MB of L2 reads per launch for
-// 116 KB of distinct data.  (r01's first ticket merge used __threadfence() - an L2 write-back + invalidate per workgroup - and
+// The splits of a (batch, head) are merged INSIDE this launch by the last split of the head to arrive (step 6: write-through
+// partials, one ticket per workgroup, agent-scope loads; MmhaParams::tail_tickets) - plugin and session alike - which leaves the
+// O-projection a plain fp16 / int8 vector; caches that need more than 16 splits run the finest split and mmha_combine_kernel.
+// (r01 - r03 merged in the prologue of every O-projection workgroup: ~60 MB of L2 reads per launch for 116 KB of distinct data;
+// removed in r05, profiles/r04_attn_tail_merge_ab.txt.)  (r01's first ticket merge used __threadfence() - an L2 write-back + invalidate per workgroup - and
 // measured 23 us; a one-workgroup-per-head variant 22 - 35 us.  Two forms without the store drain - data-tagged granules polled by
 // a designated split, and epoch-tagged granules behind an un-drained ticket - were built in r04, bit-identical, and not faster:
 // profiles/r04_attn_granule_ab.txt.)  RoPE coefficients come from a 512-byte row the sampler
@@ -247,7 +247,10 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
             c4[3] = r4[3];
         }
     }
-    if (t0 > tl)
+    // splits that hold at least one used slot (or the slot the new token goes to): ONE expression for the early return here and
+    // for the ticket count of the merge below - a split that returns never takes a ticket, and the last ticket is nact - 1
+    const int nact = min(tl / G::TCHUNK + 1, nsplit_max);
+    if (c >= nact)
         return; // uniform: this split lies entirely beyond the sequence
     float qf[8], kf[8];
     h8_to_f(q_raw, qf);
@@ -476,12 +479,14 @@ __global__ __launch_bounds__(256) void mmha_partial_kernel(const MmhaParams p, f
         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
     }
     // ---- 6. (tail merge) the partial is written through -> one ticket per workgroup -> the last arriver of the (sequence, head)
-    //         merges.  Protocol: write-through payload, drained (vmcnt(0), in asm: the compiler may drop its own wait), relaxed
-    //         agent-scope ticket; the consumer reads the payload with agent-scope (L1-bypassing) loads behind the ticket it took.
+    //         merges.  Protocol = the guide's R1 form (cdna_hip_programming.md G16: "sc1 payload -> asm vmcnt(0) -> relaxed agent flag;
+    //         sc1 loads may replace the acquire when the producer stored sc1"): write-through payload, drained by every storing wave
+    //         (vmcnt(0) in asm: the compiler may drop its own wait), workgroup barrier, relaxed agent-scope ticket; the consumer reads
+    //         the payload with agent-scope (L1-bypassing) loads behind the ticket it took.  The ticket word re-arms itself for the
+    //         next launch; the session also zeroes it whenever a prompt is loaded (a launch that died mid-way must not poison the next).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ uint32_t sm_ticket;
-    const int nact = min(tl / G::TCHUNK + 1, nsplit_max); // splits that run (the others returned above)
     if (tid == 0)
         sm_ticket = __hip_atomic_fetch_add(p.tail_tickets + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -625,7 +630,7 @@ int launch_nit(const MmhaParams& p, hipStream_t stream)
             TLLM_MMHA_LAUNCH(false, CACHE_LINEAR);
     }
 #undef TLLM_MMHA_LAUNCH
-    if (!p.skip_combine && !p.tail_tickets)
+    if (!p.tail_tickets)
         hipLaunchKernelGGL((mmha_combine_kernel<DH, NIT>), dim3(p.num_heads, p.batch), dim3(256), 0, stream, p, ws_ml, ws_o, ns);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -643,23 +648,26 @@ int launch_dh(const MmhaParams& p, hipStream_t stream)
         return launch_nit<DH, 16>(p, stream);
     if (p.rows_per_group == 12)
         return launch_nit<DH, 12>(p, stream);
-    if (p.rows_per_group == 9)
-        return launch_nit<DH, 9>(p, stream);
     return launch_nit<DH, 4>(p, stream);
 }
 
 } // namespace
 
+size_t mmha_ticket_bytes(int32_t batch, int32_t num_heads)
+{
+    return ((size_t) batch * num_heads * sizeof(uint32_t) + 255) / 256 * 256;
+}
+
 size_t mmha_workspace_size(int32_t batch, int32_t num_heads, int32_t head_size, int32_t max_seq_len)
 {
-    // sized for the finest split (NIT = 4)
+    // the merge tickets, then the partials sized for the finest split (NIT = 4)
     const int lpr = head_size / 8;
     if (lpr <= 0 || 64 % lpr)
         return 0;
     const int tchunk = kWaves * (64 / lpr) * 4;
     const int ns = (max_seq_len + tchunk - 1) / tchunk;
     const size_t ml = ((size_t) batch * num_heads * ns * sizeof(float2) + 255) / 256 * 256;
-    return ml + (size_t) batch * num_heads * ns * head_size * sizeof(float);
+    return mmha_ticket_bytes(batch, num_heads) + ml + (size_t) batch * num_heads * ns * head_size * sizeof(float);
 }
 
 int mmha_split_layout(int32_t head_size, int32_t max_seq_len, int32_t rows_per_group, int32_t batch, int32_t num_heads,
@@ -668,7 +676,7 @@ int mmha_split_layout(int32_t head_size, int32_t max_seq_len, int32_t rows_per_g
     const int lpr = head_size / 8;
     if (lpr <= 0 || 64 % lpr)
         return -1;
-    const int nit = rows_per_group == 16 ? 16 : (rows_per_group == 12 ? 12 : (rows_per_group == 9 ? 9 : 4));
+    const int nit = rows_per_group == 16 ? 16 : (rows_per_group == 12 ? 12 : 4);
     const int tc = kWaves * (64 / lpr) * nit;
     const int ns = (max_seq_len + tc - 1) / tc;
     if (tchunk)

@@ -871,8 +871,7 @@ int launch_rmsnorm(const RmsnormParams& p, hipStream_t stream)
         set_error("layernorm: bias is required");
         return -1;
     }
-    const bool no_reg = getenv("TLLM_RMSNORM_LDS") != nullptr; // A/B switch (read per launch): the LDS-row kernel for every shape
-    if (vec && !p.layernorm && !no_reg && p.N >= 8 && p.N <= 2048 * 4)
+    if (vec && !p.layernorm && p.N >= 8 && p.N <= 2048 * 4)
     {
         if (p.N <= 2048)
             hipLaunchKernelGGL(rmsnorm_reg_kernel<1>, dim3(p.M), dim3(256), 0, stream, p);

@@ -363,8 +363,21 @@ public:
             set_error("GPTAttention: workspace is null");
             return 1;
         }
-        if (mmha_reset_workspace(ws, B, c.num_heads, stream))
-            return 1;
+        // the split merge runs inside the attention launch (the last split of a head to arrive: mmha_decode.hip step 6) - the same
+        // code path as the session's decode step; its tickets sit at the head of the workspace and are zeroed per enqueue.  Caches
+        // that need more than 16 splits take the finest split with its combine launch.
+        int tc = 0, ns = 0;
+        const size_t tick = mmha_ticket_bytes(B, c.num_heads);
+        if (mmha_split_layout(c.head_size, Smax, 16, B, c.num_heads, &tc, &ns, nullptr) == 0 && ns <= 16)
+        {
+            p.rows_per_group = 16;
+            if (mmha_split_layout(c.head_size, Smax, 12, B, c.num_heads, &tc, &ns, nullptr) == 0 && ns <= 8)
+                p.rows_per_group = 12;
+            if (mmha_reset_workspace(ws, B, c.num_heads, stream))
+                return 1;
+            p.tail_tickets = static_cast<uint32_t*>(ws);
+        }
+        p.workspace = static_cast<char*>(ws) + tick;
         return launch_mmha(p, stream) ? 1 : 0;
     }
 
@@ -620,10 +633,7 @@ public:
     }
     size_t workspaceSize(const Desc* in, int nin, const Desc* out, int nout) const override
     {
-        // prefill-sized calls expand the integers to fp16 once (kernels/gemm.hip): room for [N, K] halfs
-        const int64_t M = rows_of(in[0].dims);
-        const int K = in[0].dims.d[in[0].dims.nbDims - 1];
-        return M >= 32 ? gemm_woq_scratch_bytes(n_of(in[1].dims, in[1].type), K) : 0;
+        return 0; // the prefill GEMM dequantises in its main loop (kernels/gemm_woq.hip): no fp16 image of the weights
     }
     int enqueue(const Desc* inDesc, const Desc* outDesc, const void* const* in, void* const* out, void* ws,
         hipStream_t stream) override
@@ -656,7 +666,6 @@ public:
         g.scale_col = in[2];
         g.c = out[0];
         g.ldc = N;
-        g.scratch = M >= 32 ? ws : nullptr;
         return launch_gemm(g, stream) ? 1 : 0;
     }
     void serialize(Writer& w) const override

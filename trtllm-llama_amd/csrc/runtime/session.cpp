@@ -192,7 +192,6 @@ struct tllm_session
     float* logits = nullptr; // [B, V] (or gathered [tp, B, Vr])
     float* logits_local = nullptr;
     void* last_hidden = nullptr;
-    void* woq_scratch = nullptr;
     // tensor-parallel decode with the fused peer-to-peer seam (kernels/p2p_allreduce.hip): this rank's partial projection
     // output, the normalised (+ quantised) row the next GEMV consumes, its per-token scales
     void* ar_partial = nullptr; // [B, D] fp16
@@ -208,9 +207,8 @@ struct tllm_session
     int32_t* rope_pos = nullptr; // [B]: the position that row belongs to (tllm_session_get_step_state)
     int attn_nit = 4, attn_tchunk = 0, attn_ns = 0;
     size_t attn_o_off = 0;
-    bool attn_fused = false; // split-KV merge fused into the O-projection prologue
-    // r04: the last split of a head to arrive merges inside the attention launch (mmha_decode.hip step 6); TLLM_NO_ATTN_TAIL_MERGE=1
-    // brings the r01 - r03 path back (every O-projection workgroup merges all partials in its prologue)
+    // the last split of a head to arrive merges inside the attention launch (mmha_decode.hip step 6); beyond 16 partials the finest
+    // split runs with its own combine launch
     bool attn_tail = false;
     uint32_t* attn_tickets = nullptr;
     // r05: batch-1 greedy decode of a SmoothQuant engine runs the QKV projection, RoPE, the cache append and the attention of a head
@@ -446,16 +444,6 @@ struct tllm_session
         p.epi_scale = epi_scale;
         p.y = y;
         p.ldy = ldy;
-        if (pro >= PRO_ATTN)
-        {
-            p.attn_ml = mmha_ws;
-            p.attn_o = reinterpret_cast<const float*>(static_cast<const char*>(mmha_ws) + attn_o_off);
-            p.attn_seq_len = seq_len;
-            p.attn_heads = Hr;
-            p.attn_dh = Dh;
-            p.attn_tchunk = attn_tchunk;
-            p.attn_nsmax = attn_ns;
-        }
         if (tap_dst)
             p.x_pro_out = tap_dst;
         if (up)
@@ -478,14 +466,7 @@ struct tllm_session
             {
                 GemvParams q = p;
                 q.M = M - m0 < 8 ? M - m0 : 8;
-                if (pro < PRO_ATTN)
-                    q.x = static_cast<const char*>(xin) + (int64_t) m0 * ldx * xes;
-                else
-                {
-                    q.attn_ml = static_cast<const char*>(p.attn_ml) + (int64_t) m0 * Hr * attn_ns * 8 /* (m, l) float pairs */;
-                    q.attn_o = p.attn_o + (int64_t) m0 * Hr * attn_ns * Dh;
-                    q.attn_seq_len = seq_len + m0;
-                }
+                q.x = static_cast<const char*>(xin) + (int64_t) m0 * ldx * xes;
                 q.y = static_cast<char*>(y) + (int64_t) m0 * ldy * yes;
                 if (residual)
                     q.residual = static_cast<const char*>(residual) + (int64_t) m0 * ldy * 2;
@@ -507,7 +488,6 @@ struct tllm_session
         GemmParams g;
         g.residual = residual;
         g.silu_gate = silu_gate;
-        g.scratch = woq_scratch; // weight-only prefill: room for the fp16 expansion of the largest weight matrix
         g.wtype = L.wtype;
         g.out_dtype = out_dtype;
         g.M = M;
@@ -539,10 +519,8 @@ struct tllm_session
         if (off || layers.empty() || packed) // packed inputs: M varies with the prompt batch, the nearest bucket entry serves
             return 0;
         const Layer& L = layers[0];
-        // weight-only prefill runs gemm_woq.hip (one kernel per shape class, no tactic table); only the r02 expand path
-        // (TLLM_WOQ_EXPAND=1) runs the fp16 kernels on the expanded weights
-        const bool woq_l = L.qkv.wtype == W_INT8_WOQ || L.qkv.wtype == W_INT4_WOQ;
-        if (woq_l && !getenv("TLLM_WOQ_EXPAND"))
+        // weight-only prefill runs gemm_woq.hip (one kernel per shape class, no tactic table)
+        if (L.qkv.wtype == W_INT8_WOQ || L.qkv.wtype == W_INT4_WOQ)
             return 0;
         for (const Linear* l : {&L.qkv, &L.dense, &L.fc, &L.proj})
         {
@@ -650,7 +628,7 @@ struct tllm_session
             c.cu_seqlens = packed ? cu_dev : nullptr;
             // SmoothQuant static: the O-projection's input quantiser rides in the attention's epilogue (padded inputs; with
             // packed inputs M counts real tokens only and the pass below covers exactly those)
-            const bool q_in_attn = sq && !per_token && !packed && !getenv("TLLM_NO_ATTN_QUANT_FUSE");
+            const bool q_in_attn = sq && !per_token && !packed;
             if (q_in_attn)
             {
                 c.out_q8 = q8;
@@ -668,9 +646,8 @@ struct tllm_session
             }
             // (weight-only: gemm_woq.hip adds the residual in its epilogue too - same two roundings; its own serve conditions)
             const bool woq_w = L.dense.wtype == W_INT8_WOQ || L.dense.wtype == W_INT4_WOQ;
-            static const bool woq_expand = getenv("TLLM_WOQ_EXPAND") != nullptr;
             const bool fuse_res = tp == 1 && !force_comm && M >= 32 && D % 8 == 0
-                && (woq_w ? (!woq_expand && !getenv("TLLM_NO_WOQ_RESIDUAL_FUSE") && L.dense.K % 64 == 0 && L.proj.K % 64 == 0)
+                && (woq_w ? (L.dense.K % 64 == 0 && L.proj.K % 64 == 0)
                           : ((L.dense.wtype == W_INT8_SQ || L.dense.wtype == W_FP16)
                               && (L.dense.K * (L.dense.wtype == W_FP16 ? 2 : 1)) % 128 == 0
                               && (L.proj.K * (L.proj.wtype == W_FP16 ? 2 : 1)) % 128 == 0));
@@ -707,7 +684,7 @@ struct tllm_session
             RUN(launch_rmsnorm(r, st));
             const void* p_in = inter_buf;
             bool mlp_fused = false;
-            if (sq && !per_token && M >= 32 && !getenv("TLLM_NO_DUAL_GEMM"))
+            if (sq && !per_token && M >= 32)
             {
                 // fc and gate in one kernel with SwiGLU + the static quantiser in its epilogue (gemm_sqp.hip, DUAL): the two fp16
                 // [M, Ir] intermediates and the pointwise pass between the GEMMs disappear.  The int8 result goes to inter_buf
@@ -745,8 +722,7 @@ struct tllm_session
             else
             {
             RUN(gemm(L.fc, M, a_in, sq && per_token ? qscale : nullptr, sq && per_token, g, DT_HALF, st));
-            const bool no_gate_fuse = getenv("TLLM_NO_SWIGLU_FUSE") != nullptr;
-            if (!sq && !no_gate_fuse)
+            if (!sq)
             {
                 // fp16 / weight-only: SwiGLU folded into the second projection's epilogue (g is read there instead of in a pass of
                 // its own; same rounding points) - one launch and a [M, Ir] write + read fewer per layer
@@ -1007,7 +983,6 @@ struct tllm_session
             m.tokens_per_block = tokens_per_block;
             m.max_blocks_per_seq = max_blocks;
             m.rows_per_group = attn_nit;
-            m.skip_combine = attn_fused ? 1 : 0;
             const bool tail_q8 = attn_tail && sq && !per_token;
             if (attn_tail)
             {
@@ -1023,7 +998,7 @@ struct tllm_session
             if (!qkv_attn_fused && (ok < 0 || ok == 2))
                 RUN(timed(PC_ATTENTION, st, [&] { return launch_mmha(m, st); }));
             // K4: x <- x + O(ctx)     (TP: rank 0 carries the residual into the all-reduce)
-            const int pro_o = !attn_fused ? pro_q : (!sq ? PRO_ATTN : (per_token ? PRO_ATTN_QDYN : PRO_ATTN_QSTATIC));
+            const int pro_o = pro_q;
             if (ok < 0 || ok == 4)
             {
                 if (taps)
@@ -1531,16 +1506,6 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
     RUN(s->dalloc(&s->logits, (size_t) B * s->Vr * s->tp * 4));
     RUN(s->dalloc(&s->last_hidden, (size_t) B * D * 2));
     RUN(s->dalloc(&s->ctx_ws, context_attention_workspace_size(Bc, s->Hr, s->Dh, S) + 256));
-    // the fp16 image of the largest weight matrix is needed by the r02 expand path only (TLLM_WOQ_EXPAND=1, the A/B switch);
-    // the production weight-only prefill dequantises in the GEMM's main loop (gemm_woq.hip) and needs no scratch
-    if (s->woq && Bc * S >= 32 && getenv("TLLM_WOQ_EXPAND"))
-    {
-        size_t mx = 0;
-        for (auto& L : s->layers)
-            for (const Linear* l : {&L.qkv, &L.dense, &L.fc, &L.gate, &L.proj})
-                mx = std::max(mx, gemm_woq_scratch_bytes(l->N, l->K));
-        RUN(s->dalloc(&s->woq_scratch, mx));
-    }
     if ((size_t) Bc * S >= 32)
         RUN(s->profile_prefill_gemms(Bc * S));
     RUN(s->dalloc(&s->ar_partial, (size_t) B * D * 2));
@@ -1584,42 +1549,26 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
     HIP_OK(hipMemset(s->rope_row, 0, (size_t) B * s->Dh * sizeof(float)));
     RUN(s->dalloc(&s->rope_pos, (size_t) B * 4));
     HIP_OK(hipMemset(s->rope_pos, 0, (size_t) B * 4));
-    // coarse KV splits (16 rows per lane group) + merge fused into the O-projection when that needs <= 8 partials
-    // per head; otherwise the fine split with its own combine launch
+    // The split-KV merge runs inside the attention launch, by the last split of a head to arrive (mmha_decode.hip step 6; up to
+    // 16 partials: 16-row splits cover 4096 cache slots at head size 128); 12 rows per lane group while that needs <= 8 partials
+    // (7 x 32 instead of 5 x 32 workgroups at the 1024-token bench context).  Beyond 16 partials: the finest split with its own
+    // combine launch.
     {
         int tc = 0, ns = 0;
         size_t off = 0;
-        s->attn_fused = false;
         s->attn_tail = false;
         s->attn_nit = 4;
-        // The split-KV merge: inside the attention launch by the last split of a head to arrive (r04, up to 16 partials: 16-row
-        // splits cover 4096 cache slots), in the prologue of every O-projection workgroup (r01 - r03, TLLM_NO_ATTN_TAIL_MERGE=1; up to
-        // 8 partials - there every slot costs each of ~500 workgroups a load), or by a combine launch (TLLM_NO_FUSED_ATTN_MERGE=1,
-        // or more partials than either takes).
-        const bool want_tail = !getenv("TLLM_NO_ATTN_TAIL_MERGE");
-        const int max_parts = want_tail ? 16 : 8;
-        if (!getenv("TLLM_NO_FUSED_ATTN_MERGE") && mmha_split_layout(s->Dh, Smax, 16, B, s->Hr, &tc, &ns, &off) == 0 && ns <= max_parts
-            && (want_tail || s->Dr <= 256 * 8 * 6))
+        s->attn_tickets = nullptr;
+        s->ctx_q8 = nullptr;
+        if (mmha_split_layout(s->Dh, Smax, 16, B, s->Hr, &tc, &ns, &off) == 0 && ns <= 16)
         {
             s->attn_nit = 16;
-            // 12 rows per lane group while that still needs <= 8 partials: more workgroups (7 x 32 instead of 5 x 32 at the
-            // 1024-token bench context; beyond 8 the launch would exceed one workgroup per CU)
             if (mmha_split_layout(s->Dh, Smax, 12, B, s->Hr, &tc, &ns, &off) == 0 && ns <= 8)
                 s->attn_nit = 12;
-            // experiment switch (r04): TLLM_ATTN_ROWS=9 -> 144-token splits = 8 x 32 = 256 workgroups at the
-            // 1024-token bench context, all CUs busy (measured: no gain, profiles/r04_attn_rows*_ab.txt)
-            const char* rows_env = getenv("TLLM_ATTN_ROWS");
-            if (rows_env && atoi(rows_env) == 9 && mmha_split_layout(s->Dh, Smax, 9, B, s->Hr, &tc, &ns, &off) == 0 && ns <= 8)
-                s->attn_nit = 9;
-            if (want_tail)
-            {
-                s->attn_tail = true;
-                RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_tickets), (size_t) B * s->Hr * 4));
-                HIP_OK(hipMemset(s->attn_tickets, 0, (size_t) B * s->Hr * 4));
-                RUN(s->dalloc(&s->ctx_q8, (size_t) B * s->Dr));
-            }
-            else
-                s->attn_fused = true;
+            s->attn_tail = true;
+            RUN(s->dalloc(reinterpret_cast<void**>(&s->attn_tickets), (size_t) B * s->Hr * 4));
+            HIP_OK(hipMemset(s->attn_tickets, 0, (size_t) B * s->Hr * 4));
+            RUN(s->dalloc(&s->ctx_q8, (size_t) B * s->Dr));
         }
         if (mmha_split_layout(s->Dh, Smax, s->attn_nit, B, s->Hr, &tc, &ns, &off))
         {
@@ -1790,6 +1739,8 @@ static int upload_prompt(tllm_session_t s, const int32_t* input_ids, const int32
         HIP_OK(hipMemsetAsync(s->cache_ind, 0, (size_t) B * Smax * 4, st)); // every slot -> hypothesis 0's rows
     }
     HIP_OK(hipMemcpyAsync(s->seq_len, seq.data(), B * 4, hipMemcpyHostToDevice, st));
+    if (s->attn_tickets) // re-arm the in-launch merge (it re-arms itself per launch; this covers a step that never finished)
+        HIP_OK(hipMemsetAsync(s->attn_tickets, 0, (size_t) B * s->Hr * 4, st));
     HIP_OK(hipMemcpyAsync(s->finished, zeros.data(), B * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(s->masked, mask.data(), mask.size() * 4, hipMemcpyHostToDevice, st));
     HIP_OK(hipMemcpyAsync(s->out_ids, out.data(), out.size() * 4, hipMemcpyHostToDevice, st));

@@ -160,7 +160,7 @@ class Builder():
         if m_max < 32:
             return ''
         qm = int(cfg.get('quant_mode', 0))
-        if (qm & 3) and not (qm & 4) and not os.environ.get('TLLM_WOQ_EXPAND'):  # weight-only (no activation quantisation)
+        if (qm & 3) and not (qm & 4):  # weight-only (no activation quantisation)
             # weight-only prefill dequantises in the GEMM's main loop (csrc/kernels/gemm_woq.hip): one kernel per shape class,
             # the fp16 tactic table is never consulted - nothing to profile
             return ''
