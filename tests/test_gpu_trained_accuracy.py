@@ -40,24 +40,13 @@ CONFIGS = {
 }
 NEW = 100
 
-# Teacher-forced logit tolerance per configuration, (max, mean) of |logit(engine) - logit(HF fp32)|.
-#   fp16: the reference's own bound, atol 1e-1 (T/tests/model/test_llama.py:286-288, 352-354 - an fp16 model test).
-#   quantised: the reference states NO logit bound for a quantised model (its acceptance test is summarize.py's ROUGE, README.md:921);
-#   atol 1e-1 ABSOLUTE is 0.4 % of this parent's logit scale (27.2) and is missed by every int8 path, the reference's own
-#   algorithms first (int8 KV cache alone: 0.26; weight-only int8: 0.27) - measured r04, profiles/r04_trained_parent.txt.  The
-#   bounds below are the stated tolerances of this build, as fractions of the logit scale, ~1.4 x what was measured; WHERE the
-#   SmoothQuant error comes from is in tools/sq_trained_sweep.py (CPU): the static per-tensor quantiser in front of mlp.proj - the
-#   SwiGLU product has a 55 x max / rms tail (absmax 690 at rms 12 in the last layer) that no per-channel smoothing removes - carries
-#   2.15 / 0.205 of the 2.87 / 0.206 alone; the other three quantisers together 0.4 / 0.02.
-LOGIT_TOL = {
-    'fp16': (1e-1, None),
-    'int8_kv': (0.02, 0.001),
-    'woq8_int8kv': (0.02, 0.001),
-    'woq4_int8kv': (0.08, 0.005),
-    'sq_static_int8kv': (0.15, 0.012),
-    'sq_per_token_int8kv': (0.12, 0.004),
-    'sq_static_int8kv_down1': (0.15, 0.006),
-}
+# Teacher-forced logits: the fp16 engine is held to the reference's own bound, atol 1e-1 (T/tests/model/test_llama.py:286-288,
+# 352-354 - an fp16 model test).  The reference states NO logit bound for a quantised model (its acceptance test is summarize.py's
+# ROUGE, README.md:921); the quantised configurations are bounded by a PRINCIPLE, not by numbers fitted to a measurement (r04's
+# LOGIT_TOL): at most K = 1.25 x the error of the numpy restatement of the same algorithm on the same integers -
+# tests/trained_parents.py, tests/test_gpu_stochastic_accuracy.py::test_teacher_forced_logits_within_k_times_the_algorithms_own_error
+# (both parents, every configuration).  Here, on the engines the command-line flow builds: every arg-max is HF's, the KL bound,
+# and - SmoothQuant static - the engine's distance to HF equals that of the torch restatement of its algorithm.
 
 
 def load_eval():
@@ -133,9 +122,9 @@ def test_rouge_l_delta_vs_hf_within_one(ft_dirs, name):
 @pytest.mark.gpu
 @pytest.mark.parametrize('name', list(CONFIGS))
 def test_teacher_forced_logits_within_the_reference_tolerance(ft_dirs, name):
-    """Every generated step on HF's own token path: |logit(engine) - logit(HF fp32)| within LOGIT_TOL (fp16: the reference's atol
-    1e-1, test_llama.py:288,354; quantised: the stated bounds above), every arg-max is HF's, and - SmoothQuant static - the engine's
-    distance to HF equals that of the torch restatement of its algorithm on the same integers."""
+    """Every generated step on HF's own token path: fp16 within the reference's atol 1e-1 (test_llama.py:288,354), every arg-max is
+    HF's, the KL bound, and - SmoothQuant static - the engine's distance to HF equals that of the torch restatement of its algorithm
+    on the same integers (the bound of the quantised configurations: tests/trained_parents.py)."""
     from tensorrt_llm import Mapping
     from tensorrt_llm.runtime import GenerationSession, ModelConfig
     base, ft = ft_dirs
@@ -189,11 +178,8 @@ def test_teacher_forced_logits_within_the_reference_tolerance(ft_dirs, name):
           f'error {conf_agree}/{confident}')
     assert kl_sum / cnt < (1e-5 if name == 'fp16' else 5e-3)
     assert conf_agree == confident and agree == n * NEW  # every arg-max is HF's
-    tol_max, tol_mean = LOGIT_TOL[name]
-    if tol_mean is None:
-        assert worst <= tol_max, f'{name}: max |dlogit| {worst:.4f} exceeds the reference tolerance 1e-1 (logit scale {scale:.1f})'
-    else:
-        assert worst <= tol_max * scale and sum_err / cnt <= tol_mean * scale, (name, worst, sum_err / cnt, scale)
+    if name == 'fp16':
+        assert worst <= 1e-1, f'{name}: max |dlogit| {worst:.4f} exceeds the reference tolerance 1e-1 (logit scale {scale:.1f})'
     if name == 'sq_static_int8kv':
         # the engine's distance to HF is the ALGORITHM's: the torch restatement of SmoothQuant-static + int8 KV
         # (bench_parity.FakeQuantSQ, pinned to the oracle by tests/test_fakequant_checker.py) on the same int8 weights and scales

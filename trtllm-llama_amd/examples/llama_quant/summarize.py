@@ -171,7 +171,12 @@ def main(args):
         with open(os.path.join(args.engine_dir, 'config.json')) as f:
             vocab = json.load(f)['builder_config']['vocab_size']
     model = None
-    if test_hf:
+    hf_precomputed = None
+    if test_hf and args.hf_tokens_npy:
+        # HF's greedy continuations of the same prompts, made once with the fixture (tests/golden/train_stochastic_llama.py: HF fp32
+        # on the CPU, the reference's run_hf.py path) - several engines are then scored against ONE HF run instead of repeating it
+        hf_precomputed = np.load(args.hf_tokens_npy)
+    if test_hf and hf_precomputed is None:
         from transformers import AutoModelForCausalLM
         profiler.start('load HF model')
         model = AutoModelForCausalLM.from_pretrained(args.hf_model_location)
@@ -248,7 +253,7 @@ def main(args):
             profiler.stop('tensorrt_llm')
         if test_hf:
             profiler.start('hf')
-            s_hf = summarize_hf(batch)
+            s_hf = [hf_precomputed[it + i, :output_len] for i in range(len(batch))] if hf_precomputed is not None else summarize_hf(batch)
             profiler.stop('hf')
         if runtime_rank != 0:
             continue
@@ -290,6 +295,21 @@ def main(args):
         if 'tensorrt_llm' in result and 'hf' in result:
             result['rougeL_delta_vs_hf'] = result['tensorrt_llm']['rougeL'] - result['hf']['rougeL']
             logger.info(f'  rougeL delta vs HF : {result["rougeL_delta_vs_hf"]:.3f}')
+            # paired bootstrap over the prompts (seeded): how far the delta of THIS sample of prompts can be from the delta of the
+            # prompt population.  The reference quotes a single number on 20 articles (README.md:921 "within about 1"); with
+            # near-tied continuations one flipped token changes a whole summary, so the interval is what makes the number readable
+            a = np.array([r[2] for r in metric_trt.rows]) * 100
+            b = np.array([r[2] for r in metric_hf.rows]) * 100
+            d = a - b
+            rs = np.random.default_rng(args.bootstrap_seed)
+            boots = d[rs.integers(0, len(d), (args.bootstrap, len(d)))].mean(1) if len(d) > 1 and args.bootstrap > 0 else np.array([d.mean()])
+            result['rougeL_delta_ci95'] = [float(np.quantile(boots, 0.025)), float(np.quantile(boots, 0.975))]
+            result['rougeL_delta_stderr'] = float(d.std(ddof=1) / np.sqrt(len(d))) if len(d) > 1 else 0.0
+            result['samples'] = int(len(d))
+            result['samples_identical_to_hf'] = int(np.sum([r[2] >= 1.0 - 1e-12 for r in metric_vs_hf.rows])) if metric_vs_hf.rows else 0
+            if args.per_sample:
+                result['per_sample_rougeL'] = dict(tensorrt_llm=a.tolist(), hf=b.tolist())
+            logger.info(f'  rougeL delta 95 % interval (paired bootstrap over {len(d)} prompts): {result["rougeL_delta_ci95"]}')
         if args.output_json:  # before the checks: a run that fails them still leaves its numbers
             with open(args.output_json, 'w') as f:
                 json.dump(result, f, indent=1)
@@ -299,7 +319,8 @@ def main(args):
             assert result[key]['rouge1'] > args.tensorrt_llm_rouge1_threshold, result
             # the team's acceptance criterion, "ROUGE difference within about 1" (README.md:921), when HF ran beside the engine
             if args.rougeL_delta_threshold is not None and 'rougeL_delta_vs_hf' in result:
-                assert abs(result['rougeL_delta_vs_hf']) <= args.rougeL_delta_threshold, result
+                assert abs(result['rougeL_delta_vs_hf']) <= args.rougeL_delta_threshold, \
+                    {k: v for k, v in result.items() if k != 'per_sample_rougeL'}
     return result
 
 
@@ -325,6 +346,12 @@ def parse_arguments(argv=None):
                         help='reference continuations [n, L] (token ids) for --prompts_npy: ROUGE of the engine and of HF against them')
     parser.add_argument('--rougeL_delta_threshold', type=float, default=None,
                         help='with --check_accuracy: |rougeL(engine) - rougeL(HF)| against the references must not exceed this')
+    parser.add_argument('--hf_tokens_npy', type=str, default=None,
+                        help='with --test_hf: HF greedy continuations [n, >= output_len] made beforehand (same prompts, same order) '
+                             'instead of running HF here')
+    parser.add_argument('--bootstrap', type=int, default=2000, help='paired-bootstrap resamples for the ROUGE-L delta interval')
+    parser.add_argument('--bootstrap_seed', type=int, default=0)
+    parser.add_argument('--per_sample', action='store_true', help='keep the per-prompt ROUGE-L of both sides in --output_json')
     parser.add_argument('--synthetic', action='store_true', help='seeded random token prompts')
     parser.add_argument('--synthetic_len', type=int, default=64)
     parser.add_argument('--output_len', type=int, default=100)
