@@ -554,7 +554,7 @@ def main():
     # PMC counters cannot be read from inside the timed run: `traffic` is the committed rocprofv3 measurement of this same
     # kernel / shape (tools/refresh_pmc.sh -> profiles/*_pmc_summary.json), named in `traffic_source` - not this run's
     traffic = traffic_source = None
-    for rnd in ('r04', 'r03', 'r02', 'r01'):
+    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
         pmc = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_summary.json')
         if os.path.exists(pmc):
             try:
@@ -632,6 +632,10 @@ def main():
         'step': {'hbm_bytes': res['step_bytes'], 'hbm_frac_of_peak': res['step_bytes'] / (res['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  'device_ms_per_step': res['dev_ms'] / args.steps, 'outputs_finite': res['finite'],
                  'layer_kernel_us': res['kernel_us'],
+                 # batch-1 SmoothQuant decode runs the QKV projection, RoPE, the cache append and the attention in ONE launch
+                 # (kernels/qkv_attn_fused.hip): its time is the 'qkv' entry, 'attention' is then an empty slot
+                 'qkv_and_attention_in_one_launch': bool(res['kernel_us'].get('attention', 1.0) < 1.0
+                                                         and not getattr(args, 'two_launch_attention', False)),
                  'profile_ms_per_step': {k: v[0] / prof_steps for k, v in prof.items()},
                  'launches_per_step': {k: v[1] / prof_steps for k, v in prof.items()}},
     }
