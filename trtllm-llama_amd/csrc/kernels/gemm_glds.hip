@@ -504,11 +504,15 @@ int launch_cfg(const GemmParams& p, hipStream_t stream)
 struct Shape
 {
     int id, bm, bn;
-    double f; // measured time per (workgroup round x tile area), relative to the phased 256 x 192 tile (profiles/r04_tile256x128.txt)
+    // measured time per (workgroup round x tile area), relative to the phased 256 x 192 tile of the same operand type.  fp16:
+    // profiles/r04_tile256x128.txt.  SmoothQuant (r05): relative to the PERSISTENT 256 x 192 tile (profiles/r05_sqgemm_persistent.txt:
+    // O at M = 8192 117 us against 135 for 256 x 256 in two rounds, O at M = 4096 63 us for 256 x 128 against 69)
+    double f, f_sq;
 };
 // id 42 is the phased 256 x 128 tile of gemm_sqp.hip (its fp16 sibling is id 54): it has no lock-step form in this file
 constexpr int kPhased256x128 = 42;
-constexpr Shape kShapes[] = {{8, 128, 128, 1.40}, {6, 256, 192, 1.0}, {2, 256, 256, 1.04}, {4, 128, 256, 1.39}, {kPhased256x128, 256, 128, 1.08}};
+constexpr Shape kShapes[] = {{8, 128, 128, 1.40, 1.80}, {6, 256, 192, 1.0, 1.0}, {2, 256, 256, 1.04, 1.30}, {4, 128, 256, 1.39, 1.60},
+    {kPhased256x128, 256, 128, 1.08, 1.37}};
 constexpr int kNumCfg = 12;
 
 template <int WT>
@@ -586,7 +590,7 @@ static int static_shape_cfg(const GemmParams& p, bool phased_ok = true)
         // beyond two rounds the 256 x 128 tile loses to 256 x 256 / 256 x 192 (M = 8192: 162 vs 136 us on O, 467 vs 377 on gate / up)
         if (s.id == kPhased256x128 && tiles > 2 * cus)
             continue;
-        const double cost = (double) ((tiles + cus - 1) / cus) * s.bm * s.bn * s.f;
+        const double cost = (double) ((tiles + cus - 1) / cus) * s.bm * s.bn * (p.wtype == W_INT8_SQ ? s.f_sq : s.f);
         if (cost < best)
         {
             best = cost;
@@ -602,9 +606,13 @@ int gemm_static_cfg(const GemmParams& p)
     if (!glds_serves(p))
         return 0;
     const int cfg = static_shape_cfg(p);
+    // (SmoothQuant: the persistent forms 62 / 63 of gemm_sqp.hip serve fp16 output on 16-byte rows; launch_gemm_glds falls back
+    // to the one-tile-per-workgroup forms 42 / 20 for the rest)
+    const bool persist = p.wtype == W_INT8_SQ && p.out_dtype == DT_HALF && !(p.ldc & 7) && !(p.N & 7)
+        && !(reinterpret_cast<uintptr_t>(p.c) & 15) && p.K >= 256;
     if (cfg == kPhased256x128)
-        return p.wtype == W_INT8_SQ ? 42 : 54;
-    return cfg == 6 ? (p.wtype == W_INT8_SQ ? 20 : 50) : cfg; // the 256 x 192 tile runs its phased sibling (gemm_sqp.hip)
+        return p.wtype == W_INT8_SQ ? (persist ? 62 : 42) : 54;
+    return cfg == 6 ? (p.wtype == W_INT8_SQ ? (persist ? 63 : 20) : 50) : cfg; // the 256 x 192 tile runs its phased sibling (gemm_sqp.hip)
 }
 
 // exactly kernel `cfg`, no fall-back: 0 launched, -1 launch error, 1 this kernel does not serve the problem (the tactic profiler)
@@ -649,7 +657,9 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
         if (cfg == kPhased256x128)
         {
             // one round of 256 x 128 tiles where 128 x 128 would take two (O / down at M = 2048: 34 vs 44 us, 84 vs 107 us)
-            const int r = sq ? launch_gemm_sqp(p, 42, stream) : launch_gemm_f16p(p, 54, stream);
+            int r = sq ? launch_gemm_sqp(p, 62, stream) : 1; // the persistent form first (r05)
+            if (r > 0)
+                r = sq ? launch_gemm_sqp(p, 42, stream) : launch_gemm_f16p(p, 54, stream);
             if (r <= 0)
                 return r;
             cfg = static_shape_cfg(p, false);
@@ -666,7 +676,11 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
     {
         // the 256 x 192 SmoothQuant tile has a phased sibling (gemm_sqp.hip) that measures 2-5 % faster at the 7B prefill
         // shapes; exact either way
-        const int r = launch_gemm_sqp(p, 20, stream);
+        // ... and that one a persistent form (r05: one workgroup per CU walks its tiles, the next tile's first K-tiles are
+        // requested under the epilogue, tiles ordered in bands of 4 row tiles): 3 - 10 % on top (profiles/r05_sqgemm_persistent.txt)
+        int r = launch_gemm_sqp(p, 63, stream);
+        if (r > 0)
+            r = launch_gemm_sqp(p, 20, stream);
         if (r <= 0)
             return r;
     }

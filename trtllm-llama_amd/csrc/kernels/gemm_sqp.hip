@@ -69,11 +69,15 @@ __device__ __forceinline__ int swz_g(int row)
 // holds 16 bytes of a 64-byte k-step of one row; 16 x 16 fp32 / int32 results in the same lanes), a 128-byte K line is 64 halfs,
 // so the quarter units, the swizzle, the DMA schedule and the counted waits carry over unchanged; fp32 accumulation, optional fp16
 // per-channel scale (the weight-only expand path), A7 P/gemmPlugin/gemmPlugin.cpp:121-190.
+// PERSIST (r05): one workgroup per CU walks tiles wg, wg + grid, ...; the fp16 tile leaves through a STAGING area of its own
+// (quarter-tile rounds) instead of the operand buffers, so the next tile's scales and its first two K-tiles are requested BEFORE
+// the epilogue and land under it; the epilogue's stores stay in the vmcnt queue across the next tile's first waits (counted).
 template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRIO, int ABL, int RSP, bool DUAL = false, bool SCL = true,
-    bool F16 = false>
+    bool F16 = false, bool PERSIST = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams p)
 {
     static_assert(SCL || !DUAL, "the fused SwiGLU epilogue reads its scales from LDS");
+    static_assert(!PERSIST || (SCL && !DUAL && !F16), "the persistent form is the SmoothQuant fp16-output GEMM");
     static_assert(!F16 || (!DUAL && !SCL), "the fp16 variant has no dual / staged-scale form");
     using acc_t = typename std::conditional<F16, f32x4, i32x4>::type;
     constexpr int ES = F16 ? 2 : 1; // bytes per operand element
@@ -105,11 +109,12 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int tm = wg % tiles_m, tn = wg / tiles_m;
-    // DUAL: W-half 0 = rows [n0, n0 + BH) of the first matrix, W-half 1 = the SAME rows of the second one; BH output columns
-    const int m0 = tm * BM, n0 = tn * (DUAL ? BH : BN);
     const int M = p.M, N = p.N;
+    const int tiles_n = (N + (DUAL ? BH : BN) - 1) / (DUAL ? BH : BN);
+    const int total_tiles = tiles_m * tiles_n;
     const int ntile = p.K * ES / 128;
+    // DUAL: W-half 0 = rows [n0, n0 + BH) of the first matrix, W-half 1 = the SAME rows of the second one; BH output columns
+    int m0, n0;
 
     // ---- DMA sources.  Unit kinds: 0 = X0, 1 = W0, 2 = W1, 3 = X1 (issue order inside a K-tile).  Chunk c of a unit
     // covers rows [8c, 8c+8); lane l -> row 8c + (l >> 3), LDS piece l & 7 <- global piece (l & 7) ^ g(row).
@@ -119,29 +124,43 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     const char* wb2 = DUAL ? reinterpret_cast<const char*>(p.w2) : wb;
     uint32_t xo[2][APW], wo[2][BPW];
     const int wrev = NW - 1 - wid;
+    auto set_tile = [&](int tw) {
+        // tile order: bands of GM row tiles, row-fastest inside a band.  The 32 workgroups an XCD runs side by side (ids are
+        // contiguous per XCD, above) then cover GM row tiles x 32 / GM column tiles, and what the XCD's L2 has to fetch per round is
+        // GM X-tiles + 32 / GM W-tiles instead of 32 X-tiles + 1 W-tile (M = 8192: 10 MB instead of 33 MB per XCD and round)
+        constexpr int GM = 4;
+        const int bi = tw / (GM * tiles_n), rem = tw - bi * (GM * tiles_n);
+        const int bh = tiles_m - bi * GM < GM ? tiles_m - bi * GM : GM;
+        const int tm = bi * GM + rem % bh, tn = rem / bh;
+        m0 = tm * BM, n0 = tn * (DUAL ? BH : BN);
+        int lane = tid & 63;
+        if constexpr (PERSIST) // per-lane terms recomputed per tile: kept live across the K loop they cost main-loop registers
+            asm volatile("" : "+v"(lane));
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
-    {
-#pragma unroll
-        for (int k = 0; k < APW; ++k)
+        for (int h = 0; h < 2; ++h)
         {
-            const int c = wid + k * NW;
-            const int row = c * 8 + (lane >> 3);
-            int gr = m0 + h * AH + row;
-            gr = gr < M ? gr : M - 1;
-            xo[h][k] = (uint32_t) (gr * (int) p.lda * ES + (((lane & 7) ^ swz_g(row)) << 4));
-        }
 #pragma unroll
-        for (int k = 0; k < BPW; ++k)
-        {
-            int c = (h == 0 ? wid : wrev) + k * NW;
-            c = c < BCH ? c : BCH - 1;
-            const int row = c * 8 + (lane >> 3);
-            int gr = n0 + (DUAL ? 0 : h * BH) + row;
-            gr = gr < N ? gr : N - 1;
-            wo[h][k] = (uint32_t) (gr * (int) p.ldw + (((lane & 7) ^ swz_g(row)) << 4));
+            for (int k = 0; k < APW; ++k)
+            {
+                const int c = wid + k * NW;
+                const int row = c * 8 + (lane >> 3);
+                int gr = m0 + h * AH + row;
+                gr = gr < M ? gr : M - 1;
+                xo[h][k] = (uint32_t) (gr * (int) p.lda * ES + (((lane & 7) ^ swz_g(row)) << 4));
+            }
+#pragma unroll
+            for (int k = 0; k < BPW; ++k)
+            {
+                int c = (h == 0 ? wid : wrev) + k * NW;
+                c = c < BCH ? c : BCH - 1;
+                const int row = c * 8 + (lane >> 3);
+                int gr = n0 + (DUAL ? 0 : h * BH) + row;
+                gr = gr < N ? gr : N - 1;
+                wo[h][k] = (uint32_t) (gr * (int) p.ldw + (((lane & 7) ^ swz_g(row)) << 4));
+            }
         }
-    }
+    };
+    set_tile(wg);
     const uint32_t lds_base = (uint32_t) (uintptr_t) (lds_void_t*) lds;
     // issue unit `kind` of K-tile t into buffer t & 1
     auto dma = [&](int kind, int t) {
@@ -175,15 +194,18 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     }
 
     acc_t acc[2][2][MTH][NTH];
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int m = 0; m < MTH; ++m)
+                for (int m = 0; m < MTH; ++m)
 #pragma unroll
-                for (int n = 0; n < NTH; ++n)
-                    acc[i][j][m][n] = acc_t{0, 0, 0, 0};
+                    for (int n = 0; n < NTH; ++n)
+                        acc[i][j][m][n] = acc_t{0, 0, 0, 0};
+    };
+    zero_acc();
 
     i32x4 fa[2][MTH][2];     // X-half fragments [half][m][ks]
     i32x4 fb0[2][NTH][2];    // W-half 0 fragments, two sets: the next tile's are read while this tile's are still in use
@@ -232,44 +254,57 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
 
     // ---- the tile's scales go to LDS by 4-byte LDS-DMA, ahead of the operand stream (older in the vmcnt order): the
     // epilogue then needs no global load at all.  s_col -> [0, BN) floats, s_row -> [BN, BN + BM) floats behind the buffers
+    // (PERSIST: two such areas, the next tile's scales land while this tile's are still in use)
     constexpr int SC_OFF = 2 * BUF;
-    if constexpr (SCL)
-    {
-        constexpr int CCH = (BN + 63) / 64, RCH = (BM + 63) / 64;
-        const char* scb = reinterpret_cast<const char*>(p.scale_col);
-        const char* srb = reinterpret_cast<const char*>(p.scale_row);
-        for (int c = wid; c < CCH + RCH; c += NW) // wave-uniform
+    constexpr int SCB = (BM + BN) * 4;
+    // head of a tile's stream: its scales, then K-tiles 0 and 1
+    auto issue_head = [&](int area) {
+        if constexpr (SCL)
         {
-            if (c < CCH)
+            constexpr int CCH = (BN + 63) / 64, RCH = (BM + 63) / 64;
+            const char* scb = reinterpret_cast<const char*>(p.scale_col);
+            const char* srb = reinterpret_cast<const char*>(p.scale_row);
+            const uint32_t sbase = lds_base + SC_OFF + area * SCB;
+            for (int c = wid; c < CCH + RCH; c += NW) // wave-uniform
             {
-                const int j = c * 64 + lane; // column slot of the tile: DUAL keeps the second matrix's scales in [BH, 2 BH)
-                int col = n0 + (DUAL ? (j < BH ? j : j - BH) : j);
-                col = col < N ? col : N - 1;
-                const char* base = (DUAL && j >= BH) ? reinterpret_cast<const char*>(p.scale_col2) : scb;
-                glds4v(base + (p.per_channel ? (int64_t) col * 4 : 0), lds_base + SC_OFF + c * 256);
-            }
-            else
-            {
-                int row = m0 + (c - CCH) * 64 + lane;
-                row = row < M ? row : M - 1;
-                glds4s(srb, p.per_token ? (uint32_t) row * 4u : 0u, lds_base + SC_OFF + BN * 4 + (c - CCH) * 256);
+                if (c < CCH)
+                {
+                    const int j = c * 64 + lane; // column slot of the tile: DUAL keeps the second matrix's scales in [BH, 2 BH)
+                    int col = n0 + (DUAL ? (j < BH ? j : j - BH) : j);
+                    col = col < N ? col : N - 1;
+                    const char* base = (DUAL && j >= BH) ? reinterpret_cast<const char*>(p.scale_col2) : scb;
+                    glds4v(base + (p.per_channel ? (int64_t) col * 4 : 0), sbase + c * 256);
+                }
+                else
+                {
+                    int row = m0 + (c - CCH) * 64 + lane;
+                    row = row < M ? row : M - 1;
+                    glds4s(srb, p.per_token ? (uint32_t) row * 4u : 0u, sbase + BN * 4 + (c - CCH) * 256);
+                }
             }
         }
-    }
-    // ---- prologue: tiles 0 and 1 requested, X0(0) / W0(0) fragments in registers, X0(2) requested
-    dma(0, 0), dma(1, 0), dma(2, 0), dma(3, 0);
-    if (ntile > 1)
-    {
-        dma(0, 1), dma(1, 1), dma(2, 1), dma(3, 1);
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CYC) : "memory");
-    }
-    else
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    read_x(fa[0], lds + OFF_X0);
-    read_w(fb0[0], lds + OFF_W0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (ntile > 2)
-        dma(0, 2);
+        dma(0, 0), dma(1, 0), dma(2, 0), dma(3, 0);
+        if (ntile > 1)
+            dma(0, 1), dma(1, 1), dma(2, 1), dma(3, 1);
+    };
+    // ---- prologue: tiles 0 and 1 requested, X0(0) / W0(0) fragments in registers, X0(2) requested.  `behind`: vector-memory
+    // instructions this wave has issued AFTER the head (PERSIST: the previous tile's output stores) - negative: unknown, drain
+    auto finish_head = [&](int behind) {
+        if (ntile > 1 && behind == 0)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CYC) : "memory");
+        else if (PERSIST && ntile > 1 && behind > 0)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CYC + (PERSIST ? 2 * MTH * (WR * 16 * (BN / 8)) / (NW * 64) : 0)) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        read_x(fa[0], lds + OFF_X0);
+        read_w(fb0[0], lds + OFF_W0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (ntile > 2)
+            dma(0, 2);
+    };
+    issue_head(0);
+    if constexpr (!PERSIST)
+        finish_head(0);
 
     // one phase: the MFMAs of C quadrant (I, J); the NR fragment reads of the NEXT phase are spread evenly between them (all
     // 8 waves reading in one burst behind the barrier fills the LDS queue and the in-order waves stall in front of their
@@ -366,21 +401,127 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                 tile(P1{}, group, t + 1);
         }
     };
-    if constexpr (DMA_POS0 < 0)
-    {
-        static_assert(NW == 8, "per-pair DMA slots are laid out for 8 waves");
-        switch (wid >> 1) // wave-uniform
+    auto kloop = [&]() {
+        if constexpr (DMA_POS0 < 0)
         {
-        case 0: loop(std::integral_constant<int, 0>{}); break;
-        case 1: loop(std::integral_constant<int, 1>{}); break;
-        case 2: loop(std::integral_constant<int, 2>{}); break;
-        default: loop(std::integral_constant<int, 3>{}); break;
+            static_assert(NW == 8, "per-pair DMA slots are laid out for 8 waves");
+            switch (wid >> 1) // wave-uniform
+            {
+            case 0: loop(std::integral_constant<int, 0>{}); break;
+            case 1: loop(std::integral_constant<int, 1>{}); break;
+            case 2: loop(std::integral_constant<int, 2>{}); break;
+            default: loop(std::integral_constant<int, 3>{}); break;
+            }
         }
+        else if (grp == 0)
+            loop(P0{});
+        else
+            loop(P1{});
+    };
+    if constexpr (PERSIST)
+    {
+        // fp16 tile out in 2 * MTH rounds of RR = 16 * WR rows (round (i, m): every wave's 16 rows of MFMA tile row m of X-half i)
+        constexpr int PITCH = BN * 2 + 16, RR = WR * 16, PPR = BN / 8, SPT = RR * PPR / (NW * 64); // 16-byte stores per thread per round
+        static_assert((RR * PPR) % (NW * 64) == 0, "a round's pieces must divide evenly over the threads");
+        char* stg = lds + SC_OFF + 2 * SCB;
+        // the wave-group dispatch is the OUTERMOST branch: with the two K-loop forms re-joining once per tile the register
+        // allocator spilled fragments inside the loop (scratch traffic shares the vmcnt queue with the DMA)
+        auto persist = [&](auto group) {
+        int area = 0, behind = 0;
+        for (int tw = wg;;)
+        {
+            finish_head(behind);
+            loop(group);
+            // the last LDS read of the operand buffers sits in front of the last tile's P3 barrier: both buffers are free here
+            const int em0 = m0, en0 = n0;
+            const int next = tw + nwg;
+            const bool has_next = next < total_tiles; // workgroup-uniform
+            if (has_next)
+            {
+                set_tile(next);
+                issue_head(area ^ 1);
+            }
+            const float* sc_t = reinterpret_cast<const float*>(lds + SC_OFF + area * SCB);
+            const float* sr_t = sc_t + BN;
+            int lane = threadIdx.x & 63, tid = threadIdx.x; // (fresh copies: see set_tile)
+            asm volatile("" : "+v"(lane), "+v"(tid));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int m = 0; m < MTH; ++m)
+                {
+                    if (i | m)
+                        __syncthreads(); // the previous round has been read out of the staging rows
+                    const int rl = i * AH + (wr * MTH + m) * 16 + (lane & 15);
+                    const float sr = sr_t[rl];
+                    char* srow = stg + (wr * 16 + (lane & 15)) * PITCH;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int n = 0; n < NTH; ++n)
+                        {
+                            const int cl = j * BH + (wc * NTH + n) * 16 + 4 * (lane >> 4);
+                            const float4 sc = *reinterpret_cast<const float4*>(sc_t + cl);
+                            const acc_t a = acc[i][j][m][n];
+                            // the same two products per element, as packed fp32 multiplies (v_pk_mul_f32)
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            const f32x2 v01 = f32x2{(float) a[0], (float) a[1]} * (f32x2{sc.x, sc.y} * f32x2{sr, sr});
+                            const f32x2 v23 = f32x2{(float) a[2], (float) a[3]} * (f32x2{sc.z, sc.w} * f32x2{sr, sr});
+                            const uint32_t lo = (uint32_t) f2h(v01.x) | ((uint32_t) f2h(v01.y) << 16);
+                            const uint32_t hi = (uint32_t) f2h(v23.x) | ((uint32_t) f2h(v23.y) << 16);
+                            *reinterpret_cast<uint2*>(srow + cl * 2) = make_uint2(lo, hi);
+                        }
+                    __syncthreads();
+#pragma unroll
+                    for (int q = 0; q < SPT; ++q)
+                    {
+                        const int k = tid + q * NW * 64;
+                        const int sr16 = k / PPR, pc = k % PPR;
+                        const int grow = em0 + i * AH + ((sr16 >> 4) * MTH + m) * 16 + (sr16 & 15), gcol = en0 + pc * 8;
+                        if (grow < M && gcol < N)
+                        {
+                            uint4 v = *reinterpret_cast<const uint4*>(stg + sr16 * PITCH + pc * 16);
+                            const int64_t o = (int64_t) grow * p.ldc + gcol;
+                            if (p.residual)
+                            {
+                                const uint4 rv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.residual) + o);
+                                const uint32_t a4[4] = {v.x, v.y, v.z, v.w}, b4[4] = {rv.x, rv.y, rv.z, rv.w};
+                                uint32_t o4[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    o4[e] = (uint32_t) f2h(h2f((uint16_t) (a4[e] & 0xffffu)) + h2f((uint16_t) (b4[e] & 0xffffu)))
+                                        | ((uint32_t) f2h(h2f((uint16_t) (a4[e] >> 16)) + h2f((uint16_t) (b4[e] >> 16))) << 16);
+                                v = make_uint4(o4[0], o4[1], o4[2], o4[3]);
+                            }
+                            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                            __builtin_nontemporal_store(u4{v.x, v.y, v.z, v.w}, reinterpret_cast<u4*>(reinterpret_cast<uint16_t*>(p.c) + o));
+                        }
+                    }
+                }
+            if (!has_next)
+                break;
+            // a full tile: every thread has issued exactly 2 * MTH * SPT stores behind the next head; a ragged one: unknown
+            behind = (em0 + BM <= M && en0 + BN <= N && !p.residual) ? 1 : -1;
+            zero_acc();
+            area ^= 1;
+            tw = next;
+        }
+        };
+        static_assert(DMA_POS0 >= 0, "the persistent form dispatches on the wave half");
+        if (grp == 0)
+            persist(P0{});
+        else
+            persist(P1{});
+        if (p.clock_probe && tid == 0)
+        {
+            uint64_t* dbg = reinterpret_cast<uint64_t*>(p.clock_probe) + 2 * blockIdx.x;
+            dbg[0] = __builtin_readcyclecounter() - clk0;
+            dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+        }
+        return;
     }
-    else if (grp == 0)
-        loop(P0{});
     else
-        loop(P1{});
+        kloop();
 #undef SQP_TOP
 
     // ---- epilogue.  acc[i][j][m][n][r]: row i*AH + (wr*MTH + m)*16 + (lane & 15),
@@ -624,13 +765,14 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
 }
 
 template <int WR, int WC, int MTH, int NTH, int DP0, int DP1, bool PRIO, int ABL = 0, int RSP = 0, bool DUAL = false, bool SCL = true,
-    bool F16 = false>
+    bool F16 = false, bool PERSIST = false>
 int launch_sqp(const GemmParams& p, hipStream_t stream)
 {
     constexpr int BM = 2 * WR * MTH * 16, BN = 2 * WC * NTH * 16;
-    constexpr size_t smem = (size_t) 2 * (BM + BN) * 128 + (SCL ? (BM + BN) * 4 : 0); // operand buffers + the tile's scales
+    // operand buffers + the tile's scales (PERSIST: two scale areas + the staging rows of one output round)
+    constexpr size_t smem = (size_t) 2 * (BM + BN) * 128 + (SCL ? (BM + BN) * 4 : 0) * (PERSIST ? 2 : 1) + (PERSIST ? WR * 16 * (BN * 2 + 16) : 0);
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP, DUAL, SCL, F16>;
+    auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP, DUAL, SCL, F16, PERSIST>;
     static std::atomic<bool> attr_done{false};
     if (!attr_done)
     {
@@ -640,7 +782,22 @@ int launch_sqp(const GemmParams& p, hipStream_t stream)
     }
     constexpr int BNO = DUAL ? BN / 2 : BN; // output columns per tile
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BNO - 1) / BNO);
-    hipLaunchKernelGGL(kfn, dim3(tiles), dim3(64 * WR * WC), smem, stream, p);
+    int grid = tiles;
+    if (PERSIST)
+    {
+        // every workgroup the same number of tiles (+-1): ceil(tiles / rounds) workgroups, rounds = ceil(tiles / CUs)
+        static int cus = 0;
+        if (!cus)
+        {
+            int dev = 0, n = 0;
+            (void) hipGetDevice(&dev);
+            (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            cus = n > 0 ? n : 256;
+        }
+        const int rounds = (tiles + cus - 1) / cus;
+        grid = (tiles + rounds - 1) / rounds;
+    }
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WR * WC), smem, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
     {
@@ -691,6 +848,19 @@ int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
     case 41: return launch_sqp<2, 2, 2, 3, 2, 8, true, 16, 0, false, false>(p, stream);
     // 256 x 128 on 8 waves (64 x 64 wave tiles): the tile a split-K-2 pass of the O / down shapes would run (256 workgroups at M = 1024)
     case 42: return launch_sqp<4, 2, 2, 2, 0, 4, false, 16>(p, stream);
+    // persistent forms of 20 / 42 (fp16 output on 16-byte rows, K >= 256): one workgroup per CU, the next tile's head under the epilogue
+    case 60:
+    case 62:
+        if (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.residual) & 15) || p.K < 256)
+            return 1;
+        return cfg == 60 ? launch_sqp<4, 2, 2, 3, 0, 6, false, 16, 0, false, true, false, true>(p, stream)
+                         : launch_sqp<4, 2, 2, 2, 0, 4, false, 16, 0, false, true, false, true>(p, stream);
+    case 63: // the same with the DMA slots of id 13 (after MFMA 2 / 8 of a phase): the production form
+        if (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.residual) & 15) || p.K < 256)
+            return 1;
+        return launch_sqp<4, 2, 2, 3, 2, 8, false, 16, 0, false, true, false, true>(p, stream);
     // ablations of the 256 x 192 shape (wrong results on purpose; microbench only)
     case 21: return launch_sqp<4, 2, 2, 3, 2, 8, false, 1>(p, stream); // no DMA in the loop
     case 22: return launch_sqp<4, 2, 2, 3, 2, 8, false, 2>(p, stream); // no MFMA
