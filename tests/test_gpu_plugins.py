@@ -645,7 +645,9 @@ def test_allreduce_allgather_single_rank_rccl():
 
 
 # ---------------------------------------------------------------------------------------------- fused MLP GEMM
-@pytest.mark.parametrize('m,n,k', [(300, 456, 1152), (1024, 1376, 512), (64, 96, 128), (257, 200, 256)])
+@pytest.mark.parametrize('m,n,k', [(300, 456, 1152), (1024, 1376, 512), (64, 96, 128), (257, 200, 256),
+                                   # several tiles per persistent workgroup (r05): 460 / 440 tiles on 256 CUs, odd K-tile count, ragged rows
+                                   (1024, 11008, 384), (1000, 10560, 640)])
 def test_dual_gemm_swiglu_quant_equals_the_unfused_chain(m, n, k):
     """tllm_gemm_swiglu_quant (fc and gate of the SmoothQuant MLP in one kernel, SwiGLU + static quantiser in its epilogue,
     kernels/gemm_sqp.hip DUAL) against the chain it replaces in the prefill - two exact SmoothQuant GEMMs to fp16
@@ -692,6 +694,19 @@ def test_dual_gemm_swiglu_quant_equals_the_unfused_chain(m, n, k):
     # flip by one LSB - allow a handful, never more than 1
     diff = (got.int() - ref.int()).abs()
     assert int(diff.max()) <= 1 and int((diff > 0).sum()) <= max(4, m * n // 2000), (int(diff.max()), int((diff > 0).sum()))
+    # the persistent form (int8 rows on 16-byte boundaries) and the one-tile-per-workgroup form: the same bytes
+    lib.tllm_gemm_set_tile_cfg.argtypes = [ctypes.c_int32]
+    lib.tllm_gemm_set_tile_cfg.restype = None
+    lib.tllm_gemm_set_tile_cfg(-2)
+    try:
+        out2 = torch.full((m, n), 55, dtype=torch.int8, device='cuda')
+        q.c = out2.data_ptr()
+        assert lib.tllm_gemm_swiglu_quant(ctypes.byref(q), d['w2'].data_ptr(), d['s2'].data_ptr(), d['qs'].data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream) == 0, capi.last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(out2.cpu(), got)
+    finally:
+        lib.tllm_gemm_set_tile_cfg(0)
 
 
 def test_gemm_clock_probe_reports_a_plausible_shader_clock():

@@ -77,7 +77,7 @@ template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRI
 __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams p)
 {
     static_assert(SCL || !DUAL, "the fused SwiGLU epilogue reads its scales from LDS");
-    static_assert(!PERSIST || (SCL && !DUAL && !F16), "the persistent form is the SmoothQuant fp16-output GEMM");
+    static_assert(!PERSIST || (SCL && !F16), "the persistent form is the SmoothQuant GEMM (fp16 out, or the fused SwiGLU int8 out)");
     static_assert(!F16 || (!DUAL && !SCL), "the fp16 variant has no dual / staged-scale form");
     using acc_t = typename std::conditional<F16, f32x4, i32x4>::type;
     constexpr int ES = F16 ? 2 : 1; // bytes per operand element
@@ -257,6 +257,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     // (PERSIST: two such areas, the next tile's scales land while this tile's are still in use)
     constexpr int SC_OFF = 2 * BUF;
     constexpr int SCB = (BM + BN) * 4;
+    // PERSIST: 16-byte output stores every thread issues for a full tile (fp16: 2 MTH rounds of 16 WR rows; DUAL: the int8 tile at once)
+    constexpr int STORES_PER_TILE = DUAL ? BM * (BH / 16) / (NW * 64) : 2 * MTH * (WR * 16 * (BN / 8)) / (NW * 64);
     // head of a tile's stream: its scales, then K-tiles 0 and 1
     auto issue_head = [&](int area) {
         if constexpr (SCL)
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         if (ntile > 1 && behind == 0)
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CYC) : "memory");
         else if (PERSIST && ntile > 1 && behind > 0)
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CYC + (PERSIST ? 2 * MTH * (WR * 16 * (BN / 8)) / (NW * 64) : 0)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(CYC + STORES_PER_TILE) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         read_x(fa[0], lds + OFF_X0);
@@ -445,6 +447,60 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
             const float* sr_t = sc_t + BN;
             int lane = threadIdx.x & 63, tid = threadIdx.x; // (fresh copies: see set_tile)
             asm volatile("" : "+v"(lane), "+v"(tid));
+            if constexpr (DUAL)
+            {
+                // SwiGLU + static quantisation, as in the one-tile form below; the int8 tile [BM][BH] has staging rows of its own
+                constexpr int QPITCH = BH + 16, QPPR = BH / 16;
+                static_assert((BM * QPPR) % (NW * 64) == 0, "the tile's pieces must divide evenly over the threads");
+                const float qs = p.swiglu_qscale[0];
+                const float sr2 = p.scale_row2 ? p.scale_row2[0] : p.scale_row[0];
+#pragma unroll
+                for (int n = 0; n < NTH; ++n)
+                {
+                    const int cl = (wc * NTH + n) * 16 + 4 * (lane >> 4);
+                    const float4 sg = *reinterpret_cast<const float4*>(sc_t + cl);
+                    const float4 su = *reinterpret_cast<const float4*>(sc_t + BH + cl);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int m = 0; m < MTH; ++m)
+                        {
+                            const int rl = i * AH + (wr * MTH + m) * 16 + (lane & 15);
+                            const float sr = sr_t[rl];
+                            const i32x4 ag = acc[i][0][m][n], au = acc[i][1][m][n];
+                            const float sgv[4] = {sg.x, sg.y, sg.z, sg.w}, suv[4] = {su.x, su.y, su.z, su.w};
+                            uint32_t q4 = 0;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                            {
+                                const float g16 = h2f(f2h((float) ag[r] * (sgv[r] * sr)));
+                                const float u16 = h2f(f2h((float) au[r] * (suv[r] * sr2)));
+                                const float a16 = h2f(f2h(g16 / (1.f + __expf(-g16))));
+                                const float o16 = h2f(f2h(a16 * u16));
+                                q4 |= ((uint32_t) (uint8_t) f2i8_rni_sat(o16 * qs)) << (8 * r);
+                            }
+                            *reinterpret_cast<uint32_t*>(stg + rl * QPITCH + cl) = q4;
+                        }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < BM * QPPR / (NW * 64); ++q)
+                {
+                    const int k = tid + q * NW * 64;
+                    const int rl = k / QPPR, pc = k % QPPR;
+                    const int grow = em0 + rl, gcol = en0 + pc * 16;
+                    if (grow < M && gcol < N)
+                        *reinterpret_cast<uint4*>(reinterpret_cast<int8_t*>(p.c) + (int64_t) grow * p.ldc + gcol)
+                            = *reinterpret_cast<const uint4*>(stg + rl * QPITCH + pc * 16);
+                }
+                if (!has_next)
+                    break;
+                behind = (em0 + BM <= M && en0 + BH <= N) ? 1 : -1;
+                zero_acc();
+                area ^= 1;
+                tw = next;
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -770,7 +826,8 @@ int launch_sqp(const GemmParams& p, hipStream_t stream)
 {
     constexpr int BM = 2 * WR * MTH * 16, BN = 2 * WC * NTH * 16;
     // operand buffers + the tile's scales (PERSIST: two scale areas + the staging rows of one output round)
-    constexpr size_t smem = (size_t) 2 * (BM + BN) * 128 + (SCL ? (BM + BN) * 4 : 0) * (PERSIST ? 2 : 1) + (PERSIST ? WR * 16 * (BN * 2 + 16) : 0);
+    constexpr size_t smem = (size_t) 2 * (BM + BN) * 128 + (SCL ? (BM + BN) * 4 : 0) * (PERSIST ? 2 : 1)
+        + (PERSIST ? (DUAL ? BM * (BN / 2 + 16) : WR * 16 * (BN * 2 + 16)) : 0);
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP, DUAL, SCL, F16, PERSIST>;
     static std::atomic<bool> attr_done{false};
@@ -808,6 +865,9 @@ int launch_sqp(const GemmParams& p, hipStream_t stream)
 }
 
 } // namespace
+
+// A/B hook (tllm_gemm_set_tile_cfg(-2) / (-3)): the fused SwiGLU GEMM in its one-tile-per-workgroup form
+bool gemm_swiglu_one_tile = false;
 
 // microbench hook (tllm_gemm_set_clock_probe): device buffer of 2 x uint64 per workgroup = {shader cycles, 100 MHz ticks}
 void* gemm_clock_probe = nullptr;
@@ -916,7 +976,10 @@ int launch_gemm_swiglu(const GemmParams& p, hipStream_t stream)
         return 1;
     if ((int64_t) p.M * p.lda >= (1ll << 31) || (int64_t) p.N * p.ldw >= (1ll << 31))
         return 1;
-    return launch_sqp<4, 2, 2, 3, 0, 6, false, 0, 0, true>(p, stream); // 256 rows x 96 columns of both matrices
+    // 256 rows x 96 columns of both matrices; int8 output on 16-byte rows: the persistent form (r05)
+    if (!(p.ldc & 15) && !(p.N & 15) && !(reinterpret_cast<uintptr_t>(p.c) & 15) && p.K >= 256 && !gemm_swiglu_one_tile)
+        return launch_sqp<4, 2, 2, 3, 2, 8, false, 0, 0, true, true, false, true>(p, stream);
+    return launch_sqp<4, 2, 2, 3, 0, 6, false, 0, 0, true>(p, stream);
 }
 
 } // namespace kernels

@@ -43,6 +43,7 @@ extern int gemv_tune_blocks_per_cu;
 extern int gemv_mfma_min_rows;
 extern int gemm_tune_cfg;
 extern int gemm_woq_tune_cfg;
+extern bool gemm_swiglu_one_tile; // gemm_sqp.hip: A/B hook
 extern void* gemm_clock_probe;
 }
 } // namespace tllm
@@ -2349,6 +2350,11 @@ void tllm_gemm_set_tile_cfg(int32_t cfg)
 {
     // 0 resets both tables; 101.. select the tile shape of the weight-only main-loop-dequantising GEMM (gemm_woq.hip: 101 = 256 x 192,
     // 102 = 128 x 128, 103 = 256 x 192 two stages ahead, 104 = 256 x 192 on 4 waves)
+    // -2: the fused SwiGLU SmoothQuant GEMM in its one-tile-per-workgroup form (A/B against the persistent one; 0 resets)
+    if (cfg == 0 || cfg == -2)
+        tllm::kernels::gemm_swiglu_one_tile = cfg == -2;
+    if (cfg == -2)
+        return;
     if (cfg == 0 || cfg > 100)
         tllm::kernels::gemm_woq_tune_cfg = cfg > 100 ? cfg - 100 : 0;
     if (cfg > 100)
