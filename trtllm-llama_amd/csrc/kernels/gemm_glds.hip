@@ -608,11 +608,12 @@ int gemm_static_cfg(const GemmParams& p)
     const int cfg = static_shape_cfg(p);
     // (SmoothQuant: the persistent forms 62 / 63 of gemm_sqp.hip serve fp16 output on 16-byte rows; launch_gemm_glds falls back
     // to the one-tile-per-workgroup forms 42 / 20 for the rest)
-    const bool persist = p.wtype == W_INT8_SQ && p.out_dtype == DT_HALF && !(p.ldc & 7) && !(p.N & 7)
-        && !(reinterpret_cast<uintptr_t>(p.c) & 15) && p.K >= 256;
+    const bool persist = p.out_dtype == DT_HALF && !(p.ldc & 7) && !(p.N & 7) && !(reinterpret_cast<uintptr_t>(p.c) & 15)
+        && p.K >= 256;
     if (cfg == kPhased256x128)
-        return p.wtype == W_INT8_SQ ? (persist ? 62 : 42) : 54;
-    return cfg == 6 ? (p.wtype == W_INT8_SQ ? (persist ? 63 : 20) : 50) : cfg; // the 256 x 192 tile runs its phased sibling (gemm_sqp.hip)
+        return p.wtype == W_INT8_SQ ? (persist ? 62 : 42) : (persist ? 56 : 54);
+    // the 256 x 192 tile runs its phased sibling (gemm_sqp.hip)
+    return cfg == 6 ? (p.wtype == W_INT8_SQ ? (persist ? 63 : 20) : (persist ? 55 : 50)) : cfg;
 }
 
 // exactly kernel `cfg`, no fall-back: 0 launched, -1 launch error, 1 this kernel does not serve the problem (the tactic profiler)
@@ -657,7 +658,7 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
         if (cfg == kPhased256x128)
         {
             // one round of 256 x 128 tiles where 128 x 128 would take two (O / down at M = 2048: 34 vs 44 us, 84 vs 107 us)
-            int r = sq ? launch_gemm_sqp(p, 62, stream) : 1; // the persistent form first (r05)
+            int r = sq ? launch_gemm_sqp(p, 62, stream) : launch_gemm_f16p(p, 56, stream); // the persistent form first (r05)
             if (r > 0)
                 r = sq ? launch_gemm_sqp(p, 42, stream) : launch_gemm_f16p(p, 54, stream);
             if (r <= 0)
@@ -668,7 +669,9 @@ int launch_gemm_glds(const GemmParams& p, hipStream_t stream)
     if (!sq && cfg == 6 && gemm_tune_cfg <= 0 && !from_table)
     {
         // the same sibling on fp16 operands (r04): 6 - 7 % faster on QKV / gate / up at M = 1024 (profiles/r04_fp16_gemm_sweep.txt)
-        const int r = launch_gemm_f16p(p, 50, stream);
+        int r = launch_gemm_f16p(p, 55, stream); // (r05: its persistent form first)
+        if (r > 0)
+            r = launch_gemm_f16p(p, 50, stream);
         if (r <= 0)
             return r;
     }

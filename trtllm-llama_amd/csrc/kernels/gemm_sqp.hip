@@ -77,7 +77,7 @@ template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRI
 __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams p)
 {
     static_assert(SCL || !DUAL, "the fused SwiGLU epilogue reads its scales from LDS");
-    static_assert(!PERSIST || (SCL && !F16), "the persistent form is the SmoothQuant GEMM (fp16 out, or the fused SwiGLU int8 out)");
+    static_assert(!PERSIST || SCL || F16, "the persistent form: SmoothQuant with staged scales (fp16 out, or the fused SwiGLU int8 out), or fp16 operands");
     static_assert(!F16 || (!DUAL && !SCL), "the fp16 variant has no dual / staged-scale form");
     using acc_t = typename std::conditional<F16, f32x4, i32x4>::type;
     constexpr int ES = F16 ? 2 : 1; // bytes per operand element
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         // fp16 tile out in 2 * MTH rounds of RR = 16 * WR rows (round (i, m): every wave's 16 rows of MFMA tile row m of X-half i)
         constexpr int PITCH = BN * 2 + 16, RR = WR * 16, PPR = BN / 8, SPT = RR * PPR / (NW * 64); // 16-byte stores per thread per round
         static_assert((RR * PPR) % (NW * 64) == 0, "a round's pieces must divide evenly over the threads");
-        char* stg = lds + SC_OFF + 2 * SCB;
+        char* stg = lds + SC_OFF + (SCL ? 2 * SCB : 0);
         // the wave-group dispatch is the OUTERMOST branch: with the two K-loop forms re-joining once per tile the register
         // allocator spilled fragments inside the loop (scratch traffic shares the vmcnt queue with the DMA)
         auto persist = [&](auto group) {
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                     if (i | m)
                         __syncthreads(); // the previous round has been read out of the staging rows
                     const int rl = i * AH + (wr * MTH + m) * 16 + (lane & 15);
-                    const float sr = sr_t[rl];
+                    const float sr = F16 ? 1.f : sr_t[rl];
                     char* srow = stg + (wr * 16 + (lane & 15)) * PITCH;
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
@@ -517,7 +517,22 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                         for (int n = 0; n < NTH; ++n)
                         {
                             const int cl = j * BH + (wc * NTH + n) * 16 + 4 * (lane >> 4);
-                            const float4 sc = *reinterpret_cast<const float4*>(sc_t + cl);
+                            float4 sc;
+                            if constexpr (F16)
+                            {
+                                // fp16 operands: no scale at all, or an fp16 factor per output channel
+                                const uint16_t* g = reinterpret_cast<const uint16_t*>(p.scale_col);
+                                float v[4] = {1.f, 1.f, 1.f, 1.f};
+                                if (g)
+                                {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r)
+                                        v[r] = h2f(g[en0 + cl + r < N ? en0 + cl + r : N - 1]);
+                                }
+                                sc = make_float4(v[0], v[1], v[2], v[3]);
+                            }
+                            else
+                                sc = *reinterpret_cast<const float4*>(sc_t + cl);
                             const acc_t a = acc[i][j][m][n];
                             // the same two products per element, as packed fp32 multiplies (v_pk_mul_f32)
                             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -549,6 +564,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                                         | ((uint32_t) f2h(h2f((uint16_t) (a4[e] >> 16)) + h2f((uint16_t) (b4[e] >> 16))) << 16);
                                 v = make_uint4(o4[0], o4[1], o4[2], o4[3]);
                             }
+                            else if (F16 && p.silu_gate)
+                                v = epi_silu_gate8(v, *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.silu_gate) + o));
                             typedef uint32_t u4 __attribute__((ext_vector_type(4)));
                             __builtin_nontemporal_store(u4{v.x, v.y, v.z, v.w}, reinterpret_cast<u4*>(reinterpret_cast<uint16_t*>(p.c) + o));
                         }
@@ -557,7 +574,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
             if (!has_next)
                 break;
             // a full tile: every thread has issued exactly 2 * MTH * SPT stores behind the next head; a ragged one: unknown
-            behind = (em0 + BM <= M && en0 + BN <= N && !p.residual) ? 1 : -1;
+            behind = (em0 + BM <= M && en0 + BN <= N && !p.residual && !(F16 && (p.silu_gate || p.scale_col))) ? 1 : -1;
             zero_acc();
             area ^= 1;
             tw = next;
@@ -963,6 +980,14 @@ int launch_gemm_f16p(const GemmParams& pin, int cfg, hipStream_t stream)
     case 52: return launch_sqp<2, 2, 2, 2, 1, 5, true, 0, 0, false, false, true>(p, stream);  // 128 x 128 on 4 waves, 2 per CU
     case 53: return launch_sqp<4, 2, 2, 3, 2, 8, true, 0, 0, false, false, true>(p, stream);  // 256 x 192 with setprio
     case 54: return launch_sqp<4, 2, 2, 2, 0, 4, false, 16, 0, false, false, true>(p, stream); // 256 x 128
+    // persistent forms (r05: one workgroup per CU, the next tile's first K-tiles under the epilogue, band tile order)
+    case 55:
+    case 56:
+        if (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.residual) & 15) || (reinterpret_cast<uintptr_t>(p.silu_gate) & 15) || p.K < 128)
+            return 1;
+        return cfg == 55 ? launch_sqp<4, 2, 2, 3, 2, 8, false, 16, 0, false, false, true, true>(p, stream)  // 256 x 192
+                         : launch_sqp<4, 2, 2, 2, 0, 4, false, 16, 0, false, false, true, true>(p, stream); // 256 x 128
     default: return 1;
     }
 }
