@@ -92,6 +92,10 @@ int32_t tllm_session_get_beam_state(tllm_session_t s, int32_t* parent_ids, int32
 /* Rows the last logits hold (tllm_session_get_logits): batch_size after the prompt, batch_size * beam_width after a step. */
 int32_t tllm_session_logit_rows(tllm_session_t s);
 
+/* Vocabulary size of the model the session holds (the width of a logits row; the reference reads it from the engine's `logits`
+ * binding, runtime/session.py:116-145 infer_shapes). */
+int32_t tllm_session_vocab_size(tllm_session_t s);
+
 /* GenerationSession.decode (generation.py:782-997), greedy (top-k = 1): context step on the padded prompts,
  * then up to max_new_tokens generation steps with the sampler on device and no per-step host sync
  * (the reference syncs every step, generation.py:963).

@@ -299,7 +299,7 @@ def test_gemm_fp16(m, n, k):
 
 
 # ---------------------------------------------------------------------------------------------- prefill GEMM tiles
-@pytest.mark.parametrize('cfg', list(range(1, 21)) + [28, 29, 30, 36, 37, 40, 41, 42, 50, 51, 52, 53, 54, 55, 56, 60, 62, 63])
+@pytest.mark.parametrize('cfg', list(range(1, 13)) + [15, 18, 20, 36, 37, 42, 50, 51, 52, 53, 54, 55, 56, 60, 62, 63])
 def test_prefill_gemm_every_tile_shape(cfg):
     """Every tile shape of the LDS-DMA staged MFMA GEMM (kernels/gemm_glds.hip; tllm_gemm_set_tile_cfg) on a problem
     with ragged M / N edges and several K-tiles: SmoothQuant exact (int32 accumulation is order-independent, the

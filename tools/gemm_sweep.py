@@ -1,7 +1,7 @@
 """SmoothQuant GEMM tile-shape sweep at the LLaMA-7B prefill shapes: every requested tllm_gemm_set_tile_cfg id is checked
 exactly (against an int32 matmul of the same operands, same epilogue formula) on the first shape and then timed on all
 four, interleaved round-robin inside one process (one box, one clock state).
-    python tools/gemm_sweep.py [M] cfg [cfg ...]      e.g.  python tools/gemm_sweep.py 1024 6 8 13 15"""
+    python tools/gemm_sweep.py [M] cfg [cfg ...]      e.g.  python tools/gemm_sweep.py 1024 6 8 20 63"""
 import ctypes
 import os
 import sys

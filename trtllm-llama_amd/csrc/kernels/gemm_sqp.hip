@@ -42,19 +42,19 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // one LDS-DMA instruction: 64 lanes x 16 bytes, global (wave-uniform base + per-lane 32-bit offset) -> LDS [m0 + lane * 16]
 __device__ __forceinline__ void glds16s(const char* base, uint32_t off, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory", "m0");
 }
 
 // 4 bytes per lane from per-lane 64-bit addresses (scales of two different tensors in one chunk)
 __device__ __forceinline__ void glds4v(const void* gptr, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_byte) : "memory", "m0");
 }
 
 // the same with 4 bytes per lane (scales)
 __device__ __forceinline__ void glds4s(const char* base, uint32_t off, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory", "m0");
 }
 
 __device__ __forceinline__ int swz_g(int row)
@@ -908,21 +908,12 @@ int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
     switch (cfg)
     {
     //                              waves  tiles/half  DMA after MFMA # (low / high waves)  setprio
-    case 13: return launch_sqp<4, 2, 2, 3, 2, 8, true>(p, stream);  // 256 x 192
+    // (r05: the measured alternatives of the 256 x 192 shape - DMA slots 2/8 with and without setprio, head / tail slots, packed
+    //  fragment reads, one slot per wave pair, and the two-workgroups-per-CU 128 x 192 form - were within noise or slower
+    //  (profiles/r02_sqgemm_shapes.txt, r03_sqgemm_two_per_cu.txt) and are gone; ids 13, 16, 17, 19, 28 - 30, 40, 41)
     case 15: return launch_sqp<2, 2, 2, 2, 1, 5, true>(p, stream);  // 128 x 128, 4 waves, 2 workgroups per CU
-    case 16: return launch_sqp<4, 2, 2, 3, 0, 12, false>(p, stream); // 256 x 192, DMA at the head (low waves) / tail (high waves)
-    case 17: return launch_sqp<4, 2, 2, 3, 2, 8, false>(p, stream); // 256 x 192 without setprio
-    case 19: return launch_sqp<4, 2, 2, 3, 0, 6, false>(p, stream);
     case 20: return launch_sqp<4, 2, 2, 3, 0, 6, false, 16>(p, stream); // non-temporal output stores
-    // fragment reads packed behind the first MFMAs of the phase (one per MFMA), DMA late - no own read outstanding at its issue
-    case 28: return launch_sqp<4, 2, 2, 3, 9, 12, false, 0, 1>(p, stream);
-    case 29: return launch_sqp<4, 2, 2, 3, -1, 0, false, 16>(p, stream); // every wave its own DMA slot in the phase
-    case 30: return launch_sqp<4, 2, 2, 3, 10, 10, false, 0, 1>(p, stream);
     case 18: return launch_sqp<4, 2, 1, 2, 1, 3, true>(p, stream);  // 128 x 128 on 8 waves
-    // 128 x 192 on 4 waves (the 64 x 96 wave tile of the 256 x 192 shape), 80 KB: TWO independent workgroups per CU - one's
-    // prologue / epilogue under the other's main loop, at the price of 43 % more LDS-DMA bytes per MFMA
-    case 40: return launch_sqp<2, 2, 2, 3, 1, 7, false, 16, 0, false, false>(p, stream);
-    case 41: return launch_sqp<2, 2, 2, 3, 2, 8, true, 16, 0, false, false>(p, stream);
     // 256 x 128 on 8 waves (64 x 64 wave tiles): the tile a split-K-2 pass of the O / down shapes would run (256 workgroups at M = 1024)
     case 42: return launch_sqp<4, 2, 2, 2, 0, 4, false, 16>(p, stream);
     // persistent forms of 20 / 42 (fp16 output on 16-byte rows, K >= 256): one workgroup per CU, the next tile's head under the epilogue

@@ -1944,6 +1944,11 @@ int32_t tllm_session_logit_rows(tllm_session_t s)
     return s ? s->logit_rows : 0;
 }
 
+int32_t tllm_session_vocab_size(tllm_session_t s)
+{
+    return s ? s->vocab : 0;
+}
+
 // Back-track the beams (K/decodingKernels.cu:30-171 gatherTree, called at PY/runtime/generation.py:990-994): hypothesis j of
 // batch entry b ends with the token recorded for it at the last slot; its earlier tokens are those of its ancestors.
 int32_t tllm_session_get_beam_output(tllm_session_t s, int32_t* ids, float* cum_log_probs, tllm_stream_t stream)

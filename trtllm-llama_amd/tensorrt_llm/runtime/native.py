@@ -41,6 +41,8 @@ def _lib():
     lib.tllm_session_get_beam_state.restype = c.c_int32
     lib.tllm_session_logit_rows.argtypes = [c.c_void_p]
     lib.tllm_session_logit_rows.restype = c.c_int32
+    lib.tllm_session_vocab_size.argtypes = [c.c_void_p]
+    lib.tllm_session_vocab_size.restype = c.c_int32
     lib.tllm_session_generate.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32,
                                           c.c_void_p, c.c_void_p]
     lib.tllm_session_generate.restype = c.c_int32
@@ -97,7 +99,7 @@ class NativeSession:
         if not self._h:
             raise RuntimeError(f'tllm_session create failed: {capi.last_error()}')
         self.batch = self.max_in = self.max_new = 0
-        self.vocab = int(config['vocab_size']) if config else None
+        self.vocab = int(config['vocab_size']) if config else (int(lib.tllm_session_vocab_size(self._h)) or None)
 
     def set_tensor(self, name: str, t):
         lib = _lib()
