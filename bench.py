@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--two-launch-attention', action='store_true',
                     help='A/B: QKV projection and attention as two launches (session key fuse_qkv_attention = 0)')
+    ap.add_argument('--gemv-o-projection', action='store_true',
+                    help='A/B: the O-projection as a GEMV launch of its own (session key fuse_o_projection = 0)')
     ap.add_argument('--no-prefill', dest='prefill', action='store_false', help='skip the prefill (TTFT) and SQ-GEMM MFMA reports')
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
     ap.add_argument('--no-batch-sweep', dest='batch_sweep', action='store_false',
@@ -116,7 +118,8 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     cfg = dict(LLAMA_7B, num_layers=args.layers)
     int8_kv = mode != 'fp16'  # BASELINE.json configs: fp16 + fp16 KV; every int8 config with int8 KV
     qm = QM[mode] | (INT8_KV if int8_kv else 0)
-    sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=world, tp_rank=rank, fuse_qkv_attention=0 if args.two_launch_attention else -1))
+    sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=world, tp_rank=rank, fuse_qkv_attention=0 if args.two_launch_attention else -1,
+                              fuse_o_projection=0 if getattr(args, 'gemv_o_projection', False) else -1))
     weights = synth_weights(torch, cfg, mode, int8_kv, world, rank, dev)
     for k, v in weights.items():
         sess.set_tensor(k, v)
@@ -636,6 +639,12 @@ def main():
                  # (kernels/qkv_attn_fused.hip): its time is the 'qkv' entry, 'attention' is then an empty slot
                  'qkv_and_attention_in_one_launch': bool(res['kernel_us'].get('attention', 1.0) < 1.0
                                                          and not getattr(args, 'two_launch_attention', False)),
+                 # ... and (static SmoothQuant scales, r05) the O-projection + residual as that launch's third stage: the 'o_proj'
+                 # entry of layer_kernel_us is then the GEMV launch it REPLACES, timed alone (the A/B is --gemv-o-projection)
+                 'o_projection_in_the_attention_launch': bool(args.config == 'sq' and world == 1
+                                                              and res['kernel_us'].get('attention', 1.0) < 1.0
+                                                              and not getattr(args, 'two_launch_attention', False)
+                                                              and not getattr(args, 'gemv_o_projection', False)),
                  'profile_ms_per_step': {k: v[0] / prof_steps for k, v in prof.items()},
                  'launches_per_step': {k: v[1] / prof_steps for k, v in prof.items()}},
     }

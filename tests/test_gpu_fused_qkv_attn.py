@@ -28,8 +28,9 @@ pytestmark = pytest.mark.gpu
 PER_TOKEN = 1  # QuantMode.PER_TOKEN (T/tensorrt_llm/quantization/mode.py:6-21)
 
 
-def make(cfg, w, qm, fuse, taps=True):
-    s = NativeSession(dict(cfg, quant_mode=qm, tp_size=1, tp_rank=0, debug_taps=1 if taps else 0, fuse_qkv_attention=fuse))
+def make(cfg, w, qm, fuse, taps=True, fuse_o=-1):
+    s = NativeSession(dict(cfg, quant_mode=qm, tp_size=1, tp_rank=0, debug_taps=1 if taps else 0, fuse_qkv_attention=fuse,
+                           fuse_o_projection=fuse_o))
     for k, v in w.items():
         s.set_tensor(k, v)
     s.finalize()
@@ -156,3 +157,33 @@ def test_fused_launch_graph_replay_equals_eager_over_many_steps():
     np.testing.assert_array_equal(s2.generate(ids2, lens, NEW), g2)
     s.close()
     s2.close()
+
+
+@pytest.mark.parametrize('S,pad,int8_kv', [(3, 0, 1), (40, 9, 1), (1100, 0, 1), (4000, 0, 1), (300, 5, 0)])
+def test_o_projection_stage_equals_the_gemv_launch(S, pad, int8_kv):
+    """The O-projection + residual as the third stage of the fused launch (session key fuse_o_projection, r05) against the GEMV
+    launch it replaces (gemv_kernel<W_INT8_SQ, PK_NONE, EK_RESIDUAL>): both consume the same int8 context row, the integer dot
+    products are exact and the epilogue is the same expression - so EVERYTHING behind it must be identical: the O-projection's
+    operand, the logits of every step, the tokens and every byte of the KV cache.  Eager steps and graph replays."""
+    layers, NEW = 2, 7
+    cfg, w, qm = weights(layers, int8_kv)
+    max_in = S + pad
+    r = np.random.default_rng(100 + S)
+    ids = np.full((1, max_in), 2, np.int32)
+    ids[0, :S] = r.integers(3, cfg['vocab_size'], S)
+    lens = np.array([S], np.int32)
+    out = {}
+    for fuse_o in (0, 1):
+        s = make(cfg, w, qm, 1, fuse_o=fuse_o)
+        out[fuse_o] = run_with(s, cfg, ids, lens, max_in, NEW, layers, int8_kv, True)
+        s.close()
+    a, b = out[0], out[1]
+    for i in range(NEW):
+        np.testing.assert_array_equal(a['logits'][i], b['logits'][i])
+    for i in range(NEW - 1):
+        np.testing.assert_array_equal(a['qkv_in'][i], b['qkv_in'][i])
+        np.testing.assert_array_equal(a['o_in'][i], b['o_in'][i])
+    np.testing.assert_array_equal(a['tokens'], b['tokens'])
+    for li in range(layers):
+        np.testing.assert_array_equal(a['cache'][li], b['cache'][li])
+    assert np.abs(a['logits'][-1]).max() > 0

@@ -24,7 +24,8 @@ lib.tllm_session_fused_timeline_ptr.restype = ctypes.c_void_p
 hip = ctypes.CDLL('libamdhip64.so')
 hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 names = {0: 'start', 1: 'prologue done', 2: 'q rows done', 3: 'k rows done', 6: 'v rows done', 4: 'barrier C (q in LDS)',
-         5: 'barrier D (attention math)', 11: 'member 0: k, v, partials in LDS', 7: 'member 0: end'}
+         5: 'barrier D (attention math)', 11: 'member 0: k, v, partials in LDS', 7: 'member 0: end (context row published)',
+         8: 'row worker: O rows requested', 9: 'row worker: rows + context row in LDS', 10: 'row worker: end'}
 for rnd in range(3):
     us, n = s.time_kernel('qkv', sweeps=4)
     torch.cuda.synchronize()
@@ -33,8 +34,8 @@ for rnd in range(3):
     t = t.astype(np.int64)
     t0 = t[:, 0].min()
     print(f'--- round {rnd}: {us:.2f} us per launch; last launch, us since the first workgroup started (min / median / max over workgroups)')
-    for k in (0, 1, 2, 3, 6, 4, 5, 11, 7):
-        col = t[:, k] if k not in (7, 11) else t[:32, k]
+    for k in (0, 1, 2, 3, 6, 4, 5, 11, 7, 8, 9, 10):
+        col = t[:32, k] if k in (7, 11) else (t[32:, k] if k in (8, 9, 10) else t[:, k])
         col = col[col > 0]
         if len(col):
             r = (col - t0) / 100.0

@@ -216,8 +216,17 @@ struct FusedQkvAttnParams
     const float* out_quant_scale = nullptr;
     void* x_pro_out = nullptr; // optional s8 [K]: the quantised operand (tap)
     uint64_t* timing = nullptr; // optional [workgroups][16] stage clock (100 MHz ticks): tools/fused_timeline.py
+    // optional third stage (r05): the O-projection + residual of the same layer in the same launch,  x_out[n] = x[n] + O(ctx)[n]
+    // (needs out_q8: the context row reaches the row workers as its static int8 image).  o_w null: the launch ends with the context.
+    const void* o_w = nullptr;             // s8 [o_n, o_ldw]: rows of the dense projection, K = num_heads * head_size
+    int64_t o_ldw = 0;                     // bytes
+    int32_t o_n = 0, o_per_channel = 0;
+    const float* o_scale_col = nullptr;    // f32 [o_n] (per_channel) or [1]
+    const float* o_scale_row = nullptr;    // f32 [1]: the static activation scale of the dequantisation
+    void* x_out = nullptr;                 // fp16 [o_n]: may be x itself (every workgroup has consumed x long before)
 };
 size_t qkv_attn_fused_xchg_bytes(int32_t num_heads);
+bool qkv_attn_fused_serves_o(int32_t num_heads, int32_t head_size, int32_t o_n, int32_t o_k, int64_t o_ldw);
 bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int32_t max_seq_len, int32_t int8_kv);
 int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream);
 

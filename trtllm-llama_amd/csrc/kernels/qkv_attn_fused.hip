@@ -38,6 +38,7 @@
 // fp32 merge, nothing else.
 #include "dev_utils.h"
 #include "kernels.h"
+#include <atomic>
 #include <math.h>
 
 namespace tllm
@@ -57,6 +58,8 @@ constexpr int kWavesF = 8;     // waves per workgroup
 constexpr int kKChunks = 4;    // K = 4096 int8 = 4 x 1 KiB per weight row
 constexpr int kPartStride = 136; // granules per published partial: o[128], m, l (+ pad)
 constexpr int kHeadGranules = 3 * 64 + kMembers * kPartStride;
+constexpr int kCtxGranules = kDH / 4; // the head's context row as its int8 image, four elements per granule (O-projection stage)
+constexpr int kORowsMax = 24;         // dense-projection rows a row-worker workgroup takes at most (3 per wave)
 
 __device__ __forceinline__ void st_granule(gu64* g, uint32_t tag, uint32_t value)
 {
@@ -65,6 +68,12 @@ __device__ __forceinline__ void st_granule(gu64* g, uint32_t tag, uint32_t value
 __device__ __forceinline__ unsigned long long ld_granule(const gu64* g)
 {
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one LDS-DMA instruction: 64 lanes x 16 bytes, global (per-lane address) -> LDS [lds_byte + lane * 16]
+__device__ __forceinline__ void glds16(const void* gptr, uint32_t lds_byte)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory", "m0");
 }
 
 // RoPE (NeoX pairs (d, d + 64)) of the element pair (2l, 2l + 1) this lane of the sweeping wave holds: the partner pair sits in
@@ -198,6 +207,27 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     const bool q_dyn = p.act_quant_scale == nullptr;
     gu64* gx = (gu64*) p.xchg + (size_t) h * kHeadGranules;
     gu64* gp = gx + 3 * 64;
+    gu64* gc = (gu64*) p.xchg + (size_t) H * kHeadGranules; // [H][kCtxGranules]: the context rows (O-projection stage)
+    // O-projection stage: members 1 .. 7 of every head are the row workers - worker j takes rows [j n / W, (j + 1) n / W) of the dense
+    // projection, wave `wid` rows r0 + wid, + 8, + 16.  Their per-channel scales and residual elements are launch constants too
+    extern __shared__ __attribute__((aligned(16))) char wo_lds[]; // [rows of this worker][K bytes], filled by LDS-DMA
+    const bool o_stage = p.o_w != nullptr; // uniform
+    const int o_workers = (kMembers - 1) * H;
+    const int o_j = (mem - 1) * H + h;
+    const int o_r0 = o_stage && mem ? (int) ((int64_t) o_j * p.o_n / o_workers) : 0;
+    const int o_r1 = o_stage && mem ? (int) ((int64_t) (o_j + 1) * p.o_n / o_workers) : 0;
+    float o_cs[3], o_res[3];
+    float o_rs = 1.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+        const int row = o_r0 + wid + 8 * i;
+        const bool on = row < o_r1; // wave-uniform
+        o_cs[i] = on ? p.o_scale_col[p.o_per_channel ? row : 0] : 0.f;
+        o_res[i] = on ? h2f(reinterpret_cast<const uint16_t*>(p.x)[row]) : 0.f;
+    }
+    if (o_stage)
+        o_rs = p.o_scale_row[0];
     // launch constants, requested before anything else (and before the kernel's first store: behind one hipcc no longer uses the
     // scalar path for them, and as vector loads behind the q rows they held the prologue until the q rows had arrived)
     float pro_q = 1.f, deq = 1.f;
@@ -563,6 +593,25 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             atomicOr(p.error, 1u);
         return;
     }
+    // O-projection stage, row workers: waves 3 - 7 (no part in the publication below) request the worker's rows of the dense
+    // projection by LDS-DMA NOW - the CU's load queue is empty, and the 3 - 4 us until the context rows arrive are what the
+    // 16 MB of weights take (row slot s of the worker -> wave 3 + s % 5)
+    if (o_stage && mem != 0 && wid >= 3)
+    {
+        const uint32_t wo_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void*) wo_lds;
+        const char* owb = reinterpret_cast<const char*>(p.o_w);
+#pragma unroll
+        for (int i = 0; i < (kORowsMax + 4) / 5; ++i)
+        {
+            const int slot = (wid - 3) + 5 * i;
+            if (o_r0 + slot < o_r1) // wave-uniform
+            {
+#pragma unroll
+                for (int u = 0; u < kKChunks; ++u)
+                    glds16(owb + (int64_t) (o_r0 + slot) * p.o_ldw + u * 1024 + lane * 16, wo_base + (slot * kKChunks + u) * 1024);
+            }
+        }
+    }
     // the eight waves -> the member's partial, published as tagged granules: o[d] by thread d, m by thread 128, l by thread 129
     if (tid < kDH + 2)
     {
@@ -583,7 +632,76 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         st_granule(gp + mem * kPartStride + tid, tag, __float_as_uint(val));
     }
     if (mem != 0)
+    {
+        if (!o_stage)
+            return;
+        // -------------------------------------------------------------- 7. row workers: x_out[n] = x[n] + O(ctx)[n]
+        TLLM_STAMP(8);
+        // every head's context row (int8, 4 elements per granule): 1024 granules, two per thread, behind the DMA in the queue
+        {
+            const gu64* g0 = gc + tid;
+            const gu64* g1 = gc + 512 + tid;
+            unsigned long long a = ld_granule(g0), b = ld_granule(g1);
+            int spins = 0;
+            while (!__all((uint32_t) (a >> 32) == tag && (uint32_t) (b >> 32) == tag))
+            {
+                if (++spins > p.max_spins)
+                {
+                    if (lane == 0)
+                        misc[1] = 1.f;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                a = ld_granule(g0);
+                b = ld_granule(g1);
+            }
+            reinterpret_cast<uint32_t*>(xs)[tid] = (uint32_t) a;
+            reinterpret_cast<uint32_t*>(xs)[512 + tid] = (uint32_t) b;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the rows this wave requested are in LDS
+        __syncthreads();                                  // ... everybody's are, and so is the context row
+        TLLM_STAMP(9);
+        if (misc[1] != 0.f) // uniform
+        {
+            if (tid == 0)
+                atomicOr(p.error, 4u);
+            return;
+        }
+        // rows r0 + wid, + 8, + 16 of the worker (any wave reads any row: the barrier above is behind every wave's vmcnt(0)); the
+        // three dot products and their cross-lane sums side by side
+        int acc[3] = {0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < kKChunks; ++u)
+        {
+            const uint4 xr = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * 16);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+            {
+                const int slot = wid + 8 * i < o_r1 - o_r0 ? wid + 8 * i : 0; // (a row that does not exist: slot 0, result dropped)
+                const uint4 wv = *reinterpret_cast<const uint4*>(wo_lds + (slot * kKChunks + u) * 1024 + lane * 16);
+                acc[i] = sdot4(wv.x, xr.x, acc[i]);
+                acc[i] = sdot4(wv.y, xr.y, acc[i]);
+                acc[i] = sdot4(wv.z, xr.z, acc[i]);
+                acc[i] = sdot4(wv.w, xr.w, acc[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            acc[i] = wave_sum(acc[i]);
+        // epilogue of the unfused GEMV (gemv_impl.h, EPI_RESIDUAL): fp16(fp16(float(acc) * (scale_col * scale_row)) + residual)
+        if (lane < 3)
+        {
+            const int i = lane;
+            const int row = o_r0 + wid + 8 * i;
+            const int a = i == 0 ? acc[0] : (i == 1 ? acc[1] : acc[2]);
+            const float cs_i = i == 0 ? o_cs[0] : (i == 1 ? o_cs[1] : o_cs[2]);
+            const float rs_i = i == 0 ? o_res[0] : (i == 1 ? o_res[1] : o_res[2]);
+            if (row < o_r1)
+                reinterpret_cast<uint16_t*>(p.x_out)[row] = f2h(h2f(f2h((float) a * (cs_i * o_rs))) + rs_i);
+        }
+        TLLM_STAMP(10);
         return;
+    }
 
     // ------------------------------------------------------------------ 6. member 0: k, v, the eight partials -> context row
     if (wid == 0)
@@ -682,7 +800,11 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         const int64_t oi = (int64_t) h * kDH + d;
         reinterpret_cast<uint16_t*>(p.out)[oi] = h16;
         if (p.out_q8)
-            reinterpret_cast<int8_t*>(p.out_q8)[oi] = f2i8_rni_sat(h2f(h16) * p.out_quant_scale[0]);
+        {
+            const int8_t q8 = f2i8_rni_sat(h2f(h16) * p.out_quant_scale[0]);
+            reinterpret_cast<int8_t*>(p.out_q8)[oi] = q8;
+            reinterpret_cast<int8_t*>(red)[d] = q8; // (the prologue's scratch: free since the first barrier)
+        }
     }
     else if (tid < kDH + 16)
     {
@@ -721,6 +843,12 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         const int c = tid - 192, i = c >> 6, g = c & 63;
         reinterpret_cast<uint32_t*>(p.qkv_out)[((int64_t) (i * H + h) * kDH) / 2 + g] = raw[c];
     }
+    if (o_stage) // uniform: the context row to the row workers, four int8 per granule
+    {
+        __syncthreads(); // F
+        if (tid < kCtxGranules)
+            st_granule(gc + h * kCtxGranules + tid, tag, reinterpret_cast<const uint32_t*>(red)[tid]);
+    }
     TLLM_STAMP(7);
 }
 #undef TLLM_STAMP
@@ -729,7 +857,26 @@ template <bool INT8KV>
 int launch_i8(const FusedQkvAttnParams& p, int nit, hipStream_t stream)
 {
     const dim3 grid(p.num_heads * kMembers), block(64 * kWavesF);
-#define TLLM_FUSED_LAUNCH(N) hipLaunchKernelGGL((qkv_attn_fused_kernel<N, INT8KV>), grid, block, 0, stream, p)
+    // O-projection stage: the row worker's rows of the dense projection live in dynamic LDS (<= 24 rows x K bytes)
+    const size_t dyn = p.o_w ? (size_t) kORowsMax * kKChunks * 1024 : 0;
+    static std::atomic<bool> attr_done[2][6];
+    const int slot = nit == 1 ? 0 : nit == 2 ? 1 : nit == 3 ? 2 : nit == 4 ? 3 : nit == 6 ? 4 : 5;
+    if (dyn && !attr_done[INT8KV][slot])
+    {
+#define TLLM_FUSED_ATTR(N) (void) hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_attn_fused_kernel<N, INT8KV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn)
+        switch (nit)
+        {
+        case 1: TLLM_FUSED_ATTR(1); break;
+        case 2: TLLM_FUSED_ATTR(2); break;
+        case 3: TLLM_FUSED_ATTR(3); break;
+        case 4: TLLM_FUSED_ATTR(4); break;
+        case 6: TLLM_FUSED_ATTR(6); break;
+        default: TLLM_FUSED_ATTR(8); break;
+        }
+#undef TLLM_FUSED_ATTR
+        attr_done[INT8KV][slot] = true;
+    }
+#define TLLM_FUSED_LAUNCH(N) hipLaunchKernelGGL((qkv_attn_fused_kernel<N, INT8KV>), grid, block, dyn, stream, p)
     switch (nit)
     {
     case 1: TLLM_FUSED_LAUNCH(1); break;
@@ -763,7 +910,16 @@ int pick_nit(int max_seq_len, bool int8_kv)
 
 size_t qkv_attn_fused_xchg_bytes(int32_t num_heads)
 {
-    return (size_t) num_heads * kHeadGranules * sizeof(uint64_t);
+    return (size_t) num_heads * (kHeadGranules + kCtxGranules) * sizeof(uint64_t);
+}
+
+// the O-projection stage: K = H * Dh = 4 KiB rows (the context row is swept by 512 threads x two granules), every row worker's
+// share of the rows fits its LDS area
+bool qkv_attn_fused_serves_o(int32_t num_heads, int32_t head_size, int32_t o_n, int32_t o_k, int64_t o_ldw)
+{
+    const int workers = (kMembers - 1) * num_heads;
+    return head_size == kDH && o_k == num_heads * head_size && o_k == kKChunks * 1024 && num_heads * kCtxGranules == 1024
+        && o_ldw % 16 == 0 && o_ldw >= o_k && o_n > 0 && (o_n + workers - 1) / workers <= kORowsMax;
 }
 
 bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int32_t max_seq_len, int32_t int8_kv)
@@ -796,6 +952,14 @@ int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream)
         || (p.int8_kv && (!p.kv_scale_orig_quant || !p.kv_scale_quant_orig)) || p.ldw % 16)
     {
         set_error("fused QKV + attention: missing operand");
+        return -1;
+    }
+    if (p.o_w
+        && (!p.out_q8 || !p.o_scale_col || !p.o_scale_row || !p.x_out
+            || !qkv_attn_fused_serves_o(p.num_heads, p.head_size, p.o_n, p.num_heads * p.head_size, p.o_ldw)))
+    {
+        set_error("fused QKV + attention: the O-projection stage needs the static int8 context row and a dense projection of %d x %d",
+            p.num_heads * p.head_size, p.num_heads * p.head_size);
         return -1;
     }
     const int nit = pick_nit(p.max_seq_len, p.int8_kv != 0);
