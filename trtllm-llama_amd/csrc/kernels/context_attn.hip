@@ -412,7 +412,7 @@ __device__ __forceinline__ int swz128(int row, int c16)
 // front of the barrier is a counted one (the pieces this wave issued for block t + 1 stay outstanding).  With two stages the
 // launch could not be shorter than its chain of request -> landing latencies: the paired kernel with its arithmetic removed
 // (DMA, waits and barriers only) still took 22 of its 27 us at S = 1024 (profiles/r02_ctx_attn_pairing.txt, box D).
-template <int DH, int NQ, bool PAIR = false, bool RING = false>
+template <int DH, int NQ, bool PAIR = false, int NST = 2>
 __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const ContextAttnParams p, int spad)
 {
     static_assert(!PAIR || NQ == 4, "pairing deals four query slices");
@@ -479,8 +479,9 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
     // heavy waves are alone on their SIMDs with nothing to cover it
     const bool is_light = PAIR && qs >= 2;
     const int li = (qs - 2) * 2 + kh; // 0 .. 3 among the light waves
-    constexpr int AHEAD = RING ? 2 : 1; // block t is requested at step t - AHEAD
-    auto stage_of = [&](int t) { return RING ? t % 3 : (t & 1); };
+    constexpr bool RING = NST > 2;
+    constexpr int AHEAD = NST - 1; // block t is requested at step t - AHEAD: NST - 1 blocks in flight
+    auto stage_of = [&](int t) { return NST == 2 ? (t & 1) : t % NST; };
     auto handed_at = [&](int t) { return PAIR && (t - AHEAD > light || light == heavy); }; // workgroup-uniform
     // LDS-DMA pieces THIS wave issues for block t
     auto pieces_of = [&](int t) { return t >= nkb ? 0 : (handed_at(t) ? (is_light ? 2 * CPW : 0) : CPW); };
@@ -532,20 +533,27 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
     for (int s = 0; s < KST; ++s)
         asm volatile("" : "+v"(qf[s].x), "+v"(qf[s].y), "+v"(qf[s].z), "+v"(qf[s].w));
     issue(0);
-    if (RING && nkb > 1)
-        issue(1);
+#pragma unroll
+    for (int a = 1; a < AHEAD; ++a)
+        if (a < nkb)
+            issue(a);
     for (int t = 0; t < nkb; ++t)
     {
         // this wave's pieces of block t have landed (RING: those of block t + 1 may still be on their way - loads retire in order)
         if constexpr (RING)
         {
-            const int keep = pieces_of(t + 1); // wave-uniform
-            if (keep == 0)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (keep == CPW)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CPW) : "memory");
+            int keep = 0; // wave-uniform: the younger pieces of this wave, blocks t + 1 .. t + AHEAD - 1
+#pragma unroll
+            for (int a = 1; a < AHEAD; ++a)
+                keep += pieces_of(t + a);
+            switch (keep / CPW)
+            {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CPW) : "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * CPW) : "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * CPW) : "memory"); break;
+            }
         }
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -758,10 +766,13 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
                 // them: 30.4 -> 31.2 at S = 1024, 61.6 -> 63.0 at 2048 - the operand stream is bound by its rate, not by the latency
                 // of one block in flight; profiles/r02_ctx_attn_pairing.txt)
                 const bool ring = pair;
-                const size_t stg = ring ? stages / 2 * 3 : stages;
+                // (a FOURTH stage - three blocks in flight, 128 KB - measured 25.6 against 24.5 us at S = 1024 in r05: more bytes in
+                //  flight do not raise the rate of the operand stream)
+                const int nst = ring ? 3 : 2;
+                const size_t stg = stages / 2 * nst;
                 const size_t smem = stg > (narrow ? 2 : 4) * slab ? stg : 4 * slab;
                 auto kfn = narrow ? context_attn_mfma_ks_kernel<DH, 2>
-                                  : (pair ? context_attn_mfma_ks_kernel<DH, 4, true, true> : context_attn_mfma_ks_kernel<DH, 4>);
+                                  : (pair ? context_attn_mfma_ks_kernel<DH, 4, true, 3> : context_attn_mfma_ks_kernel<DH, 4>);
                 if (!attr_done)
                 {
                     if (stages > 64 * 1024 || 4 * slab > 64 * 1024)
@@ -770,7 +781,7 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                         (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4, true, true>),
+                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4, true, 3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
                     }
                     attr_done = true;
