@@ -216,10 +216,11 @@ void tllm_gemv_set_blocks_per_cu(int32_t n);
  * (5).  Both kernels give bit-identical results. */
 void tllm_gemv_set_mfma_rows(int32_t n);
 /* Test/bench knob: kernel id of the prefill GEMM (0 = tactic table, else the static rule).  1..12: lock-step tile shapes of
- * kernels/gemm_glds.hip (8 = 128x128, 6 = 256x192, 2 = 256x256, 4 = 128x256 are the production ones); 13..42: the phased
- * SmoothQuant pipeline of kernels/gemm_sqp.hip (20 = 256x192, 42 = 256x128; 21..33 are ablations with wrong results on
- * purpose); 50..54: the same pipeline on fp16 operands (50 = 256x192, 54 = 256x128); 101..106: the weight-only kernel of
- * kernels/gemm_woq.hip (101 = 256x192, 102 = 128x128, 106 = 256x128).  The ids are what tllm_gemm_profile reports. */
+ * kernels/gemm_glds.hip (8 = 128x128, 6 = 256x192, 2 = 256x256, 4 = 128x256 are the production ones); 15..63: the phased
+ * SmoothQuant pipeline of kernels/gemm_sqp.hip (20 = 256x192, 42 = 256x128, one tile per workgroup; 63 / 62 their persistent
+ * forms, r05; 21..33 are ablations with wrong results on purpose); 50..56: the same pipeline on fp16 operands (50 = 256x192,
+ * 54 = 256x128, 55 / 56 persistent); 101..106: the weight-only kernel of kernels/gemm_woq.hip (101 = 256x192, 102 = 128x128,
+ * 106 = 256x128); -2: the fused SwiGLU GEMM in its one-tile form.  The ids are what tllm_gemm_profile reports. */
 void tllm_gemm_set_tile_cfg(int32_t cfg);
 
 /* Kernel-level entry for the prefill GEMMs (kernels/gemm_mfma.hip; M <= 8 goes to the skinny GEMM):
@@ -241,6 +242,10 @@ typedef struct
 } tllm_gemm_params_t;
 
 int32_t tllm_gemm(const tllm_gemm_params_t* p, tllm_stream_t stream);
+/* The same with the decoder layer's residual add in the epilogue: c = fp16(fp16(epi(A W^T)) + residual), residual fp16 [M, ldc]
+ * (the `hidden_states = residual + attention_output` / `+ mlp_output` of Q/llama_model.py:78-86, which the prefill runs inside its
+ * O- and down-projection GEMMs).  fp16 output only; parity tests of the multi-tile (persistent) kernels' residual path. */
+int32_t tllm_gemm_residual(const tllm_gemm_params_t* p, const void* residual, tllm_stream_t stream);
 /* The SmoothQuant MLP's fc and gate projections in one launch (static activation scales): c = int8 [M, ldc] =
  * sat(rni(fp16(silu16(fp16(A W^T s)) * fp16(A W_up^T s_up)) * quant_scale[0])) - the rounding points of GEMM + GEMM + SwiGLU +
  * quantiser run separately (PY/layers/mlp.py:68-73 with K/quantization.cu's static quantiser), which it replaces in the

@@ -811,3 +811,66 @@ def test_mfma_skinny_gemm_equals_the_valu_kernel(m, n, k, pro, epi, per_channel,
         lib.tllm_gemv_set_mfma_rows(-1)
     assert np.abs(outs[0].astype(np.int64)).sum() > 0
     np.testing.assert_array_equal(outs[0], outs[1])
+
+
+# ---------------------------------------------------------------------------------------------- persistent prefill GEMM (r05)
+@pytest.mark.parametrize('cfg,m,n,k,residual', [
+    (63, 2304, 7000, 640, False),   # 9 x 37 = 333 tiles of 256 x 192 on 256 CUs: two tiles per workgroup, ragged columns, odd K-tile count
+    (63, 2100, 7000, 384, True),    # ragged rows as well, the residual in the epilogue (the drained-wait path)
+    (62, 2304, 5000, 512, False),   # 9 x 40 = 360 tiles of 256 x 128
+    (62, 1300, 12288, 256, True),   # 6 x 96 = 576 tiles: three per workgroup, the shortest K the persistent form serves
+    (55, 2304, 7000, 320, True),    # fp16 operands, persistent 256 x 192
+    (56, 2304, 5000, 256, False)])  # fp16 operands, persistent 256 x 128
+def test_persistent_prefill_gemm_several_tiles_per_workgroup(cfg, m, n, k, residual):
+    """The persistent forms of the phased prefill GEMM (gemm_sqp.hip PERSIST: a workgroup walks several tiles, the next tile's first
+    K-tiles are requested under the epilogue, the output stores stay counted in the waits) on problems with MORE tiles than CUs -
+    test_prefill_gemm_every_tile_shape gives every workgroup one tile.  SmoothQuant: every output exact against an fp64-accumulated
+    integer product with the reference's epilogue (fp16(float(acc) * (s_col * s_row)), then the fp16 residual add); fp16: the fp16
+    GEMM tolerance.  Ragged last row / column tiles, odd K-tile counts, with and without the fused residual."""
+    lib = capi.load_library()
+
+    class GemmParams(ctypes.Structure):
+        _fields_ = [('wtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32), ('M', ctypes.c_int32), ('N', ctypes.c_int32),
+                    ('K', ctypes.c_int32), ('a', ctypes.c_void_p), ('lda', ctypes.c_int64), ('w', ctypes.c_void_p),
+                    ('ldw', ctypes.c_int64), ('scale_col', ctypes.c_void_p), ('scale_row', ctypes.c_void_p),
+                    ('per_channel', ctypes.c_int32), ('per_token', ctypes.c_int32), ('c', ctypes.c_void_p), ('ldc', ctypes.c_int64)]
+
+    lib.tllm_gemm.argtypes = [ctypes.POINTER(GemmParams), ctypes.c_void_p]
+    lib.tllm_gemm.restype = ctypes.c_int32
+    lib.tllm_gemm_residual.argtypes = [ctypes.POINTER(GemmParams), ctypes.c_void_p, ctypes.c_void_p]
+    lib.tllm_gemm_residual.restype = ctypes.c_int32
+    lib.tllm_gemm_set_tile_cfg.argtypes = [ctypes.c_int32]
+    lib.tllm_gemm_set_tile_cfg.restype = None
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(cfg + m)
+    sq = cfg >= 60
+    stream = torch.cuda.current_stream().cuda_stream
+    res = (torch.randn((m, n), device=dev) * 3).half() if residual else None
+    c = torch.full((m, n), 7.0, dtype=torch.float16, device=dev)
+    if sq:
+        a = torch.randint(-128, 128, (m, k), dtype=torch.int8, device=dev)
+        w = torch.randint(-128, 128, (n, k), dtype=torch.int8, device=dev)
+        sc = torch.randint(1, 13, (n, ), device=dev).float() * 1e-4
+        sr = torch.randint(1, 13, (m, ), device=dev).float() * 1e-3
+        q = GemmParams(3, 1, m, n, k, a.data_ptr(), k, w.data_ptr(), k, sc.data_ptr(), sr.data_ptr(), 1, 1, c.data_ptr(), n)
+        ref = ((a.double() @ w.double().t()).float() * (sc[None, :] * sr[:, None])).half()
+    else:
+        a = torch.randn((m, k), dtype=torch.float16, device=dev)
+        w = (torch.randn((n, k), device=dev) / np.sqrt(k)).half()
+        q = GemmParams(0, 1, m, n, k, a.data_ptr(), k, w.data_ptr(), 2 * k, None, None, 0, 0, c.data_ptr(), n)
+        ref = (a.double() @ w.double().t()).half()
+    if residual:
+        ref = (ref.float() + res.float()).half()
+    lib.tllm_gemm_set_tile_cfg(cfg)
+    try:
+        for _ in range(2):  # twice: the second launch finds a warm instruction cache and different arrival orders
+            c.fill_(7.0)
+            rc = lib.tllm_gemm_residual(ctypes.byref(q), res.data_ptr(), stream) if residual else lib.tllm_gemm(ctypes.byref(q), stream)
+            assert rc == 0, capi.last_error()
+            torch.cuda.synchronize()
+            if sq:
+                assert torch.equal(c, ref), int((c != ref).sum())
+            else:
+                np.testing.assert_allclose(c.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-3, atol=4e-3 if residual else 2e-3)
+    finally:
+        lib.tllm_gemm_set_tile_cfg(0)

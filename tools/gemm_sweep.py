@@ -64,15 +64,24 @@ for name, (N, K) in shapes.items():
         if bad and cfg < 21:  # 21.. are ablations (wrong on purpose)
             print(f'cfg {cfg} {name}: {bad} of {M * N} outputs differ from the exact reference')
         res.setdefault(cfg, {})[name] = {'bad': bad, 'us': []}
+    # COLD=n: n copies of W and of X, a different one per launch (n x the bytes beyond the 256 MB Infinity Cache: every launch
+    # finds its operands in HBM, as a layer of the prefill does)
+    ncold = int(os.environ.get('COLD', '0'))
+    wcopies = [w] + [w.clone() for _ in range(max(ncold - 1, 0))]
+    acopies = [a] + [a.clone() for _ in range(max(ncold - 1, 0))]
     for rnd in range(5):
         for cfg in cfgs:
             lib.tllm_gemm_set_tile_cfg(cfg)
             lib.tllm_gemm(ctypes.byref(q), stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(20):
+            for it in range(20):
+                if ncold:
+                    q.w = wcopies[it % ncold].data_ptr()
+                    q.a = acopies[it % ncold].data_ptr()
                 lib.tllm_gemm(ctypes.byref(q), stream)
             e1.record()
+            q.w, q.a = w.data_ptr(), a.data_ptr()
             torch.cuda.synchronize()
             res[cfg][name]['us'].append(e0.elapsed_time(e1) * 1e3 / 20)
             if os.environ.get('CLOCKS'):  # the shader clock the kernel held (s_memtime against the 100 MHz counter)

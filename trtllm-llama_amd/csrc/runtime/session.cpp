@@ -2292,6 +2292,33 @@ int32_t tllm_gemm(const tllm_gemm_params_t* q, tllm_stream_t stream)
     return launch_gemm(g, reinterpret_cast<hipStream_t>(stream)) ? 1 : 0;
 }
 
+int32_t tllm_gemm_residual(const tllm_gemm_params_t* q, const void* residual, tllm_stream_t stream)
+{
+    if (!q || !residual || q->out_dtype != DT_HALF)
+    {
+        set_error("tllm_gemm_residual: needs a residual and fp16 output");
+        return 1;
+    }
+    GemmParams g;
+    g.wtype = q->wtype;
+    g.out_dtype = q->out_dtype;
+    g.M = q->M;
+    g.N = q->N;
+    g.K = q->K;
+    g.a = q->a;
+    g.lda = q->lda;
+    g.w = q->w;
+    g.ldw = q->ldw;
+    g.scale_col = q->scale_col;
+    g.scale_row = q->scale_row;
+    g.per_channel = q->per_channel;
+    g.per_token = q->per_token;
+    g.c = q->c;
+    g.ldc = q->ldc;
+    g.residual = residual;
+    return launch_gemm(g, reinterpret_cast<hipStream_t>(stream)) ? 1 : 0;
+}
+
 int32_t tllm_gemm_profile(int32_t wtype, int32_t M, int32_t N, int32_t K, int32_t* best_cfg, float* best_us, tllm_stream_t stream)
 {
     int cfg = 0;
