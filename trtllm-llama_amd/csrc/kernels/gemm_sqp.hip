@@ -43,19 +43,19 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // one LDS-DMA instruction: 64 lanes x 16 bytes, global (wave-uniform base + per-lane 32-bit offset) -> LDS [m0 + lane * 16]
 __device__ __forceinline__ void glds16s(const char* base, uint32_t off, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
 }
 
 // 4 bytes per lane from per-lane 64-bit addresses (scales of two different tensors in one chunk)
 __device__ __forceinline__ void glds4v(const void* gptr, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_byte) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
 }
 
 // the same with 4 bytes per lane (scales)
 __device__ __forceinline__ void glds4s(const char* base, uint32_t off, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
 }
 
 __device__ __forceinline__ int swz_g(int row)

@@ -192,8 +192,9 @@ struct FusedQkvAttnParams
     float eps = 1e-6f;
     const void* w = nullptr; // s8 [3 * num_heads * head_size, ldw]: q | k | v rows
     int64_t ldw = 0;         // bytes
-    const float* scale_col = nullptr; // f32 [3 * H * Dh] (per_channel) or [1]
+    const void* scale_col = nullptr; // SmoothQuant: f32 [3 * H * Dh] (per_channel) or [1]; weight-only: fp16 [3 * H * Dh]
     int32_t per_channel = 0;
+    int32_t woq8 = 0; // 1: weight-only int8 rows (u8 = q + 128) against the normalised fp16 row; no quantiser, no O-projection stage
     const float* act_quant_scale = nullptr;   // f32 [1]: static quantiser of the normalised row; null -> per-token (amax / 127)
     const float* act_dequant_scale = nullptr; // f32 [1]: the static activation scale of the dequantisation
     int32_t int8_kv = 0, max_seq_len = 0;

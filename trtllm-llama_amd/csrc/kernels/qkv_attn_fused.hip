@@ -70,10 +70,12 @@ __device__ __forceinline__ unsigned long long ld_granule(const gu64* g)
     return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// one LDS-DMA instruction: 64 lanes x 16 bytes, global (per-lane address) -> LDS [lds_byte + lane * 16]
+// one LDS-DMA instruction: 64 lanes x 16 bytes, global (per-lane address) -> LDS [lds_byte + lane * 16].  (M0 cannot go on the
+// clobber list - hipcc: "reserved register, may not be preserved" - and __builtin_amdgcn_global_load_lds would hand the waits
+// to the compiler's own vmcnt accounting; the generated code of these kernels has no other user of M0.)
 __device__ __forceinline__ void glds16(const void* gptr, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
 }
 
 // RoPE (NeoX pairs (d, d + 64)) of the element pair (2l, 2l + 1) this lane of the sweeping wave holds: the partner pair sits in
@@ -173,7 +175,10 @@ __device__ __forceinline__ float groups_max(float v)
     return max_xor32(max_xor16(v));
 }
 
-template <int NIT, bool INT8KV>
+// WOQ (r05): weight-only int8 projection weights (u8 = q + 128, fp16 per-channel scales) against the NORMALISED fp16 row - no
+// quantiser in the prologue, raw byte splices in the dots (1024 + u), 1152 * sum(x) taken off once per row: the arithmetic and
+// the summation order of gemv_impl.h's W_INT8_WOQ path, so the projection is bit-identical to the unfused GEMV.  Two-stage form only.
+template <int NIT, bool INT8KV, bool WOQ = false>
 __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnParams p)
 {
     constexpr int EPL = INT8KV ? 16 : 8; // cache elements per lane (16 bytes)
@@ -184,11 +189,12 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     constexpr int ESZ = INT8KV ? 1 : 2;
     constexpr int NQW = EPL / 2;         // 32-bit words of q per lane
 
-    __shared__ __attribute__((aligned(16))) char smem[4096 /* x s8 */ + 256 /* red */ + 3 * 256 /* q', k', v as fp16 */
+    constexpr int XSB = WOQ ? 8192 : 4096; // the projection's operand row: fp16 (weight-only) or int8
+    __shared__ __attribute__((aligned(16))) char smem[XSB /* x */ + 256 /* red */ + 3 * 256 /* q', k', v as fp16 */
         + 3 * 256 /* raw q, k, v */ + kWavesF * (kDH + 8) * 4 /* wave partials */ + kMembers * (kDH + 8) * 4 /* head partials */ + 64];
     char* xs = smem;
-    float* red = reinterpret_cast<float*>(smem + 4096);
-    uint32_t* rot = reinterpret_cast<uint32_t*>(smem + 4096 + 256);        // [3][64]: q', k' (RoPE applied), v
+    float* red = reinterpret_cast<float*>(smem + XSB);
+    uint32_t* rot = reinterpret_cast<uint32_t*>(smem + XSB + 256);         // [3][64]: q', k' (RoPE applied), v
     uint32_t* raw = rot + 3 * 64;                                          // [3][64]: q, k, v as projected
     float* wpart = reinterpret_cast<float*>(raw + 3 * 64);                 // [8][136]: o[128], m, l per wave
     float* hpart = wpart + kWavesF * (kDH + 8);                            // [8][136]: the head's partials (member 0)
@@ -260,7 +266,12 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         wrow[i] = (i * H + h) * kDH + mem * 16 + 2 * wid;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
-            cscale[i][r] = p.scale_col[p.per_channel ? wrow[i] + r : 0];
+        {
+            if constexpr (WOQ)
+                cscale[i][r] = h2f(reinterpret_cast<const uint16_t*>(p.scale_col)[wrow[i] + r]);
+            else
+                cscale[i][r] = reinterpret_cast<const float*>(p.scale_col)[p.per_channel ? wrow[i] + r : 0];
+        }
     }
     const float4 cs = reinterpret_cast<const float4*>(p.rope_row)[lane & 31]; // RoPE coefficients of elements 2 l', 2 l' + 1
     __builtin_amdgcn_sched_barrier(0); // issue order = consumption order (hipcc sank the gamma load below the weight loads)
@@ -316,8 +327,37 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             xs4[q] = h2_as_u32(hh);
             amax = fmaxf(amax, fmaxf(fabsf((float) hh.x), fabsf((float) hh.y)));
         }
+        if constexpr (WOQ)
+        {
+            // the splice bias 1152 * sum of the normalised row (fp16 values, fp32 sums) in the unfused prologue's order: thread
+            // t < 256 of that kernel owns vectors t and t + 256 - both are in this thread's registers (t2 = tid & 255), so waves
+            // 0 - 3 restate its sums and waves 4 - 7 repeat them
+            const uint4 ga = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.gamma) + t2 * 8);
+            const uint4 gb = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.gamma) + (t2 + 256) * 8);
+            const uint32_t xv[2][4] = {{xa.x, xa.y, xa.z, xa.w}, {xb.x, xb.y, xb.z, xb.w}};
+            const uint32_t gg[2][4] = {{ga.x, ga.y, ga.z, ga.w}, {gb.x, gb.y, gb.z, gb.w}};
+            float sa = 0.f, sb = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                {
+                    const h2_t hh = u32_as_h2(xv[j][q]);
+                    const h2_t g2 = u32_as_h2(gg[j][q]);
+                    const float n0 = h2f(f2h((float) hh.x * inv)), n1 = h2f(f2h((float) hh.y * inv));
+                    const float y0 = (float) (_Float16) (n0 * (float) g2.x), y1 = (float) (_Float16) (n1 * (float) g2.y);
+                    if (q & 1)
+                        sb += y0 + y1;
+                    else
+                        sa += y0 + y1;
+                }
+            const float bsum = wave_sum(1152.f * (sa + sb));
+            if (lane == 0 && wid < 4)
+                red[8 + wid] = bsum;
+            *reinterpret_cast<uint4*>(xs + tid * 16) = make_uint4(xs4[0], xs4[1], xs4[2], xs4[3]);
+        }
         float qs = pro_q;
-        if (q_dyn) // uniform: per-token scale amax / 127 (K/quantization.cu:94-118)
+        if (!WOQ && q_dyn) // uniform: per-token scale amax / 127 (K/quantization.cu:94-118)
         {
             amax = wave_max(amax);
             if (lane == 0)
@@ -340,9 +380,13 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             const uint32_t b1 = (uint8_t) f2i8_rni_sat((float) hh.y * qs);
             o[q >> 1] |= (b0 | (b1 << 8)) << (16 * (q & 1));
         }
-        *reinterpret_cast<uint2*>(xs + tid * 8) = make_uint2(o[0], o[1]);
+        if constexpr (!WOQ)
+            *reinterpret_cast<uint2*>(xs + tid * 8) = make_uint2(o[0], o[1]);
     }
     __syncthreads();
+    float xbias = 0.f;
+    if constexpr (WOQ)
+        xbias = red[8] + red[9] + red[10] + red[11];
     TLLM_STAMP(1);
     // (b2) the k rows, (c) the member's cache rows and masks
     __builtin_amdgcn_sched_barrier(0);
@@ -373,11 +417,31 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     }
     __builtin_amdgcn_sched_barrier(0);
     if (blockIdx.x == 0 && p.x_pro_out) // tap: the int8 operand exactly as the projection consumes it
-        for (int k = tid; k < K / 4; k += 512)
+        for (int k = tid; k < XSB / 4; k += 512)
             reinterpret_cast<uint32_t*>(p.x_pro_out)[k] = reinterpret_cast<const uint32_t*>(xs)[k];
 
     // ------------------------------------------------------------------ 2. the projections, one granule per wave and matrix
     auto project = [&](const uint4 (&wt)[kKChunks][2], int i) {
+        if constexpr (WOQ)
+        {
+            // lane l, chunk u: weights k = (u * 64 + l) * 16 .. + 16 against the 16 halfs of x at the same k (two LDS vectors)
+            float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < kKChunks; ++u)
+            {
+                const uint4 xlo = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * 32);
+                const uint4 xhi = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * 32 + 16);
+                f0 = dot_woq8_raw(wt[u][0], xlo, xhi, f0);
+                f1 = dot_woq8_raw(wt[u][1], xlo, xhi, f1);
+            }
+            f0 = wave_sum(f0) - xbias;
+            f1 = wave_sum(f1) - xbias;
+            // epilogue of the weight-only GEMV: fp16((sum - bias) * scale)
+            const uint32_t v = (uint32_t) f2h(f0 * (cscale[i][0] * 1.f)) | ((uint32_t) f2h(f1 * (cscale[i][1] * 1.f)) << 16);
+            if (lane == 0)
+                st_granule(gx + i * 64 + mem * 8 + wid, tag, v);
+            return;
+        }
         int a0 = 0, a1 = 0;
 #pragma unroll
         for (int u = 0; u < kKChunks; ++u)
@@ -853,17 +917,17 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
 }
 #undef TLLM_STAMP
 
-template <bool INT8KV>
+template <bool INT8KV, bool WOQ = false>
 int launch_i8(const FusedQkvAttnParams& p, int nit, hipStream_t stream)
 {
     const dim3 grid(p.num_heads * kMembers), block(64 * kWavesF);
     // O-projection stage: the row worker's rows of the dense projection live in dynamic LDS (<= 24 rows x K bytes)
     const size_t dyn = p.o_w ? (size_t) kORowsMax * kKChunks * 1024 : 0;
-    static std::atomic<bool> attr_done[2][6];
+    static std::atomic<bool> attr_done[6];
     const int slot = nit == 1 ? 0 : nit == 2 ? 1 : nit == 3 ? 2 : nit == 4 ? 3 : nit == 6 ? 4 : 5;
-    if (dyn && !attr_done[INT8KV][slot])
+    if (dyn && !attr_done[slot])
     {
-#define TLLM_FUSED_ATTR(N) (void) hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_attn_fused_kernel<N, INT8KV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn)
+#define TLLM_FUSED_ATTR(N) (void) hipFuncSetAttribute(reinterpret_cast<const void*>(qkv_attn_fused_kernel<N, INT8KV, WOQ>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn)
         switch (nit)
         {
         case 1: TLLM_FUSED_ATTR(1); break;
@@ -874,9 +938,9 @@ int launch_i8(const FusedQkvAttnParams& p, int nit, hipStream_t stream)
         default: TLLM_FUSED_ATTR(8); break;
         }
 #undef TLLM_FUSED_ATTR
-        attr_done[INT8KV][slot] = true;
+        attr_done[slot] = true;
     }
-#define TLLM_FUSED_LAUNCH(N) hipLaunchKernelGGL((qkv_attn_fused_kernel<N, INT8KV>), grid, block, dyn, stream, p)
+#define TLLM_FUSED_LAUNCH(N) hipLaunchKernelGGL((qkv_attn_fused_kernel<N, INT8KV, WOQ>), grid, block, dyn, stream, p)
     switch (nit)
     {
     case 1: TLLM_FUSED_LAUNCH(1); break;
@@ -963,6 +1027,15 @@ int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream)
         return -1;
     }
     const int nit = pick_nit(p.max_seq_len, p.int8_kv != 0);
+    if (p.woq8)
+    {
+        if (p.o_w || p.out_q8 || p.act_quant_scale)
+        {
+            set_error("fused QKV + attention: the weight-only form has no quantiser and no O-projection stage");
+            return -1;
+        }
+        return p.int8_kv ? launch_i8<true, true>(p, nit, stream) : launch_i8<false, true>(p, nit, stream);
+    }
     return p.int8_kv ? launch_i8<true>(p, nit, stream) : launch_i8<false>(p, nit, stream);
 }
 

@@ -908,10 +908,11 @@ struct tllm_session
                     f.eps = eps;
                     f.w = L.qkv.w;
                     f.ldw = L.qkv.ldw;
-                    f.scale_col = static_cast<const float*>(L.qkv.scale_col);
+                    f.scale_col = L.qkv.scale_col;
                     f.per_channel = L.qkv.per_channel;
-                    f.act_quant_scale = per_token ? nullptr : L.ln1_scale;
-                    f.act_dequant_scale = per_token ? nullptr : L.qkv.act_scale;
+                    f.woq8 = L.qkv.wtype == W_INT8_WOQ ? 1 : 0;
+                    f.act_quant_scale = (per_token || !sq) ? nullptr : L.ln1_scale;
+                    f.act_dequant_scale = (per_token || !sq) ? nullptr : L.qkv.act_scale;
                     f.int8_kv = int8_kv;
                     f.max_seq_len = Smax;
                     f.inv_sqrt_dh = 1.f / sqrtf((float) Dh);
@@ -1611,19 +1612,22 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
     s->qkv_attn_fused = false;
     s->o_fused = false;
     s->fused_xchg = nullptr;
-    if (s->fuse_qkv_cfg != 0 && s->attn_tail && B == 1 && s->beam == 1 && !s->paged_kv && s->tp == 1 && s->sq && s->neox
+    // (SmoothQuant, or - r05 - weight-only int8: the same 4 KB weight rows against the normalised fp16 row)
+    const bool woq8_all = !s->sq && !s->layers.empty() && s->layers[0].qkv.wtype == W_INT8_WOQ;
+    if (s->fuse_qkv_cfg != 0 && s->attn_tail && B == 1 && s->beam == 1 && !s->paged_kv && s->tp == 1 && (s->sq || woq8_all) && s->neox
         && qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0))
     {
         bool ok = true;
         for (auto& L : s->layers)
-            ok = ok && L.qkv.wtype == W_INT8_SQ && L.qkv.K == D && L.qkv.ldw == D && L.qkv.N == 3 * s->Dr;
+            ok = ok && L.qkv.wtype == (s->sq ? W_INT8_SQ : W_INT8_WOQ) && L.qkv.K == D && L.qkv.ldw == D && L.qkv.N == 3 * s->Dr
+                && L.qkv.scale_col;
         if (ok)
         {
             const size_t xb = qkv_attn_fused_xchg_bytes(s->Hr);
             RUN(s->dalloc(&s->fused_xchg, xb));
             HIP_OK(hipMemset(s->fused_xchg, 0, xb));
             s->qkv_attn_fused = true;
-            s->o_fused = s->fuse_o_cfg != 0 && !s->per_token; // (tp == 1 here: no all-reduce behind the projection)
+            s->o_fused = s->fuse_o_cfg != 0 && s->sq && !s->per_token; // (tp == 1 here: no all-reduce behind the projection)
             for (auto& L : s->layers)
                 s->o_fused = s->o_fused && L.dense.wtype == W_INT8_SQ && L.dense.N == D && L.dense.act_scale && L.attn_qscale
                     && qkv_attn_fused_serves_o(s->Hr, s->Dh, L.dense.N, L.dense.K, L.dense.ldw);
