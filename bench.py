@@ -645,6 +645,9 @@ def main():
                                                               and res['kernel_us'].get('attention', 1.0) < 1.0
                                                               and not getattr(args, 'two_launch_attention', False)
                                                               and not getattr(args, 'gemv_o_projection', False)),
+                 # the layer as the graph replay runs it: (device time per step - the head GEMV - the sampler, both from the eager
+                 # profile below) / layers.  layer_kernel_us above times the launches ONE BY ONE in their two-stage form
+                 'layer_us_in_graph_replay': (res['dev_ms'] / args.steps - (prof['gemv_head'][0] + prof['other'][0]) / prof_steps) * 1e3 / args.layers,
                  'profile_ms_per_step': {k: v[0] / prof_steps for k, v in prof.items()},
                  'launches_per_step': {k: v[1] / prof_steps for k, v in prof.items()}},
     }
