@@ -70,9 +70,7 @@ struct RopeRow
 };
 
 // the loads of one (token, head) - split from the rest so that a caller with several rows can have all of them in flight
-// WITH_Q = false (the MFMA path, r05): q is neither read, rotated nor written back here - the attention kernel rotates its own
-// Q fragments in registers (16 MB less traffic per layer at S = 1024)
-template <int DH, bool WITH_Q = true>
+template <int DH>
 __device__ __forceinline__ RopeRow rope_kv_load(const ContextAttnParams& p, int s, int h, int b, int li)
 {
     RopeRow r;
@@ -83,13 +81,13 @@ __device__ __forceinline__ RopeRow rope_kv_load(const ContextAttnParams& p, int 
     r.qp = row + (int64_t) h * DH + li * 8;
     r.kp = row + (int64_t) (H + h) * DH + li * 8;
     r.vp = row + (int64_t) (2 * H + h) * DH + li * 8;
-    r.q4 = WITH_Q ? *reinterpret_cast<const uint4*>(r.qp) : make_uint4(0, 0, 0, 0);
+    r.q4 = *reinterpret_cast<const uint4*>(r.qp);
     r.k4 = *reinterpret_cast<const uint4*>(r.kp);
     r.v4 = *reinterpret_cast<const uint4*>(r.vp);
     return r;
 }
 
-template <int DH, bool WITH_Q = true>
+template <int DH>
 __device__ __forceinline__ uint4 rope_kv_finish(const ContextAttnParams& p, int s, int h, int b, int li, const RopeRow& r)
 {
     constexpr int LPR = DH / 8;
@@ -152,8 +150,7 @@ __device__ __forceinline__ uint4 rope_kv_finish(const ContextAttnParams& p, int 
     }
     if (has_row)
     {
-        if (WITH_Q)
-            *reinterpret_cast<uint4*>(qp) = q4;
+        *reinterpret_cast<uint4*>(qp) = q4;
         *reinterpret_cast<uint4*>(kp) = k4;
         if (!valid)
             *reinterpret_cast<uint4*>(vp) = v4;
@@ -227,7 +224,7 @@ __global__ __launch_bounds__(256) void rope_kv_vt_kernel(const ContextAttnParams
     for (int pass = 0; pass < NP; ++pass) // every row's q / k / v requested before the first one is touched
     {
         const int s = kv0 + pass * RPP + threadIdx.x / LPR;
-        rr[pass] = rope_kv_load<DH, false>(p, s < p.seq ? s : p.seq - 1, h, b, li);
+        rr[pass] = rope_kv_load<DH>(p, s < p.seq ? s : p.seq - 1, h, b, li);
     }
 #pragma unroll
     for (int pass = 0; pass < NP; ++pass)
@@ -235,7 +232,7 @@ __global__ __launch_bounds__(256) void rope_kv_vt_kernel(const ContextAttnParams
         const int key = pass * RPP + threadIdx.x / LPR, s = kv0 + key;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (s < p.seq) // group-uniform
-            v = rope_kv_finish<DH, false>(p, s, h, b, li, rr[pass]);
+            v = rope_kv_finish<DH>(p, s, h, b, li, rr[pass]);
         uint32_t* d = reinterpret_cast<uint32_t*>(tile + key * PITCH + li * 8);
         d[0] = v.x;
         d[1] = v.y;
@@ -456,58 +453,6 @@ __global__ __launch_bounds__(128 * NQ) void context_attn_mfma_ks_kernel(const Co
 #pragma unroll
         for (int s = 0; s < KST; ++s)
             qf[s] = *reinterpret_cast<const uint4*>(qrow + (16 * s + 8 * hf) * 2);
-        // RoPE of the query, here instead of in the RoPE / KV-write launch (r05): the lane holds elements 16 s + 8 half + j, so the
-        // NeoX partner (d +- DH / 2) is k-step s +- KST / 2 of the SAME lane and the GPT-J partner (d ^ 1) the neighbouring element.
-        // Same expression and rounding as rope_kv_finish (fp32, one rounding to fp16: ...Utils.h:1517-1531)
-        if (p.rotary_dim > 0) // uniform
-        {
-            const int half = p.rotary_dim >> 1;
-            const int qpos = q < nrows ? q : nrows - 1;
-            const int pos = qpos < p.rope_table_len ? qpos : p.rope_table_len - 1;
-            const float2* tab = reinterpret_cast<const float2*>(p.rope_table) + (int64_t) pos * half;
-            if (p.neox) // (rotary_dim == DH: checked by the launcher)
-            {
-#pragma unroll
-                for (int s = 0; s < KST / 2; ++s)
-                {
-                    float a[8], b2[8];
-                    h8_to_f(qf[s], a);
-                    h8_to_f(qf[s + KST / 2], b2);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                    {
-                        const float2 cs = tab[16 * s + 8 * hf + j];
-                        const float x = a[j], y = b2[j];
-                        a[j] = cs.x * x + (-cs.y) * y;
-                        b2[j] = cs.x * y + cs.y * x;
-                    }
-                    qf[s] = f_to_h8(a);
-                    qf[s + KST / 2] = f_to_h8(b2);
-                }
-            }
-            else
-            {
-#pragma unroll
-                for (int s = 0; s < KST; ++s)
-                {
-                    float a[8];
-                    h8_to_f(qf[s], a);
-#pragma unroll
-                    for (int j = 0; j < 8; j += 2)
-                    {
-                        const int d = 16 * s + 8 * hf + j;
-                        if (d < p.rotary_dim)
-                        {
-                            const float2 cs = tab[d >> 1];
-                            const float q0 = a[j], q1 = a[j + 1];
-                            a[j] = cs.x * q0 - cs.y * q1;
-                            a[j + 1] = cs.x * q1 + cs.y * q0;
-                        }
-                    }
-                    qf[s] = f_to_h8(a);
-                }
-            }
-        }
     }
 
     bool valid = true; // this wave's slice exists (PAIR: wave-uniform; else block-uniform and handled by the return below)
