@@ -249,3 +249,45 @@ def test_weight_only_int8_fused_launch_equals_the_two_launches(S, pad, int8_kv):
         ca, cb = a['cache'][0].view(np.float16).astype(np.float32), b['cache'][0].view(np.float16).astype(np.float32)
         bad = ca != cb
         assert bad.mean() < 1e-5 and np.all(np.abs(ca - cb)[bad] <= 2.0 ** -10 * np.maximum(np.abs(ca[bad]), 2.0 ** -14) * 1.01), bad.sum()
+
+
+@pytest.mark.parametrize('S,pad,int8_kv', [(3, 0, 1), (40, 9, 1), (1100, 0, 1), (4000, 0, 1), (300, 5, 0)])
+def test_weight_only_o_projection_stage_equals_the_gemv_launch(S, pad, int8_kv):
+    """The O-projection stage on weight-only int8 weights (the context row travels as fp16, two elements per granule) against the
+    GEMV launch it replaces (gemv_kernel<W_INT8_WOQ, PK_NONE, EK_RESIDUAL>): the row workers restate that kernel's arithmetic AND
+    order - raw byte splices, per-lane runs over the four 1 KiB chunks of a row, the cross-lane sum, 1152 * sum(ctx) in the
+    prologue's association - so everything behind it is identical: logits of every step, tokens, every cache byte."""
+    layers, NEW = 2, 7
+    cfg, w, qm = woq_weights(layers, int8_kv)
+    max_in = S + pad
+    r = np.random.default_rng(400 + S)
+    ids = np.full((1, max_in), 2, np.int32)
+    ids[0, :S] = r.integers(3, cfg['vocab_size'], S)
+    lens = np.array([S], np.int32)
+    D = cfg['hidden_size']
+    out = {}
+    for fuse_o in (0, 1):
+        s = make(cfg, w, qm, 1, fuse_o=fuse_o)
+        s.setup(1, max_in, NEW)
+        s.context(ids, lens)
+        rec = dict(o_in=[], mlp_in=[], logits=[s.logits()])
+        for i in range(NEW - 1):
+            s.step(1, use_graph=i >= 2)
+            rec['o_in'].append(np.stack([s.attention_tap(li, D, quantised=False)[0] for li in range(layers)]))
+            rec['mlp_in'].append(np.stack([s.tap(li, 'mlp_in', D, quantised=False)[0] for li in range(layers)]))
+            rec['logits'].append(s.logits())
+        rec['tokens'] = s.output_ids()
+        nbytes = 2 * cfg['num_heads'] * (max_in + NEW) * (D // cfg['num_heads']) * (1 if int8_kv else 2)
+        rec['cache'] = [read_cache(s, li, nbytes) for li in range(layers)]
+        out[fuse_o] = rec
+        s.close()
+    a, b = out[0], out[1]
+    for i in range(NEW - 1):
+        np.testing.assert_array_equal(a['o_in'][i], b['o_in'][i])
+        np.testing.assert_array_equal(a['mlp_in'][i], b['mlp_in'][i])
+    for i in range(NEW):
+        np.testing.assert_array_equal(a['logits'][i], b['logits'][i])
+    np.testing.assert_array_equal(a['tokens'], b['tokens'])
+    for li in range(layers):
+        np.testing.assert_array_equal(a['cache'][li], b['cache'][li])
+    assert np.abs(a['logits'][-1]).max() > 0

@@ -222,7 +222,7 @@ struct FusedQkvAttnParams
     const void* o_w = nullptr;             // s8 [o_n, o_ldw]: rows of the dense projection, K = num_heads * head_size
     int64_t o_ldw = 0;                     // bytes
     int32_t o_n = 0, o_per_channel = 0;
-    const float* o_scale_col = nullptr;    // f32 [o_n] (per_channel) or [1]
+    const void* o_scale_col = nullptr;     // SmoothQuant: f32 [o_n] (per_channel) or [1]; weight-only: fp16 [o_n]
     const float* o_scale_row = nullptr;    // f32 [1]: the static activation scale of the dequantisation
     void* x_out = nullptr;                 // fp16 [o_n]: may be x itself (every workgroup has consumed x long before)
 };

@@ -40,6 +40,7 @@
 #include "kernels.h"
 #include <atomic>
 #include <math.h>
+#include <type_traits>
 
 namespace tllm
 {
@@ -59,6 +60,7 @@ constexpr int kKChunks = 4;    // K = 4096 int8 = 4 x 1 KiB per weight row
 constexpr int kPartStride = 136; // granules per published partial: o[128], m, l (+ pad)
 constexpr int kHeadGranules = 3 * 64 + kMembers * kPartStride;
 constexpr int kCtxGranules = kDH / 4; // the head's context row as its int8 image, four elements per granule (O-projection stage)
+constexpr int kCtxGranulesH = kDH / 2; // ... as fp16, two elements per granule (weight-only engines)
 constexpr int kORowsMax = 24;         // dense-projection rows a row-worker workgroup takes at most (3 per wave)
 
 __device__ __forceinline__ void st_granule(gu64* g, uint32_t tag, uint32_t value)
@@ -229,10 +231,13 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     {
         const int row = o_r0 + wid + 8 * i;
         const bool on = row < o_r1; // wave-uniform
-        o_cs[i] = on ? p.o_scale_col[p.o_per_channel ? row : 0] : 0.f;
+        if constexpr (WOQ)
+            o_cs[i] = on ? h2f(reinterpret_cast<const uint16_t*>(p.o_scale_col)[row]) : 0.f;
+        else
+            o_cs[i] = on ? reinterpret_cast<const float*>(p.o_scale_col)[p.o_per_channel ? row : 0] : 0.f;
         o_res[i] = on ? h2f(reinterpret_cast<const uint16_t*>(p.x)[row]) : 0.f;
     }
-    if (o_stage)
+    if (o_stage && !WOQ)
         o_rs = p.o_scale_row[0];
     // launch constants, requested before anything else (and before the kernel's first store: behind one hipcc no longer uses the
     // scalar path for them, and as vector loads behind the q rows they held the prologue until the q rows had arrived)
@@ -701,14 +706,25 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             return;
         // -------------------------------------------------------------- 7. row workers: x_out[n] = x[n] + O(ctx)[n]
         TLLM_STAMP(8);
-        // every head's context row (int8, 4 elements per granule): 1024 granules, two per thread, behind the DMA in the queue
+        // every head's context row - int8, four elements per granule: 1024 granules, two per thread; weight-only: fp16, two per
+        // granule: 2048, four per thread - behind the DMA in the queue
         {
-            const gu64* g0 = gc + tid;
-            const gu64* g1 = gc + 512 + tid;
-            unsigned long long a = ld_granule(g0), b = ld_granule(g1);
+            constexpr int NG = WOQ ? 4 : 2;
+            const gu64* gbase = gc + tid;
+            unsigned long long g[NG];
             int spins = 0;
-            while (!__all((uint32_t) (a >> 32) == tag && (uint32_t) (b >> 32) == tag))
+            for (;;)
             {
+#pragma unroll
+                for (int i = 0; i < NG; ++i)
+                    g[i] = ld_granule(gbase + 512 * i);
+                __builtin_amdgcn_sched_barrier(0);
+                uint32_t bad = 0;
+#pragma unroll
+                for (int i = 0; i < NG; ++i)
+                    bad |= (uint32_t) (g[i] >> 32) ^ tag;
+                if (__all(bad == 0))
+                    break;
                 if (++spins > p.max_spins)
                 {
                     if (lane == 0)
@@ -716,11 +732,10 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
                     break;
                 }
                 __builtin_amdgcn_s_sleep(1);
-                a = ld_granule(g0);
-                b = ld_granule(g1);
             }
-            reinterpret_cast<uint32_t*>(xs)[tid] = (uint32_t) a;
-            reinterpret_cast<uint32_t*>(xs)[512 + tid] = (uint32_t) b;
+#pragma unroll
+            for (int i = 0; i < NG; ++i)
+                reinterpret_cast<uint32_t*>(xs)[tid + 512 * i] = (uint32_t) g[i];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the rows this wave requested are in LDS
         __syncthreads();                                  // ... everybody's are, and so is the context row
@@ -731,37 +746,79 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
                 atomicOr(p.error, 4u);
             return;
         }
+        float obias = 0.f;
+        if constexpr (WOQ)
+        {
+            // the splice bias 1152 * sum(ctx) in the unfused GEMV's order (thread t < 256 owns vectors t and t + 256 of the row)
+            if (wid < 4)
+            {
+                const uint4 va = *reinterpret_cast<const uint4*>(xs + tid * 16);
+                const uint4 vb = *reinterpret_cast<const uint4*>(xs + (tid + 256) * 16);
+                const uint32_t xv[2][4] = {{va.x, va.y, va.z, va.w}, {vb.x, vb.y, vb.z, vb.w}};
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                    {
+                        const h2_t hh = u32_as_h2(xv[j][q]);
+                        if (q & 1)
+                            sb += (float) hh.x + (float) hh.y;
+                        else
+                            sa += (float) hh.x + (float) hh.y;
+                    }
+                const float bsum = wave_sum(1152.f * (sa + sb));
+                if (lane == 0)
+                    red[8 + wid] = bsum;
+            }
+            __syncthreads();
+            obias = red[8] + red[9] + red[10] + red[11];
+        }
         // rows r0 + wid, + 8, + 16 of the worker (any wave reads any row: the barrier above is behind every wave's vmcnt(0)); the
         // three dot products and their cross-lane sums side by side
-        int acc[3] = {0, 0, 0};
+        using oacc_t = typename std::conditional<WOQ, float, int>::type;
+        oacc_t acc[3] = {0, 0, 0};
 #pragma unroll
         for (int u = 0; u < kKChunks; ++u)
         {
-            const uint4 xr = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * 16);
+            uint4 xr, xr2;
+            if constexpr (WOQ)
+            {
+                xr = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * 32);
+                xr2 = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * 32 + 16);
+            }
+            else
+                xr = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * 16);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
             {
                 const int slot = wid + 8 * i < o_r1 - o_r0 ? wid + 8 * i : 0; // (a row that does not exist: slot 0, result dropped)
                 const uint4 wv = *reinterpret_cast<const uint4*>(wo_lds + (slot * kKChunks + u) * 1024 + lane * 16);
-                acc[i] = sdot4(wv.x, xr.x, acc[i]);
-                acc[i] = sdot4(wv.y, xr.y, acc[i]);
-                acc[i] = sdot4(wv.z, xr.z, acc[i]);
-                acc[i] = sdot4(wv.w, xr.w, acc[i]);
+                if constexpr (WOQ)
+                    acc[i] = dot_woq8_raw(wv, xr, xr2, acc[i]);
+                else
+                {
+                    acc[i] = sdot4(wv.x, xr.x, acc[i]);
+                    acc[i] = sdot4(wv.y, xr.y, acc[i]);
+                    acc[i] = sdot4(wv.z, xr.z, acc[i]);
+                    acc[i] = sdot4(wv.w, xr.w, acc[i]);
+                }
             }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
             acc[i] = wave_sum(acc[i]);
         // epilogue of the unfused GEMV (gemv_impl.h, EPI_RESIDUAL): fp16(fp16(float(acc) * (scale_col * scale_row)) + residual)
+        // (weight-only: (sum - bias) * scale, scale_row = 1)
         if (lane < 3)
         {
             const int i = lane;
             const int row = o_r0 + wid + 8 * i;
-            const int a = i == 0 ? acc[0] : (i == 1 ? acc[1] : acc[2]);
+            const float a = (float) (i == 0 ? acc[0] : (i == 1 ? acc[1] : acc[2])) - obias;
             const float cs_i = i == 0 ? o_cs[0] : (i == 1 ? o_cs[1] : o_cs[2]);
             const float rs_i = i == 0 ? o_res[0] : (i == 1 ? o_res[1] : o_res[2]);
             if (row < o_r1)
-                reinterpret_cast<uint16_t*>(p.x_out)[row] = f2h(h2f(f2h((float) a * (cs_i * o_rs))) + rs_i);
+                reinterpret_cast<uint16_t*>(p.x_out)[row] = f2h(h2f(f2h(a * (cs_i * o_rs))) + rs_i);
         }
         TLLM_STAMP(10);
         return;
@@ -869,6 +926,8 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             reinterpret_cast<int8_t*>(p.out_q8)[oi] = q8;
             reinterpret_cast<int8_t*>(red)[d] = q8; // (the prologue's scratch: free since the first barrier)
         }
+        if constexpr (WOQ)
+            reinterpret_cast<uint16_t*>(red)[d] = h16; // weight-only: the row travels as fp16
     }
     else if (tid < kDH + 16)
     {
@@ -910,8 +969,9 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     if (o_stage) // uniform: the context row to the row workers, four int8 per granule
     {
         __syncthreads(); // F
-        if (tid < kCtxGranules)
-            st_granule(gc + h * kCtxGranules + tid, tag, reinterpret_cast<const uint32_t*>(red)[tid]);
+        constexpr int CG = WOQ ? kCtxGranulesH : kCtxGranules;
+        if (tid < CG)
+            st_granule(gc + h * CG + tid, tag, reinterpret_cast<const uint32_t*>(red)[tid]);
     }
     TLLM_STAMP(7);
 }
@@ -974,7 +1034,7 @@ int pick_nit(int max_seq_len, bool int8_kv)
 
 size_t qkv_attn_fused_xchg_bytes(int32_t num_heads)
 {
-    return (size_t) num_heads * (kHeadGranules + kCtxGranules) * sizeof(uint64_t);
+    return (size_t) num_heads * (kHeadGranules + kCtxGranulesH) * sizeof(uint64_t);
 }
 
 // the O-projection stage: K = H * Dh = 4 KiB rows (the context row is swept by 512 threads x two granules), every row worker's
@@ -1019,7 +1079,7 @@ int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream)
         return -1;
     }
     if (p.o_w
-        && (!p.out_q8 || !p.o_scale_col || !p.o_scale_row || !p.x_out
+        && ((!p.woq8 && (!p.out_q8 || !p.o_scale_row)) || !p.o_scale_col || !p.x_out
             || !qkv_attn_fused_serves_o(p.num_heads, p.head_size, p.o_n, p.num_heads * p.head_size, p.o_ldw)))
     {
         set_error("fused QKV + attention: the O-projection stage needs the static int8 context row and a dense projection of %d x %d",
@@ -1029,9 +1089,9 @@ int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream)
     const int nit = pick_nit(p.max_seq_len, p.int8_kv != 0);
     if (p.woq8)
     {
-        if (p.o_w || p.out_q8 || p.act_quant_scale)
+        if (p.out_q8 || p.act_quant_scale)
         {
-            set_error("fused QKV + attention: the weight-only form has no quantiser and no O-projection stage");
+            set_error("fused QKV + attention: the weight-only form has no quantiser");
             return -1;
         }
         return p.int8_kv ? launch_i8<true, true>(p, nit, stream) : launch_i8<false, true>(p, nit, stream);

@@ -946,7 +946,7 @@ struct tllm_session
                         f.o_ldw = L.dense.ldw;
                         f.o_n = L.dense.N;
                         f.o_per_channel = L.dense.per_channel;
-                        f.o_scale_col = static_cast<const float*>(L.dense.scale_col);
+                        f.o_scale_col = L.dense.scale_col;
                         f.o_scale_row = L.dense.act_scale;
                         f.x_out = x;
                     }
@@ -1021,7 +1021,8 @@ struct tllm_session
             {
                 // K4 ran as the third stage of the fused launch: x already holds x + O(ctx)
                 if (taps)
-                    HIP_OK(hipMemcpyAsync(tap_ptr(1, li), ctx_q8, (size_t) B * Dr, hipMemcpyDeviceToDevice, st));
+                    HIP_OK(hipMemcpyAsync(tap_ptr(1, li), sq ? (const void*) ctx_q8 : ctx, (size_t) B * Dr * (sq ? 1 : 2), hipMemcpyDeviceToDevice,
+                        st));
             }
             else if (ok < 0 || ok == 4)
             {
@@ -1627,9 +1628,11 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
             RUN(s->dalloc(&s->fused_xchg, xb));
             HIP_OK(hipMemset(s->fused_xchg, 0, xb));
             s->qkv_attn_fused = true;
-            s->o_fused = s->fuse_o_cfg != 0 && s->sq && !s->per_token; // (tp == 1 here: no all-reduce behind the projection)
+            // (tp == 1 here: no all-reduce behind the projection.  Weight-only int8: the context row travels as fp16)
+            s->o_fused = s->fuse_o_cfg != 0 && (s->sq ? !s->per_token : true);
             for (auto& L : s->layers)
-                s->o_fused = s->o_fused && L.dense.wtype == W_INT8_SQ && L.dense.N == D && L.dense.act_scale && L.attn_qscale
+                s->o_fused = s->o_fused && L.dense.N == D && L.dense.scale_col
+                    && (s->sq ? (L.dense.wtype == W_INT8_SQ && L.dense.act_scale && L.attn_qscale) : L.dense.wtype == W_INT8_WOQ)
                     && qkv_attn_fused_serves_o(s->Hr, s->Dh, L.dense.N, L.dense.K, L.dense.ldw);
             s->fused_timing = nullptr;
             if (s->fused_timeline)
