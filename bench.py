@@ -11,8 +11,9 @@ A "step" is one generation step (one new token for the whole batch) through all 
 sampler, replayed from the captured hipGraph with the KV cache holding `context` tokens (+ the tokens generated so
 far).  Weights are synthetic (seeded random of the LLaMA-7B architecture, generated on the GPU in the storage format
 of the chosen config); inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line with
-`roofline` (dominant kernel = the layer GEMV, HBM-bound) and `cpu_baseline` (HF transformers LLaMA on the host CPU,
-the reference's run_hf.py path, bounded sample) objects.
+`roofline` (the launch that takes most of the step, picked at run time as max(calls x average duration) over the launches the
+step is made of - all of them are listed in `roofline.kernels`; HBM-bound) and `cpu_baseline` (HF transformers LLaMA on the host
+CPU, the reference's run_hf.py path, bounded sample) objects.
 """
 import argparse
 import json
@@ -44,6 +45,10 @@ def parse():
                     help='A/B: QKV projection and attention as two launches (session key fuse_qkv_attention = 0)')
     ap.add_argument('--gemv-o-projection', action='store_true',
                     help='A/B: the O-projection as a GEMV launch of its own (session key fuse_o_projection = 0)')
+    ap.add_argument('--gemv-gate-up', action='store_true',
+                    help='A/B: RMSNorm + gate|up + SwiGLU as a GEMV launch of its own (session key fuse_mlp_front = 0)')
+    ap.add_argument('--mlp-delay', type=int, default=-1,
+                    help='tuning: ticks of 10 ns a gate|up workgroup of the fused launch waits before it requests weights (session key fused_mlp_delay)')
     ap.add_argument('--no-prefill', dest='prefill', action='store_false', help='skip the prefill (TTFT) and SQ-GEMM MFMA reports')
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
     ap.add_argument('--no-batch-sweep', dest='batch_sweep', action='store_false',
@@ -113,13 +118,90 @@ def synth_weights(torch, cfg, mode, int8_kv, tp, rank, dev):
     return t
 
 
+def _fused_nit(smax, int8_kv):
+    """cache rows per lane group of the one-launch projection + attention (qkv_attn_fused.hip pick_nit): names the instance"""
+    ngrp = 8 * (8 if int8_kv else 4)
+    need = -(-smax // (8 * ngrp))
+    for n in (1, 2, 3, 4, 6, 8):
+        if need <= n:
+            return n
+    return 0
+
+
+def step_launches(cfg, mode, world, form, l_mean, int8_kv, smax):
+    """The launches one generation step is made of, as this session runs it (tllm_session_decode_form), each with its kernel
+    name as rocprofv3 prints it, its launches per step and its ALGORITHMIC HBM bytes per launch (weights +
+    per-channel scales + KV read at the mean context of the timed steps + the activation rows in and out)."""
+    D, H, L = cfg['hidden_size'], cfg['num_heads'], cfg['num_layers']
+    Dh = D // H
+    Dr, Ir, Hr = D // world, cfg['inter_size'] // world, H // world
+    Vr = (cfg['vocab_size'] + world - 1) // world
+    wb = {'sq': 1.0, 'woq8': 1.0, 'woq4': 0.5, 'fp16': 2.0}[mode]
+    sb = {'sq': 4, 'woq8': 2, 'woq4': 2, 'fp16': 0}[mode]  # per-output-channel scale
+    wt = {'sq': 3, 'woq8': 1, 'woq4': 2, 'fp16': 0}[mode]
+    e = 1 if int8_kv else 2
+    row = D * 2  # one fp16 activation row
+    qkv = 3 * Dr * D * wb + 3 * Dr * sb + 2 * row + 3 * Dr * 2
+    kv = 2 * Hr * Dh * l_mean * e + 2 * Hr * Dh * e
+    o = D * Dr * wb + D * sb + Dr * (1 if mode == 'sq' else 2) + 2 * row
+    gate_up = 2 * Ir * D * wb + 2 * Ir * sb + 2 * row + Ir * (1 if mode == 'sq' else 2)
+    down = D * Ir * wb + D * sb + Ir * (1 if mode == 'sq' else 2) + 2 * row
+    head = Vr * D * 2 + 2 * row + Vr * 4
+    out = []
+    if form & 1:
+        nit = _fused_nit(smax, int8_kv)
+        name = 'qkv_attn_fused_kernel<%d, %s, %s>' % (nit, 'true' if int8_kv else 'false', 'true' if mode == 'woq8' else 'false')
+        b, what = qkv + kv - 3 * Dr * 2, 'RMSNorm -> QKV GEMV -> RoPE -> cache append -> attention'
+        if form & 2:
+            b, what = b + o - Dr * (1 if mode == 'sq' else 2), what + ' -> O-projection + residual'
+        if form & 4:
+            b, what = b + gate_up - row, what + ' | RMSNorm -> gate|up GEMV -> SwiGLU'
+        out.append(dict(key='front', id=7, kernel=name, what=what, bytes=b, calls=L, match=['qkv_attn_fused_kernel']))
+    else:
+        out.append(dict(key='qkv', id=1, kernel='gemv_kernel<%d, 1, 0, 1, 2, 4>' % wt, what='RMSNorm -> QKV GEMV', bytes=qkv, calls=L,
+                        match=['gemv_kernel<%d, 1, 0' % wt]))
+        out.append(dict(key='attention', id=2, kernel='mmha_partial_kernel', what='RoPE -> cache append -> split attention + merge',
+                        bytes=kv + 3 * Dr * 2, calls=L, match=['mmha_']))
+    if not form & 2:
+        out.append(dict(key='o_proj', id=4, kernel='gemv (O-projection + residual)', what='O-projection + residual', bytes=o, calls=L,
+                        match=['gemv_ksplit_kernel', 'gemv_kernel<%d, 0, 0' % wt, 'gemv_kernel<%d, 2, 0' % wt]))
+    if not form & 4:
+        out.append(dict(key='gate_up', id=5, kernel='gemv_kernel<%d, 1, 1, 1, 2, 4>' % wt, what='RMSNorm -> gate|up GEMV -> SwiGLU',
+                        bytes=gate_up, calls=L, match=['gemv_kernel<%d, 1, 1' % wt]))
+    out.append(dict(key='down', id=6, kernel='gemv_ksplit_kernel<3, 3>' if mode == 'sq' else 'gemv (down projection + residual)',
+                    what='down projection + residual', bytes=down, calls=L,
+                    match=['gemv_ksplit_kernel', 'gemv_kernel<%d, 0, 0' % wt, 'gemv_kernel<%d, 2, 0' % wt]))
+    out.append(dict(key='head', id=None, kernel='gemv_kernel<0, 1, 0, ...> (ln_f -> lm_head, fp32 logits)', what='final RMSNorm -> lm_head GEMV',
+                    bytes=head, calls=1, match=['gemv_kernel<0, 1, 0']))
+    return out
+
+
+def pmc_traffic(launch, rows):
+    """HBM bytes per launch of this kernel from the committed rocprofv3 --pmc summary (FETCH_SIZE x 2 + WRITE_SIZE): among the
+    rows whose name matches, the one whose volume is nearest to the algorithmic bytes (several shapes share a template instance)."""
+    import math
+    best = None
+    for r in rows:
+        if not any(m in r['kernel'] for m in launch['match']):
+            continue
+        t = r['fetch_bytes'] + r['write_bytes']
+        if t <= 0:
+            continue
+        d = abs(math.log(t / launch['bytes']))
+        if d < math.log(1.6) and (best is None or d < best[0]):
+            best = (d, t, r['kernel'])
+    return (best[1], best[2]) if best else (None, None)
+
+
 def run_config(torch, dist, args, mode, rank, world, dev):
     from tensorrt_llm.runtime.native import NativeSession
     cfg = dict(LLAMA_7B, num_layers=args.layers)
     int8_kv = mode != 'fp16'  # BASELINE.json configs: fp16 + fp16 KV; every int8 config with int8 KV
     qm = QM[mode] | (INT8_KV if int8_kv else 0)
     sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=world, tp_rank=rank, fuse_qkv_attention=0 if args.two_launch_attention else -1,
-                              fuse_o_projection=0 if getattr(args, 'gemv_o_projection', False) else -1))
+                              fuse_o_projection=0 if getattr(args, 'gemv_o_projection', False) else -1,
+                              fuse_mlp_front=0 if getattr(args, 'gemv_gate_up', False) else -1,
+                              fused_mlp_delay=getattr(args, 'mlp_delay', -1)))
     weights = synth_weights(torch, cfg, mode, int8_kv, world, rank, dev)
     for k, v in weights.items():
         sess.set_tensor(k, v)
@@ -172,22 +254,20 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     step_bytes = sess.step_bytes(int(round(l_mean)))
     res = dict(graph=use_graph, mode=mode, wall_s=wall, dev_ms=dev_ms, ms_per_step=wall * 1e3 / K, tokens_per_s=K / wall, finite=finite,
                step_bytes=step_bytes, mean_context=l_mean)
-    # instrumented pass for the roofline of the dominant kernel (layer GEMVs) — rank 0 reports
+    # instrumented pass (eager, an event pair around every launch): the head GEMV's and the sampler's time, the collectives
     prof = sess.profile(8, stream=stream)
     res['profile'] = prof
-    # algorithmic bytes of the layer GEMVs per step = step bytes - lm_head - KV traffic
-    sess_b0 = sess.step_bytes(0)
-    kv_row = sess.step_bytes(1) - sess_b0
-    head_bytes = ((cfg['vocab_size'] + world - 1) // world) * cfg['hidden_size'] * 2
-    res['gemv_layer_bytes_per_step'] = sess_b0 - kv_row - head_bytes
-    # live timing of each per-layer kernel (one HIP event pair around 4 x 32 back-to-back launches, every launch on
-    # its own layer's weights = cold HBM as in a real step); the roofline is quoted on the dominant one (gate|up)
-    res['kernel_us'] = {k: sess.time_kernel(k, 4, stream=stream)[0] for k in NativeSession.LAYER_KERNELS}
-    D, Ir = cfg['hidden_size'], cfg['inter_size'] // world
-    wbytes = {'sq': 1.0, 'woq8': 1.0, 'woq4': 0.5, 'fp16': 2.0}[mode]
-    sbytes = {'sq': 4, 'woq8': 2, 'woq4': 2, 'fp16': 0}[mode]  # per-output-channel scale
-    # gate|up GEMV, algorithmic HBM bytes per launch: both weight matrices + their scales + x + gamma + the output row
-    res['gate_up_bytes'] = 2 * Ir * D * wbytes + 2 * Ir * sbytes + D * 2 + D * 2 + Ir * (1 if mode == 'sq' else 2)
+    # live timing of every launch the step is made of (one HIP event pair around 4 x 32 back-to-back launches, every launch on
+    # its own layer's weights = cold HBM as in a real step) next to its algorithmic HBM bytes
+    form = sess.decode_form()
+    res['decode_form'] = form
+    res['launches'] = step_launches(cfg, mode, world, form, l_mean, int8_kv, args.context + 2 * K + W + 4)
+    for ln in res['launches']:
+        if ln['id'] is not None:
+            ln['avg_us'] = sess.time_kernel(ln['key'], 4, stream=stream)[0]
+        else:  # the head GEMV: one launch per step, from the instrumented pass
+            ln['avg_us'] = prof['gemv_head'][0] * 1e3 / max(prof['gemv_head'][1], 1)
+    res['kernel_us'] = {ln['key']: ln['avg_us'] for ln in res['launches']}
     # time-to-first-token: the real context phase (MFMA GEMMs + flash attention + KV write) on a random 1024-token
     # prompt - reported beside the decode metric, not part of it
     if args.prefill and mode == args.config:
@@ -551,22 +631,28 @@ def main():
 
     prof = res['profile']
     prof_steps = 8
-    avg_dur_s = res['kernel_us']['gate_up'] * 1e-6
-    bytes_per_launch = res['gate_up_bytes']
-    achieved = bytes_per_launch / avg_dur_s / 1e9 if avg_dur_s > 0 else 0.0
-    # PMC counters cannot be read from inside the timed run: `traffic` is the committed rocprofv3 measurement of this same
+    # PMC counters cannot be read from inside the timed run: `traffic` is the committed rocprofv3 measurement of the same
     # kernel / shape (tools/refresh_pmc.sh -> profiles/*_pmc_summary.json), named in `traffic_source` - not this run's
-    traffic = traffic_source = None
-    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+    pmc_rows, traffic_source = [], None
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
         pmc = os.path.join(ROOT, 'profiles', f'{rnd}_pmc_summary.json')
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.config, {}).get('gate_up_hbm_bytes_per_launch')
+                pmc_rows = json.load(open(pmc)).get(args.config, {}).get('kernels') or []
             except Exception:
-                traffic = None
-            if traffic is not None:
-                traffic_source = f'profiles/{rnd}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run)'
+                pmc_rows = []
+            if pmc_rows:
+                traffic_source = f'profiles/{rnd}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE passes, not this run)'
                 break
+    kernels = []
+    for ln in res['launches']:
+        us = ln['avg_us']
+        gbs = ln['bytes'] / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        tr, tr_kernel = pmc_traffic(ln, pmc_rows)
+        kernels.append({'kernel': ln['kernel'], 'what': ln['what'], 'launches_per_step': ln['calls'], 'avg_launch_us': us,
+                        'us_per_step': us * ln['calls'], 'bytes_per_launch': ln['bytes'], 'achieved': gbs, 'frac': gbs / HBM_PEAK_GBS,
+                        'traffic': tr, 'traffic_kernel': tr_kernel})
+    dom = max(kernels, key=lambda k: k['us_per_step'])  # the dominant launch of THIS run: max(calls x average duration)
     cpu = None
     parity = cpu_model = cpu_info = None
     if world == 1 and args.parity and args.config == 'sq':
@@ -625,28 +711,23 @@ def main():
                    'comm_us_per_step': (prof['comm'][0] * 1e3 / prof_steps) if world > 1 else 0.0,
                    'comm_launches_per_step': (prof['comm'][1] / prof_steps) if world > 1 else 0,
                    'step_launch': 'hipGraph replay' if res.get('graph', True) else 'eager (graph capture failed)'},
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
-                     # name as rocprofv3 prints it: gemv_kernel<WT, PK_NORM = 1, EK_SWIGLU = 1, MB = 1, NXV = 2, U = 4>
-                     'kernel': 'gemv_kernel<%d, 1, 1, 1, 2, 4> (RMSNorm -> gate|up GEMV -> SwiGLU; 25-30 %% of a step)'
-                               % {'sq': 3, 'woq8': 1, 'woq4': 2, 'fp16': 0}[args.config],
-                     'bytes_per_launch': bytes_per_launch, 'avg_launch_us': avg_dur_s * 1e6},
+        'roofline': {'bound': 'hbm', 'achieved': dom['achieved'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': dom['frac'],
+                     'traffic': dom['traffic'], 'traffic_source': traffic_source if dom['traffic'] is not None else None,
+                     # name as rocprofv3 prints it; the dominant launch = max(launches x average duration) over `kernels`
+                     'kernel': '%s (%s; %.0f %% of the step\'s launches)'
+                               % (dom['kernel'], dom['what'], 100.0 * dom['us_per_step'] / max(sum(k['us_per_step'] for k in kernels), 1e-9)),
+                     'bytes_per_launch': dom['bytes_per_launch'], 'avg_launch_us': dom['avg_launch_us'],
+                     'kernels': kernels},
         'cpu_baseline': cpu,
         'step': {'hbm_bytes': res['step_bytes'], 'hbm_frac_of_peak': res['step_bytes'] / (res['ms_per_step'] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  'device_ms_per_step': res['dev_ms'] / args.steps, 'outputs_finite': res['finite'],
-                 'layer_kernel_us': res['kernel_us'],
-                 # batch-1 SmoothQuant decode runs the QKV projection, RoPE, the cache append and the attention in ONE launch
-                 # (kernels/qkv_attn_fused.hip): its time is the 'qkv' entry, 'attention' is then an empty slot
-                 'qkv_and_attention_in_one_launch': bool(res['kernel_us'].get('attention', 1.0) < 1.0
-                                                         and not getattr(args, 'two_launch_attention', False)),
-                 # ... and (static SmoothQuant scales, r05) the O-projection + residual as that launch's third stage: the 'o_proj'
-                 # entry of layer_kernel_us is then the GEMV launch it REPLACES, timed alone (the A/B is --gemv-o-projection)
-                 'o_projection_in_the_attention_launch': bool(args.config == 'sq' and world == 1
-                                                              and res['kernel_us'].get('attention', 1.0) < 1.0
-                                                              and not getattr(args, 'two_launch_attention', False)
-                                                              and not getattr(args, 'gemv_o_projection', False)),
+                 # the launches one layer is made of in this run, timed one by one (the same numbers as roofline.kernels)
+                 'layer_kernel_us': {k: v for k, v in res['kernel_us'].items() if k != 'head'},
+                 'decode_form': {'qkv_and_attention_in_one_launch': bool(res['decode_form'] & 1),
+                                 'o_projection_in_that_launch': bool(res['decode_form'] & 2),
+                                 'gate_up_in_that_launch': bool(res['decode_form'] & 4)},
                  # the layer as the graph replay runs it: (device time per step - the head GEMV - the sampler, both from the eager
-                 # profile below) / layers.  layer_kernel_us above times the launches ONE BY ONE in their two-stage form
+                 # profile below) / layers.  layer_kernel_us above times the launches ONE BY ONE
                  'layer_us_in_graph_replay': (res['dev_ms'] / args.steps - (prof['gemv_head'][0] + prof['other'][0]) / prof_steps) * 1e3 / args.layers,
                  'profile_ms_per_step': {k: v[0] / prof_steps for k, v in prof.items()},
                  'launches_per_step': {k: v[1] / prof_steps for k, v in prof.items()}},

@@ -162,14 +162,25 @@ int32_t tllm_session_get_tap_ex(tllm_session_t s, int32_t layer, int32_t which, 
  * algorithmic-bytes model of SURVEY.md §8(d), evaluated for this session's configuration. */
 int64_t tllm_session_step_bytes(tllm_session_t s, int32_t context_len);
 
-/* Live per-kernel timing for bench.py's roofline: launches ONLY kernel K<which> of every layer (1 = RMSNorm+QKV GEMV,
- * 2 = decode attention, 4 = O-projection GEMV, 5 = RMSNorm+gate|up GEMV+SwiGLU, 6 = down GEMV) back to back,
+/* Live per-kernel timing for bench.py's roofline: launches ONLY kernel K<which> of every layer (1 = RMSNorm+QKV GEMV - or, when
+ * the session runs the one-launch projection + attention, that launch WITHOUT its later stages; 2 = decode attention,
+ * 4 = O-projection GEMV, 5 = RMSNorm+gate|up GEMV+SwiGLU, 6 = down GEMV, 7 = the one-launch projection + attention exactly
+ * as the generation step runs it, with every stage tllm_session_decode_form reports) back to back,
  * `sweeps` passes over the layers (each layer has its own weights, so every launch streams cold HBM exactly as in a
  * real step), bracketed by one HIP event pair on the session's stream.  avg_us = elapsed / launches (inter-launch
  * gaps included).  Activations are whatever the buffers hold: timing only, call tllm_session_fake_context or
  * tllm_session_context again before generating. */
 int32_t tllm_session_time_kernel(tllm_session_t s, int32_t which, int32_t sweeps, float* avg_us, int64_t* launches,
     tllm_stream_t stream);
+
+/* Requests tllm_session_generate ran a SECOND time because a bounded in-launch wait of the one-launch projection + attention
+ * expired (the session falls back to separate launches and repeats the request: greedy generation is a function of the prompt). */
+int32_t tllm_session_fused_retries(tllm_session_t s);
+
+/* Which launches a generation step of this session is made of (decided at setup; a time-out of the one-launch form clears it):
+ * bit 0 = QKV projection + RoPE + cache append + attention in one launch (kernels/qkv_attn_fused.hip), bit 1 = the O-projection +
+ * residual as a stage of that launch, bit 2 = RMSNorm + gate|up + SwiGLU as workgroups of that launch.  -1 before setup. */
+int32_t tllm_session_decode_form(tllm_session_t s);
 
 /* Instrumented generation steps (eager, a hipEvent pair around every launch) for the roofline report:
  * elapsed milliseconds and launch counts per class over `n_steps` steps.

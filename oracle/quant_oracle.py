@@ -64,8 +64,11 @@ class _Linear:
         return O.sq_gemm(xq, self.w_i8, tok, self.per_channel_scale)
 
 
-def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, reference_rounding=False):
+def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, reference_rounding=False, start_caches=None):
     """Context step + n_new-1 generation steps.  Returns ([logits per step], greedy ids [B, n_new]).
+    `start_caches` (one [B, 2, H, S + n_new, Dh] array per layer, with `feed_ids`): the context step is skipped and generation
+    starts from these cache contents at length S - parity tests of the generation kernels at long contexts seed both sides with
+    the same cache bytes instead of running two prefills; logits[0] is then None.
     `taps` (a dict) receives 'caches' (the per-layer KV caches, live objects: their state after the last step),
     'caches_after_context' (copies), 'attn_ctx' = [step][layer] attention output [B, H*Dh] of every generation step
     (the O-projection's input before its quantiser) and 'gemm_in' = [step][layer] dict(qkv_in, o_in, mlp_in, proj_in): the
@@ -133,6 +136,10 @@ def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, re
             gemm_in.append(rec)
         return O.f16(x1 + m)
 
+    if start_caches is not None:
+        assert feed_ids is not None and len(start_caches) == L
+        caches = [np.array(c, copy=True) for c in start_caches]
+        assert all(c.shape == (B, 2, H, smax, Dh) for c in caches)
     # ---- context
     x = O.f16(model['emb'][ids]).reshape(B * S, D)
     valid = np.concatenate([np.arange(S) < lens[b] for b in range(B)])
@@ -141,7 +148,7 @@ def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, re
         out, _ = O.context_attention(qkv.reshape(B, S, 3 * D), cache, lens, H, Dh, Dh, True, 1.0, lw.get('kv_oq'))
         return out.reshape(B * S, D)
 
-    for li in range(L):
+    for li in range(L if start_caches is None else 0):
         x = layer(li, x, valid, ctx_attn)
     if taps is not None:
         taps['caches'] = caches
@@ -150,8 +157,8 @@ def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, re
         taps['gemm_in'] = []
     x = x.reshape(B, S, D)
     last = np.stack([x[b, int(lens[b]) - 1] for b in range(B)])
-    logits = [(O.rmsnorm(last, model['lnf'], eps) @ model['head'].T).astype(F32)]
-    gen = [logits[0].argmax(-1)]
+    logits = [(O.rmsnorm(last, model['lnf'], eps) @ model['head'].T).astype(F32)] if start_caches is None else [None]
+    gen = [logits[0].argmax(-1) if start_caches is None else np.zeros(B, np.int64)]
     masked = np.zeros((B, smax), np.int32)
     for b in range(B):
         masked[b, lens[b]:S] = 1
@@ -196,13 +203,13 @@ def run_fp16_model(cfg, w, ids, lens, n_new, feed_ids=None):
     return _forward(_fp16_model(cfg, w), ids, lens, n_new, feed_ids)
 
 
-def run_model(qmodel, ids, lens, n_new, feed_ids=None, taps=None, reference_rounding=False):
+def run_model(qmodel, ids, lens, n_new, feed_ids=None, taps=None, reference_rounding=False, start_caches=None):
     m = qmodel['oracle']
     for lw in m['layers']:
         for n in LINEARS:
             if lw[n].kind == 'woq':
                 lw[n].reference_rounding = reference_rounding
-    return _forward(m, ids, lens, n_new, feed_ids, taps=taps, reference_rounding=reference_rounding)
+    return _forward(m, ids, lens, n_new, feed_ids, taps=taps, reference_rounding=reference_rounding, start_caches=start_caches)
 
 
 def quantise_model(cfg, w, mode, int8_kv, calib_ids, calib_lens, alpha=0.5):

@@ -128,8 +128,9 @@ size_t dtype_bytes(int32_t t)
 #define RUN(expr)                                                                                                      \
     do                                                                                                                 \
     {                                                                                                                  \
-        if ((expr) != 0)                                                                                               \
-            return 1;                                                                                                  \
+        const int _rc = (expr); /* (the callee's code travels up: kFusedTimedOut is told apart from a plain failure) */   \
+        if (_rc != 0)                                                                                                  \
+            return _rc;                                                                                                \
     } while (0)
 
 } // namespace
@@ -219,6 +220,13 @@ struct tllm_session
     // ... and the O-projection + residual of the layer as a third stage of that launch (static SmoothQuant: the context row
     // travels as its int8 image); session key fuse_o_projection = 0 keeps the GEMV launch
     int fuse_o_cfg = -1;
+    // ... and (r06) RMSNorm + gate|up + SwiGLU as CU-count more workgroups of that launch; session key fuse_mlp_front = 0 keeps the
+    // GEMV launch, fused_mlp_delay = ticks of 10 ns a gate|up workgroup waits before it requests weights
+    int fuse_mlp_cfg = -1;
+    int fused_mlp_delay = -1;
+    bool mlp_fused = false;
+    int fused_retries = 0;          // requests tllm_session_generate ran a second time behind an expired in-launch wait
+    int fused_max_spins = -1;       // session key fused_max_spins: bound of the in-launch waits (tests: 0 = the first miss times out)
     bool o_fused = false;
     uint64_t* fused_xchg = nullptr; // granule exchange, shared by all layers
     uint32_t* step_epoch = nullptr; // advanced by the sampler once per generation step (the granule tags derive from it)
@@ -689,6 +697,7 @@ struct tllm_session
             RUN(launch_rmsnorm(r, st));
             const void* p_in = inter_buf;
             bool mlp_fused = false;
+    int fused_retries = 0;          // requests tllm_session_generate ran a second time behind an expired in-launch wait
             if (sq && !per_token && M >= 32)
             {
                 // fc and gate in one kernel with SwiGLU + the static quantiser in its epilogue (gemm_sqp.hip, DUAL): the two fp16
@@ -897,7 +906,7 @@ struct tllm_session
             if (qkv_attn_fused)
             {
                 // K1 + K2 + K3 in one launch (kernels/qkv_attn_fused.hip)
-                if (ok < 0 || ok == 1)
+                if (ok < 0 || ok == 1 || ok == 7)
                 {
                     FusedQkvAttnParams f;
                     f.K = D;
@@ -927,8 +936,10 @@ struct tllm_session
                     f.tag_mul = (uint32_t) num_layers + 1;
                     f.tag_add = (uint32_t) li + 1;
                     if (ok >= 0) // eager launches outside a step: the epoch does not advance between them
-                        f.tag_host = 0x40000000u + (++timing_tag & 0x3fffffffu);
+                        f.tag_host = 1u + (++timing_tag & 0x3fffffffu); // (the kernel sets the top bit: host tags never meet step tags)
                     f.error = fused_err;
+                    if (fused_max_spins >= 0)
+                        f.max_spins = fused_max_spins;
                     f.qkv_out = qkv;
                     f.out = ctx;
                     if (sq && !per_token)
@@ -938,9 +949,9 @@ struct tllm_session
                     }
                     f.x_pro_out = taps ? tap_ptr(0, li) : nullptr;
                     f.timing = fused_timing;
-                    // (the kernel-timing mode measures the launches of the two-stage form one by one; with the stage clock on, the
-                    //  three-stage form is what it looks at - x is overwritten by every timed launch, which the clock does not mind)
-                    if (o_fused && (ok < 0 || fused_timing))
+                    // (kernel-timing id 1 measures the two-stage form, id 7 the launch exactly as the step runs it; with the stage clock
+                    //  on, the three-stage form is what it looks at - x is overwritten by every timed launch: the timer restores it)
+                    if (o_fused && (ok < 0 || ok == 7 || fused_timing))
                     {
                         f.o_w = L.dense.w;
                         f.o_ldw = L.dense.ldw;
@@ -949,6 +960,26 @@ struct tllm_session
                         f.o_scale_col = L.dense.scale_col;
                         f.o_scale_row = L.dense.act_scale;
                         f.x_out = x;
+                        if (mlp_fused)
+                        {
+                            // K5 as workgroups of the same launch (they read x + O(ctx) from the row workers' granules)
+                            f.m_gamma = L.ln2;
+                            f.m_act_quant = L.ln2_scale;
+                            f.m_w_fc = L.fc.w;
+                            f.m_w_gate = L.gate.w;
+                            f.m_ldw = L.fc.ldw;
+                            f.m_n = L.fc.N;
+                            f.m_per_channel = L.fc.per_channel;
+                            f.m_scale_fc = L.fc.scale_col;
+                            f.m_scale_gate = L.gate.scale_col;
+                            f.m_row_fc = L.fc.act_scale;
+                            f.m_row_gate = L.gate.act_scale;
+                            f.m_out_quant = L.mlp_qscale;
+                            f.m_out = q8;
+                            f.m_x_pro_out = taps ? tap_ptr(2, li) : nullptr;
+                            if (fused_mlp_delay >= 0)
+                                f.m_delay_ticks = fused_mlp_delay;
+                        }
                     }
                     RUN(timed(PC_ATTENTION, st, [&] { return launch_qkv_attn_fused(f, st) ? 1 : 0; }));
                 }
@@ -1054,7 +1085,11 @@ struct tllm_session
             }
             // K5
             const bool q_inter = sq && !per_token;
-            if (ok < 0 || ok == 5)
+            if (qkv_attn_fused && o_fused && mlp_fused && ok < 0)
+            {
+                // K5 ran as the gate|up workgroups of the fused launch: q8 already holds the quantised SwiGLU row
+            }
+            else if (ok < 0 || ok == 5)
             {
                 int rc5;
                 if (fused_ar)
@@ -1156,6 +1191,9 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->debug_taps = geti("debug_taps", 0) != 0;
     s->fuse_qkv_cfg = geti("fuse_qkv_attention", -1);
     s->fuse_o_cfg = geti("fuse_o_projection", -1);
+    s->fused_max_spins = geti("fused_max_spins", -1);
+    s->fuse_mlp_cfg = geti("fuse_mlp_front", -1);
+    s->fused_mlp_delay = geti("fused_mlp_delay", -1);
     s->fused_timeline = geti("fused_timeline", 0) != 0;
     if (kv.count("gemm_tactics") && !kv["gemm_tactics"].empty())
     {
@@ -1612,6 +1650,7 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
     s->fused_err = s->step_epoch + 8;
     s->qkv_attn_fused = false;
     s->o_fused = false;
+    s->mlp_fused = false;
     s->fused_xchg = nullptr;
     // (SmoothQuant, or - r05 - weight-only int8: the same 4 KB weight rows against the normalised fp16 row)
     const bool woq8_all = !s->sq && !s->layers.empty() && s->layers[0].qkv.wtype == W_INT8_WOQ;
@@ -1634,11 +1673,26 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
                 s->o_fused = s->o_fused && L.dense.N == D && L.dense.scale_col
                     && (s->sq ? (L.dense.wtype == W_INT8_SQ && L.dense.act_scale && L.attn_qscale) : L.dense.wtype == W_INT8_WOQ)
                     && qkv_attn_fused_serves_o(s->Hr, s->Dh, L.dense.N, L.dense.K, L.dense.ldw);
+            // r06: + the gate|up workgroups (static SmoothQuant; the instance is held to 128 VGPRs and is built up to 3 cache rows
+            // per lane group: caches of up to 1536 slots (int8) - beyond, the GEMV launch stays)
+            s->mlp_fused = s->o_fused && s->sq && !s->per_token && s->fuse_mlp_cfg != 0;
+            for (auto& L : s->layers)
+                s->mlp_fused = s->mlp_fused && L.fc.wtype == W_INT8_SQ && L.gate.wtype == W_INT8_SQ && L.fc.K == D && L.gate.K == D
+                    && L.fc.N == L.gate.N && L.fc.ldw == L.gate.ldw && L.fc.ldw % 16 == 0 && L.fc.per_channel == L.gate.per_channel
+                    && L.fc.scale_col && L.gate.scale_col && L.fc.act_scale && L.ln2_scale && L.mlp_qscale && L.dense.N % 2 == 0;
+            s->mlp_fused = s->mlp_fused && qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, 0, 3);
+            // ... and the instance that will run must be resident as a whole (occupancy query x CUs of this device >= its grid)
+            if (!qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, s->sq ? 0 : 1, (s->o_fused ? 1 : 0) | (s->mlp_fused ? 2 : 0)))
+            {
+                s->mlp_fused = false;
+                s->o_fused = s->o_fused && qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, s->sq ? 0 : 1, 1);
+                s->qkv_attn_fused = qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, s->sq ? 0 : 1, s->o_fused ? 1 : 0);
+            }
             s->fused_timing = nullptr;
             if (s->fused_timeline)
             {
-                RUN(s->dalloc(&s->fused_timing, (size_t) s->Hr * 8 * 16 * 8));
-                HIP_OK(hipMemset(s->fused_timing, 0, (size_t) s->Hr * 8 * 16 * 8));
+                RUN(s->dalloc(&s->fused_timing, (size_t) s->Hr * 8 * 2 * 16 * 8));
+                HIP_OK(hipMemset(s->fused_timing, 0, (size_t) s->Hr * 8 * 2 * 16 * 8));
             }
         }
     }
@@ -1649,6 +1703,9 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
 // never hang: a bounded wait that expires raises a device flag and every later launch backs off, p2p_allreduce.hip.)  Then
 // the hidden states / logits behind this point are not sums over all ranks: fail the call and take the transport out of
 // service, so that later sessions of this process fall back to RCCL.
+// (distinct from 1: tllm_session_generate re-runs the request on the launches the session has fallen back to)
+constexpr int kFusedTimedOut = 2;
+
 static int check_comm(tllm_session_t s)
 {
     if (s->qkv_attn_fused && s->fused_err)
@@ -1666,6 +1723,7 @@ static int check_comm(tllm_session_t s)
             (void) hipMemset(s->fused_err, 0, 4);
             s->qkv_attn_fused = false; // later steps take the two-launch path
             s->o_fused = false;
+            s->mlp_fused = false;
             if (s->graph)
             {
                 (void) hipGraphExecDestroy(s->graph);
@@ -1673,7 +1731,7 @@ static int check_comm(tllm_session_t s)
             }
             set_error("session: the fused QKV + attention launch timed out waiting for a sibling workgroup (code %u); the results of "
                       "this call are invalid, later steps run the projection and the attention as two launches", e);
-            return 1;
+            return kFusedTimedOut;
         }
     }
     // only while the transport is IN SERVICE: once a time-out has taken it out (below), later calls run over RCCL and the
@@ -1868,8 +1926,29 @@ int32_t tllm_session_fake_context(tllm_session_t s, int32_t length, uint32_t see
     return 0;
 }
 
+static int32_t generate_once(tllm_session_t s, const int32_t* input_ids, const int32_t* input_lengths, int32_t max_new_tokens,
+    int32_t end_id, int32_t pad_id, int32_t* output_ids, tllm_stream_t stream);
+
 int32_t tllm_session_generate(tllm_session_t s, const int32_t* input_ids, const int32_t* input_lengths,
     int32_t max_new_tokens, int32_t end_id, int32_t pad_id, int32_t* output_ids, tllm_stream_t stream)
+{
+    // A bounded wait of the one-launch projection + attention expired (its grid was not resident at once - another queue's kernels
+    // held CUs): the session has fallen back to the two-launch path, the tokens behind the expired wait are invalid.  Greedy
+    // generation is a function of the prompt alone, every cache slot is rewritten before it is read: run the request again.
+    const int32_t rc = generate_once(s, input_ids, input_lengths, max_new_tokens, end_id, pad_id, output_ids, stream);
+    if (rc != kFusedTimedOut)
+        return rc;
+    s->fused_retries += 1;
+    return generate_once(s, input_ids, input_lengths, max_new_tokens, end_id, pad_id, output_ids, stream) ? 1 : 0;
+}
+
+int32_t tllm_session_fused_retries(tllm_session_t s)
+{
+    return s ? s->fused_retries : 0;
+}
+
+static int32_t generate_once(tllm_session_t s, const int32_t* input_ids, const int32_t* input_lengths, int32_t max_new_tokens,
+    int32_t end_id, int32_t pad_id, int32_t* output_ids, tllm_stream_t stream)
 {
     if (!s || !s->B || !input_ids || !input_lengths || !output_ids)
     {
@@ -2173,15 +2252,29 @@ int64_t tllm_session_step_bytes(tllm_session_t s, int32_t context_len)
 int32_t tllm_session_time_kernel(tllm_session_t s, int32_t which, int32_t sweeps, float* avg_us, int64_t* launches,
     tllm_stream_t stream)
 {
-    if (!s || !s->B || sweeps < 1 || !avg_us || !launches || !(which == 1 || which == 2 || which == 4 || which == 5 || which == 6))
+    if (!s || !s->B || sweeps < 1 || !avg_us || !launches
+        || !(which == 1 || which == 2 || which == 4 || which == 5 || which == 6 || which == 7))
     {
-        set_error("tllm_session_time_kernel: bad arguments (which in {1,2,4,5,6}) / setup not called");
+        set_error("tllm_session_time_kernel: bad arguments (which in {1,2,4,5,6,7}) / setup not called");
+        return 1;
+    }
+    if (which == 7 && !s->qkv_attn_fused)
+    {
+        set_error("tllm_session_time_kernel: kernel 7 is the one-launch projection + attention, which this session does not run");
         return 1;
     }
     hipStream_t st = s->pick(stream);
     hipEvent_t a, b;
     (void) hipEventCreate(&a);
     (void) hipEventCreate(&b);
+    // (id 7 with the O-projection stage adds O(ctx) to x on every launch: the residual row is put back afterwards)
+    std::vector<char> x_keep;
+    if (which == 7)
+    {
+        x_keep.resize((size_t) s->B * s->hidden * 2);
+        HIP_OK(hipMemcpyAsync(x_keep.data(), s->x, x_keep.size(), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
     s->only_kernel = which;
     int rc = s->run_decode_step(st); // untimed sweep
     (void) hipEventRecord(a, st);
@@ -2198,9 +2291,21 @@ int32_t tllm_session_time_kernel(tllm_session_t s, int32_t which, int32_t sweeps
     }
     (void) hipEventDestroy(a);
     (void) hipEventDestroy(b);
+    if (!x_keep.empty())
+    {
+        HIP_OK(hipMemcpyAsync(s->x, x_keep.data(), x_keep.size(), hipMemcpyHostToDevice, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
     *launches = (int64_t) sweeps * s->num_layers;
     *avg_us = ms * 1000.f / (float) *launches;
     return rc;
+}
+
+int32_t tllm_session_decode_form(tllm_session_t s)
+{
+    if (!s || !s->B)
+        return -1;
+    return (s->qkv_attn_fused ? 1 : 0) | (s->qkv_attn_fused && s->o_fused ? 2 : 0) | (s->qkv_attn_fused && s->o_fused && s->mlp_fused ? 4 : 0);
 }
 
 int32_t tllm_session_profile(tllm_session_t s, int32_t n_steps, float* ms_per_class, int64_t* launches_per_class,

@@ -73,6 +73,10 @@ def _lib():
     lib.tllm_session_time_kernel.argtypes = [c.c_void_p, c.c_int32, c.c_int32, c.POINTER(c.c_float), c.POINTER(c.c_int64),
                                              c.c_void_p]
     lib.tllm_session_time_kernel.restype = c.c_int32
+    lib.tllm_session_fused_retries.argtypes = [c.c_void_p]
+    lib.tllm_session_fused_retries.restype = c.c_int32
+    lib.tllm_session_decode_form.argtypes = [c.c_void_p]
+    lib.tllm_session_decode_form.restype = c.c_int32
     lib.tllm_session_destroy.argtypes = [c.c_void_p]
     lib.tllm_session_destroy.restype = None
     _bound = True
@@ -190,7 +194,15 @@ class NativeSession:
         _check(_lib().tllm_session_profile(self._h, n_steps, ms, cnt, stream), 'profile')
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(self.PROFILE_CLASSES)}
 
-    LAYER_KERNELS = {'qkv': 1, 'attention': 2, 'o_proj': 4, 'gate_up': 5, 'down': 6}
+    LAYER_KERNELS = {'qkv': 1, 'attention': 2, 'o_proj': 4, 'gate_up': 5, 'down': 6, 'front': 7}
+
+    def fused_retries(self) -> int:
+        """requests generate() repeated behind an expired in-launch wait of the one-launch projection + attention"""
+        return int(_lib().tllm_session_fused_retries(self._h))
+
+    def decode_form(self) -> int:
+        """bit 0: QKV projection + attention in one launch, bit 1: + the O-projection stage, bit 2: + the gate|up workgroups"""
+        return int(_lib().tllm_session_decode_form(self._h))
 
     def time_kernel(self, which: str, sweeps: int = 4, stream: int = 0):
         """(average microseconds per launch, launches) of one per-layer kernel launched back to back over all layers."""
