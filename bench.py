@@ -49,6 +49,7 @@ def parse():
                     help='A/B: RMSNorm + gate|up + SwiGLU as a GEMV launch of its own (session key fuse_mlp_front = 0)')
     ap.add_argument('--mlp-delay', type=int, default=-1,
                     help='tuning: ticks of 10 ns a gate|up workgroup of the fused launch waits before it requests weights (session key fused_mlp_delay)')
+    ap.add_argument('--mlp-tiles', type=int, default=-1, help='tuning: 8 KB tiles per wave a gate|up workgroup requests ahead of its input (0 - 2)')
     ap.add_argument('--no-prefill', dest='prefill', action='store_false', help='skip the prefill (TTFT) and SQ-GEMM MFMA reports')
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
     ap.add_argument('--no-batch-sweep', dest='batch_sweep', action='store_false',
@@ -201,7 +202,7 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=world, tp_rank=rank, fuse_qkv_attention=0 if args.two_launch_attention else -1,
                               fuse_o_projection=0 if getattr(args, 'gemv_o_projection', False) else -1,
                               fuse_mlp_front=0 if getattr(args, 'gemv_gate_up', False) else -1,
-                              fused_mlp_delay=getattr(args, 'mlp_delay', -1)))
+                              fused_mlp_delay=getattr(args, 'mlp_delay', -1), fused_mlp_tiles=getattr(args, 'mlp_tiles', -1)))
     weights = synth_weights(torch, cfg, mode, int8_kv, world, rank, dev)
     for k, v in weights.items():
         sess.set_tensor(k, v)

@@ -12,7 +12,8 @@ dev = torch.device('cuda', 0)
 w = bench.synth_weights(torch, cfg, 'sq', True, 1, 0, dev)
 s = NativeSession(dict(cfg, quant_mode=bench.QM['sq'] | bench.INT8_KV, tp_size=1, tp_rank=0, fused_timeline=1,
                        fuse_mlp_front=int(sys.argv[2]) if len(sys.argv) > 2 else -1,
-                       fused_mlp_delay=int(sys.argv[3]) if len(sys.argv) > 3 else -1))
+                       fused_mlp_delay=int(sys.argv[3]) if len(sys.argv) > 3 else -1,
+                       fused_mlp_tiles=int(sys.argv[4]) if len(sys.argv) > 4 else -1))
 for k, v in w.items():
     s.set_tensor(k, v)
 s.finalize()

@@ -245,6 +245,7 @@ struct FusedQkvAttnParams
     void* m_out = nullptr;                 // s8 [m_n]
     void* m_x_pro_out = nullptr;           // optional s8 [K]: the quantised operand (tap)
     int32_t m_delay_ticks = 600;           // 100 MHz ticks after its start before a gate|up workgroup requests weights
+    int32_t m_prefetch_tiles = 2;          // 8 KB tiles per wave it requests AHEAD of x + O(ctx) (0 - 2; the rest behind the hand-off)
 };
 size_t qkv_attn_fused_xchg_bytes(int32_t num_heads);
 bool qkv_attn_fused_serves_o(int32_t num_heads, int32_t head_size, int32_t o_n, int32_t o_k, int64_t o_ldw);

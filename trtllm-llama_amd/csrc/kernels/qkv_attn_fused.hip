@@ -244,8 +244,11 @@ __device__ __forceinline__ void mlp_gate_up_role(const FusedQkvAttnParams& p, ch
         __builtin_amdgcn_s_sleep(16);
     uint4 wv[kKChunks][2], wv2[kKChunks][2];
     __builtin_amdgcn_sched_barrier(0);
-    load_tile(0, wv);
-    load_tile(1, wv2);
+    const int pre = p.m_prefetch_tiles; // uniform: tiles per wave requested AHEAD of x1 (0, 1 or 2)
+    if (pre >= 1)
+        load_tile(0, wv);
+    if (pre >= 2)
+        load_tile(1, wv2);
     __builtin_amdgcn_sched_barrier(0);
     if (p.timing && lane == 0 && wid == 0)
         p.timing[(size_t) blockIdx.x * 16 + 1] = wall_clock64();
@@ -280,6 +283,12 @@ __device__ __forceinline__ void mlp_gate_up_role(const FusedQkvAttnParams& p, ch
         for (int i = 0; i < 4; ++i)
             x1s[tid + 512 * i] = (uint32_t) g[i];
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (pre < 1)
+        load_tile(0, wv);
+    if (pre < 2)
+        load_tile(1, wv2);
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     if (p.timing && lane == 0 && wid == 0)
         p.timing[(size_t) blockIdx.x * 16 + 2] = wall_clock64();

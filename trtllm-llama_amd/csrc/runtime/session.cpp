@@ -224,6 +224,7 @@ struct tllm_session
     // GEMV launch, fused_mlp_delay = ticks of 10 ns a gate|up workgroup waits before it requests weights
     int fuse_mlp_cfg = -1;
     int fused_mlp_delay = -1;
+    int fused_mlp_tiles = -1;
     bool mlp_fused = false;
     int fused_retries = 0;          // requests tllm_session_generate ran a second time behind an expired in-launch wait
     int fused_max_spins = -1;       // session key fused_max_spins: bound of the in-launch waits (tests: 0 = the first miss times out)
@@ -979,6 +980,8 @@ struct tllm_session
                             f.m_x_pro_out = taps ? tap_ptr(2, li) : nullptr;
                             if (fused_mlp_delay >= 0)
                                 f.m_delay_ticks = fused_mlp_delay;
+                            if (fused_mlp_tiles >= 0)
+                                f.m_prefetch_tiles = fused_mlp_tiles;
                         }
                     }
                     RUN(timed(PC_ATTENTION, st, [&] { return launch_qkv_attn_fused(f, st) ? 1 : 0; }));
@@ -1194,6 +1197,7 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->fused_max_spins = geti("fused_max_spins", -1);
     s->fuse_mlp_cfg = geti("fuse_mlp_front", -1);
     s->fused_mlp_delay = geti("fused_mlp_delay", -1);
+    s->fused_mlp_tiles = geti("fused_mlp_tiles", -1);
     s->fused_timeline = geti("fused_timeline", 0) != 0;
     if (kv.count("gemm_tactics") && !kv["gemm_tactics"].empty())
     {
