@@ -45,11 +45,6 @@ def parse():
                     help='A/B: QKV projection and attention as two launches (session key fuse_qkv_attention = 0)')
     ap.add_argument('--gemv-o-projection', action='store_true',
                     help='A/B: the O-projection as a GEMV launch of its own (session key fuse_o_projection = 0)')
-    ap.add_argument('--gemv-gate-up', action='store_true',
-                    help='A/B: RMSNorm + gate|up + SwiGLU as a GEMV launch of its own (session key fuse_mlp_front = 0)')
-    ap.add_argument('--mlp-delay', type=int, default=-1,
-                    help='tuning: ticks of 10 ns a gate|up workgroup of the fused launch waits before it requests weights (session key fused_mlp_delay)')
-    ap.add_argument('--mlp-tiles', type=int, default=-1, help='tuning: 8 KB tiles per wave a gate|up workgroup requests ahead of its input (0 - 2)')
     ap.add_argument('--no-prefill', dest='prefill', action='store_false', help='skip the prefill (TTFT) and SQ-GEMM MFMA reports')
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
     ap.add_argument('--no-batch-sweep', dest='batch_sweep', action='store_false',
@@ -155,8 +150,6 @@ def step_launches(cfg, mode, world, form, l_mean, int8_kv, smax):
         b, what = qkv + kv - 3 * Dr * 2, 'RMSNorm -> QKV GEMV -> RoPE -> cache append -> attention'
         if form & 2:
             b, what = b + o - Dr * (1 if mode == 'sq' else 2), what + ' -> O-projection + residual'
-        if form & 4:
-            b, what = b + gate_up - row, what + ' | RMSNorm -> gate|up GEMV -> SwiGLU'
         out.append(dict(key='front', id=7, kernel=name, what=what, bytes=b, calls=L, match=['qkv_attn_fused_kernel']))
     else:
         out.append(dict(key='qkv', id=1, kernel='gemv_kernel<%d, 1, 0, 1, 2, 4>' % wt, what='RMSNorm -> QKV GEMV', bytes=qkv, calls=L,
@@ -166,9 +159,8 @@ def step_launches(cfg, mode, world, form, l_mean, int8_kv, smax):
     if not form & 2:
         out.append(dict(key='o_proj', id=4, kernel='gemv (O-projection + residual)', what='O-projection + residual', bytes=o, calls=L,
                         match=['gemv_ksplit_kernel', 'gemv_kernel<%d, 0, 0' % wt, 'gemv_kernel<%d, 2, 0' % wt]))
-    if not form & 4:
-        out.append(dict(key='gate_up', id=5, kernel='gemv_kernel<%d, 1, 1, 1, 2, 4>' % wt, what='RMSNorm -> gate|up GEMV -> SwiGLU',
-                        bytes=gate_up, calls=L, match=['gemv_kernel<%d, 1, 1' % wt]))
+    out.append(dict(key='gate_up', id=5, kernel='gemv_kernel<%d, 1, 1, 1, 2, 4>' % wt, what='RMSNorm -> gate|up GEMV -> SwiGLU',
+                    bytes=gate_up, calls=L, match=['gemv_kernel<%d, 1, 1' % wt]))
     out.append(dict(key='down', id=6, kernel='gemv_ksplit_kernel<3, 3>' if mode == 'sq' else 'gemv (down projection + residual)',
                     what='down projection + residual', bytes=down, calls=L,
                     match=['gemv_ksplit_kernel', 'gemv_kernel<%d, 0, 0' % wt, 'gemv_kernel<%d, 2, 0' % wt]))
@@ -200,9 +192,7 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     int8_kv = mode != 'fp16'  # BASELINE.json configs: fp16 + fp16 KV; every int8 config with int8 KV
     qm = QM[mode] | (INT8_KV if int8_kv else 0)
     sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=world, tp_rank=rank, fuse_qkv_attention=0 if args.two_launch_attention else -1,
-                              fuse_o_projection=0 if getattr(args, 'gemv_o_projection', False) else -1,
-                              fuse_mlp_front=0 if getattr(args, 'gemv_gate_up', False) else -1,
-                              fused_mlp_delay=getattr(args, 'mlp_delay', -1), fused_mlp_tiles=getattr(args, 'mlp_tiles', -1)))
+                              fuse_o_projection=0 if getattr(args, 'gemv_o_projection', False) else -1))
     weights = synth_weights(torch, cfg, mode, int8_kv, world, rank, dev)
     for k, v in weights.items():
         sess.set_tensor(k, v)
@@ -725,8 +715,7 @@ def main():
                  # the launches one layer is made of in this run, timed one by one (the same numbers as roofline.kernels)
                  'layer_kernel_us': {k: v for k, v in res['kernel_us'].items() if k != 'head'},
                  'decode_form': {'qkv_and_attention_in_one_launch': bool(res['decode_form'] & 1),
-                                 'o_projection_in_that_launch': bool(res['decode_form'] & 2),
-                                 'gate_up_in_that_launch': bool(res['decode_form'] & 4)},
+                                 'o_projection_in_that_launch': bool(res['decode_form'] & 2)},
                  # the layer as the graph replay runs it: (device time per step - the head GEMV - the sampler, both from the eager
                  # profile below) / layers.  layer_kernel_us above times the launches ONE BY ONE
                  'layer_us_in_graph_replay': (res['dev_ms'] / args.steps - (prof['gemv_head'][0] + prof['other'][0]) / prof_steps) * 1e3 / args.layers,

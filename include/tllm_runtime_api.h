@@ -179,7 +179,7 @@ int32_t tllm_session_fused_retries(tllm_session_t s);
 
 /* Which launches a generation step of this session is made of (decided at setup; a time-out of the one-launch form clears it):
  * bit 0 = QKV projection + RoPE + cache append + attention in one launch (kernels/qkv_attn_fused.hip), bit 1 = the O-projection +
- * residual as a stage of that launch, bit 2 = RMSNorm + gate|up + SwiGLU as workgroups of that launch.  -1 before setup. */
+ * residual as a stage of that launch.  -1 before setup. */
 int32_t tllm_session_decode_form(tllm_session_t s);
 
 /* Instrumented generation steps (eager, a hipEvent pair around every launch) for the roofline report:

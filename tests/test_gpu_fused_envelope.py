@@ -1,5 +1,5 @@
 """The one-launch generation path (kernels/qkv_attn_fused.hip: QKV projection + RoPE + cache append + attention, + the
-O-projection stage, + the gate|up workgroups where the session runs them) against the ORACLE across its envelope - not against
+O-projection stage where the session runs it) against the ORACLE across its envelope - not against
 the two-launch HIP path (tests/test_gpu_fused_qkv_attn.py does that, bit for bit): one decoder layer at LLaMA-7B dimensions,
 batch 1, contexts 3 / 40 of 49 padded / 700 / 2300 / 4000 (fp16 cache: up to 2000), static and per-token SmoothQuant,
 weight-only int8, int8 and fp16 KV cache.
@@ -94,8 +94,9 @@ def test_one_launch_generation_vs_oracle_across_the_envelope(mode, int8_kv, shap
                     # the two implementations straddle a quantiser boundary.  Behind the O-projection every element of x + O(ctx)
                     # may sit one fp16 ulp apart (a one-LSB context element moves all 4096 sums), and one ulp of a value near 4 is
                     # 5 - 10 % of post_layernorm's quantiser step: more flips, never more than one LSB
+                    # (proj_in: one fp16 ulp of silu(fc) * gate near its largest values spans two steps of the SwiGLU quantiser)
                     floor = dict(qkv_in=1.0, o_in=0.95, mlp_in=0.85, proj_in=0.85)[n]
-                    assert d.max() <= (0 if n == 'qkv_in' else 1) and same >= floor, (tag, n, int(d.max()), same)
+                    assert d.max() <= dict(qkv_in=0, o_in=1, mlp_in=1, proj_in=2)[n] and same >= floor, (tag, n, int(d.max()), same)
                 else:
                     tol = dict(qkv_in=(1e-3, 1e-3), o_in=(2e-3, 1e-3), mlp_in=(8e-3, 4e-3), proj_in=(8e-3, 8e-3))[n]
                     np.testing.assert_allclose(g.astype(np.float32), w_.astype(np.float32), atol=tol[0], rtol=tol[1], err_msg=f'{tag} {n}')

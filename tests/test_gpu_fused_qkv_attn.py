@@ -28,9 +28,9 @@ pytestmark = pytest.mark.gpu
 PER_TOKEN = 1  # QuantMode.PER_TOKEN (T/tensorrt_llm/quantization/mode.py:6-21)
 
 
-def make(cfg, w, qm, fuse, taps=True, fuse_o=-1, fuse_mlp=-1, **keys):
+def make(cfg, w, qm, fuse, taps=True, fuse_o=-1, **keys):
     s = NativeSession(dict(cfg, quant_mode=qm, tp_size=1, tp_rank=0, debug_taps=1 if taps else 0, fuse_qkv_attention=fuse,
-                           fuse_o_projection=fuse_o, fuse_mlp_front=fuse_mlp, **keys))
+                           fuse_o_projection=fuse_o, **keys))
     for k, v in w.items():
         s.set_tensor(k, v)
     s.finalize()
@@ -174,7 +174,7 @@ def test_o_projection_stage_equals_the_gemv_launch(S, pad, int8_kv):
     lens = np.array([S], np.int32)
     out = {}
     for fuse_o in (0, 1):
-        s = make(cfg, w, qm, 1, fuse_o=fuse_o, fuse_mlp=0)
+        s = make(cfg, w, qm, 1, fuse_o=fuse_o)
         out[fuse_o] = run_with(s, cfg, ids, lens, max_in, NEW, layers, int8_kv, True)
         s.close()
     a, b = out[0], out[1]
@@ -293,82 +293,10 @@ def test_weight_only_o_projection_stage_equals_the_gemv_launch(S, pad, int8_kv):
     assert np.abs(a['logits'][-1]).max() > 0
 
 
-@pytest.mark.parametrize('S,pad,int8_kv', [(3, 0, 1), (40, 9, 1), (700, 0, 1), (1100, 0, 1), (1500, 0, 1), (300, 5, 0), (700, 0, 0)])
-def test_gate_up_workgroups_equal_the_gemv_launch(S, pad, int8_kv):
-    """r06: RMSNorm + gate|up + SwiGLU as CU-count more workgroups of the fused launch (session key fuse_mlp_front) against the GEMV
-    launch they replace (gemv_kernel<W_INT8_SQ, PK_NORM, EK_SWIGLU>; reference: GatedMLP.forward, PY/layers/mlp.py:43-73, behind
-    RmsNorm + the static quantiser).  The workgroups read x + O(ctx) from the row workers' granules - the same fp16 values the GEMV
-    reads from x - and restate its prologue's summation order, its exact integer dots and its epilogue, so EVERYTHING is identical:
-    the int8 operand behind post_layernorm's quantiser (tap mlp_in), the quantised SwiGLU row (tap proj_in), the logits of every
-    step, the tokens, every byte of the KV cache.  Eager steps and graph replays; served up to 3 cache rows per lane group
-    (1536 int8 / 768 fp16 slots)."""
-    layers, NEW = 2, 7
-    cfg, w, qm = weights(layers, int8_kv)
-    max_in = S + pad
-    r = np.random.default_rng(600 + S)
-    ids = np.full((1, max_in), 2, np.int32)
-    ids[0, :S] = r.integers(3, cfg['vocab_size'], S)
-    lens = np.array([S], np.int32)
-    D, I = cfg['hidden_size'], cfg['inter_size']
-    out = {}
-    for fuse_mlp in (0, 1):
-        s = make(cfg, w, qm, 1, fuse_o=1, fuse_mlp=fuse_mlp)
-        s.setup(1, max_in, NEW)
-        assert s.decode_form() == (7 if fuse_mlp else 3), s.decode_form()
-        s.context(ids, lens)
-        rec = dict(mlp_in=[], proj_in=[], o_in=[], logits=[s.logits()])
-        for i in range(NEW - 1):
-            s.step(1, use_graph=i >= 2)
-            rec['o_in'].append(np.stack([s.attention_tap(li, D, quantised=True)[0] for li in range(layers)]))
-            rec['mlp_in'].append(np.stack([s.tap(li, 'mlp_in', D, quantised=True)[0] for li in range(layers)]))
-            rec['proj_in'].append(np.stack([s.tap(li, 'proj_in', I, quantised=True)[0] for li in range(layers)]))
-            rec['logits'].append(s.logits())
-        rec['tokens'] = s.output_ids()
-        nbytes = 2 * cfg['num_heads'] * (max_in + NEW) * (D // cfg['num_heads']) * (1 if int8_kv else 2)
-        rec['cache'] = [read_cache(s, li, nbytes) for li in range(layers)]
-        out[fuse_mlp] = rec
-        s.close()
-    a, b = out[0], out[1]
-    for i in range(NEW - 1):
-        np.testing.assert_array_equal(a['o_in'][i], b['o_in'][i])
-        np.testing.assert_array_equal(a['mlp_in'][i], b['mlp_in'][i])
-        np.testing.assert_array_equal(a['proj_in'][i], b['proj_in'][i])
-    for i in range(NEW):
-        np.testing.assert_array_equal(a['logits'][i], b['logits'][i])
-    np.testing.assert_array_equal(a['tokens'], b['tokens'])
-    for li in range(layers):
-        np.testing.assert_array_equal(a['cache'][li], b['cache'][li])
-    assert np.abs(a['logits'][-1]).max() > 0 and np.abs(a['proj_in'][-1]).max() > 0
-
-
-def test_gate_up_workgroups_over_all_layers_and_many_replays():
-    """32 layers, 1100-token context, 40 tokens: the launch with the gate|up workgroups (graph replay) and the three-launch layer
-    give the same tokens and the same final logits; a second prompt on the same session (stale x1 granules) equals a fresh one."""
-    cfg, w, qm = weights(32, 1)
-    S, NEW = 1100, 40
-    lens = np.array([S], np.int32)
-    ids = np.random.default_rng(19).integers(3, cfg['vocab_size'], (1, S)).astype(np.int32)
-    ids2 = np.random.default_rng(20).integers(3, cfg['vocab_size'], (1, S)).astype(np.int32)
-    got = {}
-    for fuse_mlp in (0, 1):
-        s = make(cfg, w, qm, 1, taps=False, fuse_mlp=fuse_mlp)
-        s.setup(1, S, NEW)
-        assert bool(s.decode_form() & 4) == bool(fuse_mlp)
-        g = s.generate(ids, lens, NEW)
-        lg = s.logits()
-        s.setup(1, S, NEW)
-        g2 = s.generate(ids2, lens, NEW)
-        got[fuse_mlp] = (g, lg, g2, s.logits())
-        assert s.fused_retries() == 0
-        s.close()
-    for x, y in zip(got[0], got[1]):
-        np.testing.assert_array_equal(x, y)
-
-
-@pytest.mark.parametrize('fuse_mlp', [0, 1])
-def test_expired_in_launch_wait_falls_back_and_repeats_the_request(fuse_mlp):
-    """The bounded waits of the one-launch form: with `fused_max_spins = 0` the first look that misses - the row
-    workers' at the context rows, the gate|up workgroups' at x + O(ctx): neither can be there yet - raises the error word; later
+@pytest.mark.parametrize('fuse_o', [0, 1])
+def test_expired_in_launch_wait_falls_back_and_repeats_the_request(fuse_o):
+    """The bounded waits of the one-launch form: with `fused_max_spins = 0` the first look that misses - the mergers'
+    at the eight partials, the row workers' at the context rows: neither can be there at the first look - raises the error word; later
     launches return at entry; at its next synchronisation the session drops the one-launch form and tllm_session_generate runs the
     request AGAIN on separate launches.  The caller sees the tokens of a session that never used the one-launch form."""
     cfg, w, qm = weights(4, 1)
@@ -379,7 +307,7 @@ def test_expired_in_launch_wait_falls_back_and_repeats_the_request(fuse_mlp):
     ref.setup(1, S, NEW)
     want = ref.generate(ids, lens, NEW)
     ref.close()
-    s = make(cfg, w, qm, 1, taps=False, fuse_mlp=fuse_mlp, fused_max_spins=0)
+    s = make(cfg, w, qm, 1, taps=False, fuse_o=fuse_o, fused_max_spins=0)
     s.setup(1, S, NEW)
     assert s.decode_form() & 1
     got = s.generate(ids, lens, NEW)

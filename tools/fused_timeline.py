@@ -1,5 +1,5 @@
 """Stage clock of the fused QKV + attention launch (GPU box): where the 256 workgroups are at which microsecond.
-   python tools/fused_timeline.py [context] [fuse_mlp_front (-1 auto, 0 off)] [fused_mlp_delay ticks of 10 ns]"""
+   python tools/fused_timeline.py [context]"""
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,10 +10,7 @@ from tensorrt_llm.runtime.native import NativeSession, _lib
 cfg = dict(bench.LLAMA_7B)
 dev = torch.device('cuda', 0)
 w = bench.synth_weights(torch, cfg, 'sq', True, 1, 0, dev)
-s = NativeSession(dict(cfg, quant_mode=bench.QM['sq'] | bench.INT8_KV, tp_size=1, tp_rank=0, fused_timeline=1,
-                       fuse_mlp_front=int(sys.argv[2]) if len(sys.argv) > 2 else -1,
-                       fused_mlp_delay=int(sys.argv[3]) if len(sys.argv) > 3 else -1,
-                       fused_mlp_tiles=int(sys.argv[4]) if len(sys.argv) > 4 else -1))
+s = NativeSession(dict(cfg, quant_mode=bench.QM['sq'] | bench.INT8_KV, tp_size=1, tp_rank=0, fused_timeline=1))
 for k, v in w.items():
     s.set_tensor(k, v)
 s.finalize()
@@ -32,11 +29,9 @@ names = {0: 'start', 1: 'prologue done', 2: 'q rows done', 3: 'k rows done', 6: 
 for rnd in range(3):
     us, n = s.time_kernel('front', sweeps=4)
     torch.cuda.synchronize()
-    form = s.decode_form()
-    tall = np.zeros((512, 16), np.uint64)
-    assert hip.hipMemcpy(tall.ctypes.data, lib.tllm_session_fused_timeline_ptr(s._h), tall.nbytes, 2) == 0
-    tall = tall.astype(np.int64)
-    t = tall[:256]
+    t = np.zeros((256, 16), np.uint64)
+    assert hip.hipMemcpy(t.ctypes.data, lib.tllm_session_fused_timeline_ptr(s._h), t.nbytes, 2) == 0
+    t = t.astype(np.int64)
     t0 = t[:, 0].min()
     print(f'--- round {rnd}: {us:.2f} us per launch; last launch, us since the first workgroup started (min / median / max over workgroups)')
     for k in (0, 1, 2, 3, 6, 4, 5, 11, 7, 8, 9, 10):
@@ -50,12 +45,5 @@ for rnd in range(3):
           f'q in LDS - v rows done, by re-polls: ' + ', '.join(f'{k}: {np.median((t[:, 4] - t[:, 6])[t[:, 12] == k]) / 100.0:.2f} us' for k in sorted(set(t[:, 12].tolist()))))
     pd = t[:, 5].reshape(8, H)      # barrier D of every member (partials published right behind it)
     print(f'   partial hand-off (last member past barrier D -> member 0 has everything in LDS): median {np.median((t[:H, 11] - pd.max(0)) / 100.0):.2f} us')
-    if form & 4:
-        tb = tall[256:]
-        print(f'   gate|up workgroups (decode_form {form}):')
-        for k, nm in ((0, 'start'), (1, 'two tiles per wave requested'), (2, 'x1 in LDS'), (3, 'operand quantised'), (4, 'end')):
-            r = (tb[:, k][tb[:, k] > 0] - t0) / 100.0
-            print(f'   {nm:30s} {r.min():7.2f} {np.median(r):7.2f} {r.max():7.2f}')
-        print(f'   x1 polls beyond the first: {np.bincount(tb[:, 12]).tolist()}')
 for k in ('o_proj', 'gate_up', 'down'):
     print(k, s.time_kernel(k, sweeps=8))

@@ -228,31 +228,13 @@ struct FusedQkvAttnParams
     const void* o_scale_col = nullptr;     // SmoothQuant: f32 [o_n] (per_channel) or [1]; weight-only: fp16 [o_n]
     const float* o_scale_row = nullptr;    // f32 [1]: the static activation scale of the dequantisation
     void* x_out = nullptr;                 // fp16 [o_n]: may be x itself (every workgroup has consumed x long before)
-    // optional (r06, with the O-projection stage, static SmoothQuant): RMSNorm(m_gamma) + static quantiser of x_out, the fc | gate
-    // GEMV, SwiGLU and its static quantiser as CU-count MORE workgroups of the same launch (gemv_kernel<W_INT8_SQ, PK_NORM,
-    // EK_SWIGLU> restated);  m_out[n] = sat(rni(fp16(silu16(fc_n) * gate_n) * m_out_quant[0])).  m_w_fc null: no such workgroups.
-    const void* m_gamma = nullptr;         // fp16 [K]: post_layernorm
-    const float* m_act_quant = nullptr;    // f32 [1]: static quantiser of the normalised row
-    const void* m_w_fc = nullptr;          // s8 [m_n, m_ldw]
-    const void* m_w_gate = nullptr;        // s8 [m_n, m_ldw]
-    int64_t m_ldw = 0;                     // bytes
-    int32_t m_n = 0, m_per_channel = 0;
-    const void* m_scale_fc = nullptr;      // f32 [m_n] (per_channel) or [1]
-    const void* m_scale_gate = nullptr;
-    const float* m_row_fc = nullptr;       // f32 [1]: static activation scales of the two dequantisations
-    const float* m_row_gate = nullptr;     // (null: m_row_fc)
-    const float* m_out_quant = nullptr;    // f32 [1]: static quantiser of the SwiGLU output
-    void* m_out = nullptr;                 // s8 [m_n]
-    void* m_x_pro_out = nullptr;           // optional s8 [K]: the quantised operand (tap)
-    int32_t m_delay_ticks = 600;           // 100 MHz ticks after its start before a gate|up workgroup requests weights
-    int32_t m_prefetch_tiles = 2;          // 8 KB tiles per wave it requests AHEAD of x + O(ctx) (0 - 2; the rest behind the hand-off)
 };
 size_t qkv_attn_fused_xchg_bytes(int32_t num_heads);
 bool qkv_attn_fused_serves_o(int32_t num_heads, int32_t head_size, int32_t o_n, int32_t o_k, int64_t o_ldw);
-// stages: bit 0 = with the O-projection stage, bit 1 = with the gate|up workgroups (decides the instance, its LDS and the grid the
-// residency check is made for)
+// (woq8 / o_stage decide the instance and its dynamic LDS: the residency check - occupancy query x CUs of the current device >= grid
+// - is made for exactly the launch that will run)
 bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int32_t max_seq_len, int32_t int8_kv, int32_t woq8 = 0,
-    int32_t stages = 0);
+    int32_t o_stage = 0);
 int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream);
 
 // RoPE table builder (host -> device buffer owned by caller): cos/sin(pos / 10000^(2j/rot)) in fp32,

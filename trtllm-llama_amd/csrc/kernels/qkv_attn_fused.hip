@@ -64,7 +64,6 @@ constexpr int kHeadGranules = 3 * 64 + kMembers * kPartStride;
 constexpr int kCtxGranules = kDH / 4; // the head's context row as its int8 image, four elements per granule (O-projection stage)
 constexpr int kCtxGranulesH = kDH / 2; // ... as fp16, two elements per granule (weight-only engines)
 constexpr int kORowsMax = 24;         // dense-projection rows a row-worker workgroup takes at most (3 per wave)
-constexpr int kX1Granules = 2048;     // x + O(ctx) as fp16 pairs, one granule per pair (gate|up workgroups, r06): K / 2
 
 __device__ __forceinline__ void st_granule(gu64* g, uint32_t tag, uint32_t value)
 {
@@ -181,217 +180,11 @@ __device__ __forceinline__ float groups_max(float v)
 }
 
 
-// fp16 rounding points of the reference graph (gemv_impl.h silu_mul_fp16, restated: PY/layers/mlp.py:68-73, PY/functional.py:521-532)
-__device__ __forceinline__ float silu_mul_fp16_f(float g, float u)
-{
-    const float g16 = h2f(f2h(g));
-    const float u16 = h2f(f2h(u));
-    const float a = h2f(f2h(g16 / (1.f + __expf(-g16))));
-    return h2f(f2h(a * u16));
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// r06: the gate|up workgroups.  The launch carries, behind the heads' 8 x H workgroups, as many again that do nothing but the
-// layer's NEXT GEMV - RMSNorm(post_layernorm) + static quantiser of x1 = x + O(ctx), fc | gate rows, SwiGLU, static quantiser:
-// gemv_kernel<W_INT8_SQ, PK_NORM, EK_SWIGLU> restated value for value (same summation order in the prologue, exact integer dots,
-// the same epilogue expression) - so that this GEMV's weight stream no longer waits for a kernel boundary behind the attention's
-// dependent chain.  They never poll before their first two weight tiles per wave are REQUESTED (128 KB per CU, 32 MB on the chip,
-// requested `m_delay_ticks` after the workgroup's start: by then the projection's own stream is mostly through the CU's in-order
-// queue); the look at the 2048 x1 granules sits behind those tiles in each wave's queue and returns when they have landed.
-// Residency: the launch is 2 x CUs workgroups of 512 threads at <= 128 VGPRs and < 80 KB of LDS - two per CU, all resident
-// whatever the dispatch order (the launcher checks the occupancy query against the grid).
-// Reference: GatedMLP.forward (PY/layers/mlp.py:43-73) behind RmsNorm (PY/layers/normalization.py:33-54) and the static
-// quantiser (K/quantization.cu:31-59); SmoothQuant epilogue cutlass_extensions/.../epilogue_per_row_per_col_scale.h:279-347.
-__device__ __forceinline__ void mlp_gate_up_role(const FusedQkvAttnParams& p, char* smem, uint32_t tag, const gu64* gx1, int b, int nb)
-{
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid) >> 6;
-    const int K = p.K;
-    char* xs = smem;                                                 // [K] s8: the quantised operand
-    float* red = reinterpret_cast<float*>(smem + 4096);              // [64]
-    uint32_t* x1s = reinterpret_cast<uint32_t*>(smem + 4096 + 256);  // [K / 2]: x1 as fp16 pairs
-    float* give_up = red + 40;
-    const uint64_t t_start = wall_clock64();
-    if (p.timing && lane == 0 && wid == 0)
-        p.timing[(size_t) blockIdx.x * 16 + 0] = t_start;
-    // launch constants (scalar loads) and this thread's gamma vector
-    const float pro_q = p.m_act_quant[0];
-    const float rs_fc = p.m_row_fc[0];
-    const float rs_gate = p.m_row_gate ? p.m_row_gate[0] : rs_fc;
-    const float epi_q = p.m_out_quant[0];
-    const uint4 gv = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.m_gamma) + tid * 8);
-    const float* sc_fc = reinterpret_cast<const float*>(p.m_scale_fc);
-    const float* sc_gate = reinterpret_cast<const float*>(p.m_scale_gate);
-    // this wave's row groups (output n: fc row n, gate row n): n = g0, g0 + gstride, ...
-    const int g0 = b * kWavesF + wid, gstride = nb * kWavesF;
-    const int ng = g0 < p.m_n ? (p.m_n - g0 + gstride - 1) / gstride : 0;
-    const char* wfc = reinterpret_cast<const char*>(p.m_w_fc);
-    const char* wgt = reinterpret_cast<const char*>(p.m_w_gate);
-    auto load_tile = [&](int i, uint4 (&wv)[kKChunks][2]) {
-        int n = g0 + i * gstride;
-        n = n < p.m_n ? n : p.m_n - 1; // (a wave without a further group: a clamped, valid tile that nobody consumes)
-#pragma unroll
-        for (int u = 0; u < kKChunks; ++u)
-        {
-            wv[u][0] = ld_nt16(wfc + (int64_t) n * p.m_ldw + u * 1024 + lane * 16);
-            wv[u][1] = ld_nt16(wgt + (int64_t) n * p.m_ldw + u * 1024 + lane * 16);
-        }
-    };
-    if (tid == 0)
-        *give_up = 0.f;
-    // not at once: the heads' workgroups on this CU are streaming their q / k / v rows through the same in-order queue
-    while (wall_clock64() - t_start < (uint64_t) p.m_delay_ticks)
-        __builtin_amdgcn_s_sleep(16);
-    uint4 wv[kKChunks][2], wv2[kKChunks][2];
-    __builtin_amdgcn_sched_barrier(0);
-    const int pre = p.m_prefetch_tiles; // uniform: tiles per wave requested AHEAD of x1 (0, 1 or 2)
-    if (pre >= 1)
-        load_tile(0, wv);
-    if (pre >= 2)
-        load_tile(1, wv2);
-    __builtin_amdgcn_sched_barrier(0);
-    if (p.timing && lane == 0 && wid == 0)
-        p.timing[(size_t) blockIdx.x * 16 + 1] = wall_clock64();
-    // ---- x1 = x + O(ctx): 2048 granules {tag, 2 x fp16}, four per thread, requested behind the tiles
-    {
-        const gu64* gbase = gx1 + tid;
-        unsigned long long g[4];
-        int spins = 0;
-        for (;;)
-        {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                g[i] = ld_granule(gbase + 512 * i);
-            __builtin_amdgcn_sched_barrier(0);
-            uint32_t bad = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                bad |= (uint32_t) (g[i] >> 32) ^ tag;
-            if (__all(bad == 0))
-                break;
-            if (++spins > p.max_spins)
-            {
-                if (lane == 0)
-                    *give_up = 1.f;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        if (p.timing && lane == 0 && wid == 0)
-            p.timing[(size_t) blockIdx.x * 16 + 12] = (uint64_t) spins;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            x1s[tid + 512 * i] = (uint32_t) g[i];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (pre < 1)
-        load_tile(0, wv);
-    if (pre < 2)
-        load_tile(1, wv2);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    if (p.timing && lane == 0 && wid == 0)
-        p.timing[(size_t) blockIdx.x * 16 + 2] = wall_clock64();
-    if (*give_up != 0.f) // uniform
-    {
-        if (tid == 0)
-            atomicOr(p.error, 8u);
-        return;
-    }
-    // ---- RMSNorm + static quantiser -> LDS: the 256-thread prologue of gemv_impl.h (PK_NORM, MB = 1, two vectors per thread)
-    //      restated on 512 threads as in the heads' workgroups (threads >= 256 repeat the first half's sums)
-    {
-        const int t2 = tid & 255;
-        const uint4 xa = *reinterpret_cast<const uint4*>(x1s + t2 * 4);
-        const uint4 xb = *reinterpret_cast<const uint4*>(x1s + (t2 + 256) * 4);
-        float ss = 0.f;
-        const uint32_t w8[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-        {
-            const h2_t hh = u32_as_h2(w8[q]);
-            const float f0 = (float) hh.x, f1 = (float) hh.y;
-            ss += f0 * f0 + f1 * f1;
-        }
-        ss = wave_sum(ss);
-        if (lane == 0 && wid < 4)
-            red[wid] = ss;
-        __syncthreads();
-        ss = red[0] + red[1] + red[2] + red[3];
-        const float inv = 1.0f / sqrtf(ss / (float) K + p.eps);
-        uint32_t xs4[4] = {tid < 256 ? xa.x : xb.x, tid < 256 ? xa.y : xb.y, tid < 256 ? xa.z : xb.z, tid < 256 ? xa.w : xb.w};
-        const uint32_t gs4[4] = {gv.x, gv.y, gv.z, gv.w};
-        uint32_t o[2] = {0, 0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-        {
-            h2_t hh = u32_as_h2(xs4[q]);
-            const h2_t gg = u32_as_h2(gs4[q]);
-            const float n0 = h2f(f2h((float) hh.x * inv)), n1 = h2f(f2h((float) hh.y * inv));
-            hh.x = (_Float16) (n0 * (float) gg.x);
-            hh.y = (_Float16) (n1 * (float) gg.y);
-            const uint32_t b0 = (uint8_t) f2i8_rni_sat((float) hh.x * pro_q);
-            const uint32_t b1 = (uint8_t) f2i8_rni_sat((float) hh.y * pro_q);
-            o[q >> 1] |= (b0 | (b1 << 8)) << (16 * (q & 1));
-        }
-        *reinterpret_cast<uint2*>(xs + tid * 8) = make_uint2(o[0], o[1]);
-    }
-    __syncthreads();
-    if (p.timing && lane == 0 && wid == 0)
-        p.timing[(size_t) blockIdx.x * 16 + 3] = wall_clock64();
-    if (b == 0 && p.m_x_pro_out) // tap: the int8 operand exactly as the dots consume it
-        for (int k = tid; k < K / 4; k += 512)
-            reinterpret_cast<uint32_t*>(p.m_x_pro_out)[k] = reinterpret_cast<const uint32_t*>(xs)[k];
-    // ---- the row groups, two tiles in flight per wave
-    auto step = [&](int i, uint4 (&cur)[kKChunks][2]) {
-        const int n = g0 + i * gstride;
-        const float s0 = sc_fc[p.m_per_channel ? n : 0], s1 = sc_gate[p.m_per_channel ? n : 0]; // wave-uniform: scalar loads
-        int a0 = 0, a1 = 0;
-#pragma unroll
-        for (int u = 0; u < kKChunks; ++u)
-        {
-            const uint4 xr = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * 16);
-            a0 = sdot4(cur[u][0].x, xr.x, a0);
-            a0 = sdot4(cur[u][0].y, xr.y, a0);
-            a0 = sdot4(cur[u][0].z, xr.z, a0);
-            a0 = sdot4(cur[u][0].w, xr.w, a0);
-            a1 = sdot4(cur[u][1].x, xr.x, a1);
-            a1 = sdot4(cur[u][1].y, xr.y, a1);
-            a1 = sdot4(cur[u][1].z, xr.z, a1);
-            a1 = sdot4(cur[u][1].w, xr.w, a1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 2 < ng) // wave-uniform: the tile after next, into the registers just consumed
-            load_tile(i + 2, cur);
-        __builtin_amdgcn_sched_barrier(0);
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        // epilogue of gemv_impl.h (EPI_SWIGLU_QSTATIC): fp16 rounding points of the reference graph, then the static quantiser
-        const float r0 = (float) a0 * (s0 * rs_fc);
-        const float o16 = silu_mul_fp16_f(r0, (float) a1 * (s1 * rs_gate));
-        if (lane == 0)
-            reinterpret_cast<int8_t*>(p.m_out)[n] = f2i8_rni_sat(o16 * epi_q);
-    };
-    for (int i = 0; i < ng;)
-    {
-        step(i, wv);
-        if (++i >= ng)
-            break;
-        step(i, wv2);
-        ++i;
-    }
-    if (p.timing && lane == 0 && wid == 0)
-        p.timing[(size_t) blockIdx.x * 16 + 4] = wall_clock64();
-}
-
 // WOQ (r05): weight-only int8 projection weights (u8 = q + 128, fp16 per-channel scales) against the NORMALISED fp16 row - no
 // quantiser in the prologue, raw byte splices in the dots (1024 + u), 1152 * sum(x) taken off once per row: the arithmetic and
 // the summation order of gemv_impl.h's W_INT8_WOQ path, so the projection is bit-identical to the unfused GEMV.  Two-stage form only.
-// MLP (r06): the launch carries the gate|up workgroups (mlp_gate_up_role) behind the heads' - two workgroups per CU, so the
-// kernel is held to 128 VGPRs; the row workers then keep their dense-projection rows in REGISTERS (no dynamic LDS) and publish
-// x + O(ctx) a second time, as tagged fp16 pairs.
-template <int NIT, bool INT8KV, bool WOQ = false, bool MLP = false>
-__global__ __launch_bounds__(512, MLP ? 4 : 1) void qkv_attn_fused_kernel(const FusedQkvAttnParams p)
+template <int NIT, bool INT8KV, bool WOQ = false>
+__global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnParams p)
 {
     constexpr int EPL = INT8KV ? 16 : 8; // cache elements per lane (16 bytes)
     constexpr int LPR = kDH / EPL;       // lanes per cache row
@@ -427,16 +220,6 @@ __global__ __launch_bounds__(512, MLP ? 4 : 1) void qkv_attn_fused_kernel(const 
     // everything behind that launch is invalid anyway - do not spin again, layer after layer, step after step
     if (p.error[0] != 0u) // uniform (scalar load)
         return;
-    if constexpr (MLP)
-    {
-        const int heads_grid = p.num_heads * kMembers;
-        if ((int) blockIdx.x >= heads_grid) // uniform: a gate|up workgroup
-        {
-            const gu64* gx1 = (const gu64*) p.xchg + (size_t) p.num_heads * (kHeadGranules + kCtxGranulesH);
-            mlp_gate_up_role(p, smem, tag, gx1, (int) blockIdx.x - heads_grid, (int) gridDim.x - heads_grid);
-            return;
-        }
-    }
     const int tl = p.sequence_length[0]; // slots in use; the current token goes to slot tl
     const int Smax = p.max_seq_len;
     const bool q_dyn = p.act_quant_scale == nullptr;
@@ -449,10 +232,8 @@ __global__ __launch_bounds__(512, MLP ? 4 : 1) void qkv_attn_fused_kernel(const 
     const bool o_stage = p.o_w != nullptr; // uniform
     const int o_workers = (kMembers - 1) * H;
     const int o_j = (mem - 1) * H + h;
-    // (MLP: ranges of whole row PAIRS - x + O(ctx) travels to the gate|up workgroups as one granule per pair)
-    const int o_r0 = !(o_stage && mem) ? 0 : MLP ? 2 * (int) ((int64_t) o_j * (p.o_n / 2) / o_workers) : (int) ((int64_t) o_j * p.o_n / o_workers);
-    const int o_r1 = !(o_stage && mem) ? 0
-        : MLP ? 2 * (int) ((int64_t) (o_j + 1) * (p.o_n / 2) / o_workers) : (int) ((int64_t) (o_j + 1) * p.o_n / o_workers);
+    const int o_r0 = o_stage && mem ? (int) ((int64_t) o_j * p.o_n / o_workers) : 0;
+    const int o_r1 = o_stage && mem ? (int) ((int64_t) (o_j + 1) * p.o_n / o_workers) : 0;
     float o_cs[3], o_res[3];
     float o_rs = 1.f;
 #pragma unroll
@@ -545,26 +326,6 @@ __global__ __launch_bounds__(512, MLP ? 4 : 1) void qkv_attn_fused_kernel(const 
         }
         __syncthreads();
         ss = red[0] + red[1] + red[2] + red[3];
-        if constexpr (MLP)
-        {
-            // two workgroups per CU = 128 VGPRs: the wave-uniform launch constants (vector loads at the kernel's top, all answered
-            // by now: x arrived behind them) move to SGPRs - left in VGPRs, the allocator spilled the cache scales at the TOP of
-            // the kernel, behind a full s_waitcnt
-            auto to_sgpr = [](float& v) { v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
-            to_sgpr(pro_q);
-            to_sgpr(deq);
-            to_sgpr(s_oq);
-            to_sgpr(s_qo);
-            to_sgpr(o_rs);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-            {
-                to_sgpr(o_cs[i]);
-                to_sgpr(o_res[i]);
-                to_sgpr(cscale[i][0]);
-                to_sgpr(cscale[i][1]);
-            }
-        }
         const float inv = 1.0f / sqrtf(ss / (float) K + p.eps);
         // this thread's own vector: tid * 8 (threads < 256: vector a, the others: vector b)
         uint32_t xs4[4] = {tid < 256 ? xa.x : xb.x, tid < 256 ? xa.y : xb.y, tid < 256 ? xa.z : xb.z, tid < 256 ? xa.w : xb.w};
@@ -914,25 +675,7 @@ __global__ __launch_bounds__(512, MLP ? 4 : 1) void qkv_attn_fused_kernel(const 
     // O-projection stage, row workers: waves 3 - 7 (no part in the publication below) request the worker's rows of the dense
     // projection by LDS-DMA NOW - the CU's load queue is empty, and the 3 - 4 us until the context rows arrive are what the
     // 16 MB of weights take (row slot s of the worker -> wave 3 + s % 5)
-    // (MLP: every wave takes ITS rows - slots wid, wid + 8, wid + 16 - into registers; the LDS stays free for a second workgroup)
-    uint4 wo[MLP ? 3 : 1][kKChunks];
-    if constexpr (MLP)
-    {
-        if (o_stage && mem != 0) // uniform
-        {
-            const char* owb = reinterpret_cast<const char*>(p.o_w);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-            {
-                const int row = min(o_r0 + wid + 8 * i, o_r1 - 1); // (a slot beyond the range: a valid row, result dropped)
-#pragma unroll
-                for (int u = 0; u < kKChunks; ++u)
-                    wo[i][u] = ld_nt16(owb + (int64_t) row * p.o_ldw + u * 1024 + lane * 16);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    else if (o_stage && mem != 0 && wid >= 3)
+    if (o_stage && mem != 0 && wid >= 3)
     {
         const uint32_t wo_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) void*) wo_lds;
         const char* owb = reinterpret_cast<const char*>(p.o_w);
@@ -1060,11 +803,7 @@ __global__ __launch_bounds__(512, MLP ? 4 : 1) void qkv_attn_fused_kernel(const 
             for (int i = 0; i < 3; ++i)
             {
                 const int slot = wid + 8 * i < o_r1 - o_r0 ? wid + 8 * i : 0; // (a row that does not exist: slot 0, result dropped)
-                uint4 wv;
-                if constexpr (MLP)
-                    wv = wo[i][u];
-                else
-                    wv = *reinterpret_cast<const uint4*>(wo_lds + (slot * kKChunks + u) * 1024 + lane * 16);
+                const uint4 wv = *reinterpret_cast<const uint4*>(wo_lds + (slot * kKChunks + u) * 1024 + lane * 16);
                 if constexpr (WOQ)
                     acc[i] = dot_woq8_raw(wv, xr, xr2, acc[i]);
                 else
@@ -1088,19 +827,8 @@ __global__ __launch_bounds__(512, MLP ? 4 : 1) void qkv_attn_fused_kernel(const 
             const float a = (float) (i == 0 ? acc[0] : (i == 1 ? acc[1] : acc[2])) - obias;
             const float cs_i = i == 0 ? o_cs[0] : (i == 1 ? o_cs[1] : o_cs[2]);
             const float rs_i = i == 0 ? o_res[0] : (i == 1 ? o_res[1] : o_res[2]);
-            const uint16_t h16 = f2h(h2f(f2h(a * (cs_i * o_rs))) + rs_i);
             if (row < o_r1)
-                reinterpret_cast<uint16_t*>(p.x_out)[row] = h16;
-            if constexpr (MLP)
-                reinterpret_cast<uint16_t*>(wpart)[wid + 8 * i] = h16; // (the wave partials are long consumed: barrier behind the sweep)
-        }
-        if constexpr (MLP)
-        {
-            // x1 = x + O(ctx) once more, for the gate|up workgroups of this launch: one tagged granule per row pair
-            __syncthreads();
-            if (tid < (o_r1 - o_r0) / 2)
-                st_granule((gu64*) p.xchg + (size_t) H * (kHeadGranules + kCtxGranulesH) + o_r0 / 2 + tid, tag,
-                    reinterpret_cast<const uint32_t*>(wpart)[tid]);
+                reinterpret_cast<uint16_t*>(p.x_out)[row] = f2h(h2f(f2h(a * (cs_i * o_rs))) + rs_i);
         }
         TLLM_STAMP(10);
         return;
@@ -1259,37 +987,27 @@ __global__ __launch_bounds__(512, MLP ? 4 : 1) void qkv_attn_fused_kernel(const 
 }
 #undef TLLM_STAMP
 
-// the instance that serves (nit, cache type, weight type, with / without the gate|up workgroups)
-template <bool INT8KV, bool WOQ, bool MLP>
+// the instance that serves (cache rows per lane group, cache type, weight type)
+template <bool INT8KV, bool WOQ>
 const void* fused_kernel_of(int nit)
 {
     switch (nit)
     {
-    case 1: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<1, INT8KV, WOQ, MLP>);
-    case 2: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<2, INT8KV, WOQ, MLP>);
-    case 3: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<3, INT8KV, WOQ, MLP>);
-    default: break;
+    case 1: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<1, INT8KV, WOQ>);
+    case 2: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<2, INT8KV, WOQ>);
+    case 3: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<3, INT8KV, WOQ>);
+    case 4: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<4, INT8KV, WOQ>);
+    case 6: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<6, INT8KV, WOQ>);
+    case 8: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<8, INT8KV, WOQ>);
+    default: return nullptr;
     }
-    if constexpr (!MLP) // (the gate|up workgroups need <= 128 VGPRs: built up to 3 cache rows per lane group)
-    {
-        switch (nit)
-        {
-        case 4: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<4, INT8KV, WOQ, false>);
-        case 6: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<6, INT8KV, WOQ, false>);
-        case 8: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<8, INT8KV, WOQ, false>);
-        default: break;
-        }
-    }
-    return nullptr;
 }
 
-const void* fused_kernel(int nit, bool int8_kv, bool woq, bool mlp)
+const void* fused_kernel(int nit, bool int8_kv, bool woq)
 {
-    if (mlp)
-        return woq ? nullptr : (int8_kv ? fused_kernel_of<true, false, true>(nit) : fused_kernel_of<false, false, true>(nit));
     if (woq)
-        return int8_kv ? fused_kernel_of<true, true, false>(nit) : fused_kernel_of<false, true, false>(nit);
-    return int8_kv ? fused_kernel_of<true, false, false>(nit) : fused_kernel_of<false, false, false>(nit);
+        return int8_kv ? fused_kernel_of<true, true>(nit) : fused_kernel_of<false, true>(nit);
+    return int8_kv ? fused_kernel_of<true, false>(nit) : fused_kernel_of<false, false>(nit);
 }
 
 // Per-DEVICE launch state (a process may hold sessions on devices with different CU counts): the CU count, which
@@ -1341,11 +1059,10 @@ int device_cus()
     return dev_state_locked().cus;
 }
 
-size_t fused_dyn_lds(bool o_stage, bool mlp)
+size_t fused_dyn_lds(bool o_stage)
 {
-    // O-projection stage: the row worker's rows of the dense projection live in dynamic LDS (<= 24 rows x K bytes) - with the
-    // gate|up workgroups in registers instead
-    return o_stage && !mlp ? (size_t) kORowsMax * kKChunks * 1024 : 0;
+    // O-projection stage: the row worker's rows of the dense projection live in dynamic LDS (<= 24 rows x K bytes)
+    return o_stage ? (size_t) kORowsMax * kKChunks * 1024 : 0;
 }
 
 int pick_nit(int max_seq_len, bool int8_kv)
@@ -1362,7 +1079,7 @@ int pick_nit(int max_seq_len, bool int8_kv)
 
 size_t qkv_attn_fused_xchg_bytes(int32_t num_heads)
 {
-    return ((size_t) num_heads * (kHeadGranules + kCtxGranulesH) + kX1Granules) * sizeof(uint64_t);
+    return (size_t) num_heads * (kHeadGranules + kCtxGranulesH) * sizeof(uint64_t);
 }
 
 // the O-projection stage: K = H * Dh = 4 KiB rows (the context row is swept by 512 threads x two granules), every row worker's
@@ -1375,38 +1092,32 @@ bool qkv_attn_fused_serves_o(int32_t num_heads, int32_t head_size, int32_t o_n, 
 }
 
 bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int32_t max_seq_len, int32_t int8_kv, int32_t woq8,
-    int32_t stages)
+    int32_t o_stage)
 {
     const int nit = pick_nit(max_seq_len, int8_kv != 0);
     if (K != kKChunks * 1024 || head_size != kDH || nit == 0)
         return false;
-    const bool o_stage = (stages & 1) != 0, mlp = (stages & 2) != 0;
-    if (mlp && !o_stage)
-        return false;
-    const void* kfn = fused_kernel(nit, int8_kv != 0, woq8 != 0, mlp);
+    const void* kfn = fused_kernel(nit, int8_kv != 0, woq8 != 0);
     if (!kfn)
         return false;
-    // every workgroup of a head waits for its siblings (and the gate|up workgroups for the row workers): the whole grid must be
-    // RESIDENT AT ONCE.  The occupancy query (with this instance's registers and its dynamic LDS) x the CU count of THIS device
-    // must cover the grid; and the launch only pays when the heads' workgroups fill most of the chip.  (What the query cannot
-    // see - another queue's kernels holding CUs - is what the bounded waits and the session's fall-back are for.)
+    // every workgroup of a head waits for its siblings (and the row workers for every head's merger): the whole grid must be
+    // RESIDENT AT ONCE.  The occupancy query (this instance's registers, its dynamic LDS) x the CU count of THIS device must cover
+    // the grid; and the launch only pays when it fills most of the chip.  (What the query cannot see - another queue's kernels
+    // holding CUs - is what the bounded waits and the session's fall-back + retry are for.)
     const int cus = device_cus();
-    const int heads_grid = num_heads * kMembers;
-    const int grid = heads_grid + (mlp ? cus : 0);
-    if (heads_grid > cus || heads_grid * 4 < cus * 3)
+    const int grid = num_heads * kMembers;
+    if (grid > cus || grid * 4 < cus * 3)
         return false;
-    if (mlp && heads_grid != cus)
-        return false;
-    return resident_capacity(kfn, fused_dyn_lds(o_stage, mlp)) >= grid;
+    return resident_capacity(kfn, fused_dyn_lds(o_stage != 0)) >= grid;
 }
 
 int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream)
 {
-    const bool o_stage = p.o_w != nullptr, mlp = p.m_w_fc != nullptr;
-    if (!qkv_attn_fused_serves(p.K, p.num_heads, p.head_size, p.max_seq_len, p.int8_kv, p.woq8, (o_stage ? 1 : 0) | (mlp ? 2 : 0)))
+    const bool o_stage = p.o_w != nullptr;
+    if (!qkv_attn_fused_serves(p.K, p.num_heads, p.head_size, p.max_seq_len, p.int8_kv, p.woq8, o_stage ? 1 : 0))
     {
-        set_error("fused QKV + attention: shape not served or grid not resident (K %d, heads %d x %d, cache %d, stages %d)", p.K,
-            p.num_heads, p.head_size, p.max_seq_len, (o_stage ? 1 : 0) | (mlp ? 2 : 0));
+        set_error("fused QKV + attention: shape not served or grid not resident (K %d, heads %d x %d, cache %d, O stage %d)", p.K,
+            p.num_heads, p.head_size, p.max_seq_len, o_stage ? 1 : 0);
         return -1;
     }
     if (!p.x || !p.gamma || !p.w || !p.scale_col || !p.kv_cache || !p.sequence_length || !p.rope_row || !p.xchg || !p.error || !p.out
@@ -1429,20 +1140,11 @@ int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream)
         set_error("fused QKV + attention: the weight-only form has no quantiser");
         return -1;
     }
-    if (mlp
-        && (!p.m_gamma || !p.m_act_quant || !p.m_w_gate || !p.m_scale_fc || !p.m_scale_gate || !p.m_row_fc || !p.m_out_quant || !p.m_out
-            || p.m_n <= 0 || p.m_ldw % 16 || p.m_ldw < p.K || p.o_n != p.K || p.o_n % 2))
-    {
-        set_error("fused QKV + attention: the gate|up workgroups need static SmoothQuant operands of K = %d", p.K);
-        return -1;
-    }
-    const int nit = pick_nit(p.max_seq_len, p.int8_kv != 0);
-    const void* kfn = fused_kernel(nit, p.int8_kv != 0, p.woq8 != 0, mlp);
-    const int heads_grid = p.num_heads * kMembers;
-    const dim3 grid(heads_grid + (mlp ? device_cus() : 0)), block(64 * kWavesF);
+    const void* kfn = fused_kernel(pick_nit(p.max_seq_len, p.int8_kv != 0), p.int8_kv != 0, p.woq8 != 0);
+    const dim3 grid(p.num_heads * kMembers), block(64 * kWavesF);
     FusedQkvAttnParams q = p;
     void* args[] = {&q};
-    const hipError_t e = hipLaunchKernel(kfn, grid, block, args, fused_dyn_lds(o_stage, mlp), stream);
+    const hipError_t e = hipLaunchKernel(kfn, grid, block, args, fused_dyn_lds(o_stage), stream);
     if (e != hipSuccess)
     {
         set_error("fused QKV + attention launch failed: %s", hipGetErrorString(e));

@@ -220,12 +220,6 @@ struct tllm_session
     // ... and the O-projection + residual of the layer as a third stage of that launch (static SmoothQuant: the context row
     // travels as its int8 image); session key fuse_o_projection = 0 keeps the GEMV launch
     int fuse_o_cfg = -1;
-    // ... and (r06) RMSNorm + gate|up + SwiGLU as CU-count more workgroups of that launch; session key fuse_mlp_front = 0 keeps the
-    // GEMV launch, fused_mlp_delay = ticks of 10 ns a gate|up workgroup waits before it requests weights
-    int fuse_mlp_cfg = -1;
-    int fused_mlp_delay = -1;
-    int fused_mlp_tiles = -1;
-    bool mlp_fused = false;
     int fused_retries = 0;          // requests tllm_session_generate ran a second time behind an expired in-launch wait
     int fused_max_spins = -1;       // session key fused_max_spins: bound of the in-launch waits (tests: 0 = the first miss times out)
     bool o_fused = false;
@@ -961,28 +955,6 @@ struct tllm_session
                         f.o_scale_col = L.dense.scale_col;
                         f.o_scale_row = L.dense.act_scale;
                         f.x_out = x;
-                        if (mlp_fused)
-                        {
-                            // K5 as workgroups of the same launch (they read x + O(ctx) from the row workers' granules)
-                            f.m_gamma = L.ln2;
-                            f.m_act_quant = L.ln2_scale;
-                            f.m_w_fc = L.fc.w;
-                            f.m_w_gate = L.gate.w;
-                            f.m_ldw = L.fc.ldw;
-                            f.m_n = L.fc.N;
-                            f.m_per_channel = L.fc.per_channel;
-                            f.m_scale_fc = L.fc.scale_col;
-                            f.m_scale_gate = L.gate.scale_col;
-                            f.m_row_fc = L.fc.act_scale;
-                            f.m_row_gate = L.gate.act_scale;
-                            f.m_out_quant = L.mlp_qscale;
-                            f.m_out = q8;
-                            f.m_x_pro_out = taps ? tap_ptr(2, li) : nullptr;
-                            if (fused_mlp_delay >= 0)
-                                f.m_delay_ticks = fused_mlp_delay;
-                            if (fused_mlp_tiles >= 0)
-                                f.m_prefetch_tiles = fused_mlp_tiles;
-                        }
                     }
                     RUN(timed(PC_ATTENTION, st, [&] { return launch_qkv_attn_fused(f, st) ? 1 : 0; }));
                 }
@@ -1088,11 +1060,7 @@ struct tllm_session
             }
             // K5
             const bool q_inter = sq && !per_token;
-            if (qkv_attn_fused && o_fused && mlp_fused && ok < 0)
-            {
-                // K5 ran as the gate|up workgroups of the fused launch: q8 already holds the quantised SwiGLU row
-            }
-            else if (ok < 0 || ok == 5)
+            if (ok < 0 || ok == 5)
             {
                 int rc5;
                 if (fused_ar)
@@ -1195,9 +1163,6 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->fuse_qkv_cfg = geti("fuse_qkv_attention", -1);
     s->fuse_o_cfg = geti("fuse_o_projection", -1);
     s->fused_max_spins = geti("fused_max_spins", -1);
-    s->fuse_mlp_cfg = geti("fuse_mlp_front", -1);
-    s->fused_mlp_delay = geti("fused_mlp_delay", -1);
-    s->fused_mlp_tiles = geti("fused_mlp_tiles", -1);
     s->fused_timeline = geti("fused_timeline", 0) != 0;
     if (kv.count("gemm_tactics") && !kv["gemm_tactics"].empty())
     {
@@ -1654,7 +1619,6 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
     s->fused_err = s->step_epoch + 8;
     s->qkv_attn_fused = false;
     s->o_fused = false;
-    s->mlp_fused = false;
     s->fused_xchg = nullptr;
     // (SmoothQuant, or - r05 - weight-only int8: the same 4 KB weight rows against the normalised fp16 row)
     const bool woq8_all = !s->sq && !s->layers.empty() && s->layers[0].qkv.wtype == W_INT8_WOQ;
@@ -1677,26 +1641,17 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
                 s->o_fused = s->o_fused && L.dense.N == D && L.dense.scale_col
                     && (s->sq ? (L.dense.wtype == W_INT8_SQ && L.dense.act_scale && L.attn_qscale) : L.dense.wtype == W_INT8_WOQ)
                     && qkv_attn_fused_serves_o(s->Hr, s->Dh, L.dense.N, L.dense.K, L.dense.ldw);
-            // r06: + the gate|up workgroups (static SmoothQuant; the instance is held to 128 VGPRs and is built up to 3 cache rows
-            // per lane group: caches of up to 1536 slots (int8) - beyond, the GEMV launch stays)
-            s->mlp_fused = s->o_fused && s->sq && !s->per_token && s->fuse_mlp_cfg != 0;
-            for (auto& L : s->layers)
-                s->mlp_fused = s->mlp_fused && L.fc.wtype == W_INT8_SQ && L.gate.wtype == W_INT8_SQ && L.fc.K == D && L.gate.K == D
-                    && L.fc.N == L.gate.N && L.fc.ldw == L.gate.ldw && L.fc.ldw % 16 == 0 && L.fc.per_channel == L.gate.per_channel
-                    && L.fc.scale_col && L.gate.scale_col && L.fc.act_scale && L.ln2_scale && L.mlp_qscale && L.dense.N % 2 == 0;
-            s->mlp_fused = s->mlp_fused && qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, 0, 3);
             // ... and the instance that will run must be resident as a whole (occupancy query x CUs of this device >= its grid)
-            if (!qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, s->sq ? 0 : 1, (s->o_fused ? 1 : 0) | (s->mlp_fused ? 2 : 0)))
+            if (!qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, s->sq ? 0 : 1, s->o_fused ? 1 : 0))
             {
-                s->mlp_fused = false;
-                s->o_fused = s->o_fused && qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, s->sq ? 0 : 1, 1);
-                s->qkv_attn_fused = qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, s->sq ? 0 : 1, s->o_fused ? 1 : 0);
+                s->o_fused = false;
+                s->qkv_attn_fused = qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, s->sq ? 0 : 1, 0);
             }
             s->fused_timing = nullptr;
             if (s->fused_timeline)
             {
-                RUN(s->dalloc(&s->fused_timing, (size_t) s->Hr * 8 * 2 * 16 * 8));
-                HIP_OK(hipMemset(s->fused_timing, 0, (size_t) s->Hr * 8 * 2 * 16 * 8));
+                RUN(s->dalloc(&s->fused_timing, (size_t) s->Hr * 8 * 16 * 8));
+                HIP_OK(hipMemset(s->fused_timing, 0, (size_t) s->Hr * 8 * 16 * 8));
             }
         }
     }
@@ -1727,7 +1682,6 @@ static int check_comm(tllm_session_t s)
             (void) hipMemset(s->fused_err, 0, 4);
             s->qkv_attn_fused = false; // later steps take the two-launch path
             s->o_fused = false;
-            s->mlp_fused = false;
             if (s->graph)
             {
                 (void) hipGraphExecDestroy(s->graph);
@@ -2309,7 +2263,7 @@ int32_t tllm_session_decode_form(tllm_session_t s)
 {
     if (!s || !s->B)
         return -1;
-    return (s->qkv_attn_fused ? 1 : 0) | (s->qkv_attn_fused && s->o_fused ? 2 : 0) | (s->qkv_attn_fused && s->o_fused && s->mlp_fused ? 4 : 0);
+    return (s->qkv_attn_fused ? 1 : 0) | (s->qkv_attn_fused && s->o_fused ? 2 : 0);
 }
 
 int32_t tllm_session_profile(tllm_session_t s, int32_t n_steps, float* ms_per_class, int64_t* launches_per_class,

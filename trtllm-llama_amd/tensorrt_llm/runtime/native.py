@@ -201,7 +201,7 @@ class NativeSession:
         return int(_lib().tllm_session_fused_retries(self._h))
 
     def decode_form(self) -> int:
-        """bit 0: QKV projection + attention in one launch, bit 1: + the O-projection stage, bit 2: + the gate|up workgroups"""
+        """bit 0: QKV projection + attention in one launch, bit 1: + the O-projection stage"""
         return int(_lib().tllm_session_decode_form(self._h))
 
     def time_kernel(self, which: str, sweeps: int = 4, stream: int = 0):
