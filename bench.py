@@ -49,6 +49,8 @@ def parse():
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
     ap.add_argument('--no-batch-sweep', dest='batch_sweep', action='store_false',
                     help='skip the side report of decode tokens/s at 4 and 8 sequences (N = 1 only; not part of the metric)')
+    ap.add_argument('--no-tp-prediction', dest='tp_prediction', action='store_false',
+                    help='skip the side report of one rank\'s step time at the tp = 2 / 4 / 8 extents without collectives')
     ap.add_argument('--no-parity', dest='parity', action='store_false',
                     help='skip the 7B accuracy report (GPU engines vs HF fp32 on the host CPU on identical weights)')
     ap.add_argument('--parity-new-tokens', type=int, default=128, help='new tokens per prompt of the accuracy report (SURVEY 8d: 128)')
@@ -297,6 +299,46 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     del weights
     torch.cuda.empty_cache()
     return res
+
+
+def tp_rank_prediction(torch, args, dev):
+    """Side report for the first multi-GPU run to be held against: ONE rank's generation step at the tensor-
+    parallel extents tp = 2 / 4 / 8 (heads, FFN columns, vocabulary / tp), timed on this one GPU WITHOUT its
+    collectives (session key no_comm: the all-reduces and the logits all-gather are skipped, every other launch is the rank's own).
+    tokens/s of the tp-way job = 1 / (this + the 64 all-reduces + the all-gather of a step); `hbm_floor_ms` = the rank's bytes at
+    6.3 TB/s.  Timing only - the hidden states are one rank's partial sums."""
+    from tensorrt_llm.runtime.native import NativeSession
+    out = {'note': 'one rank, no collectives (session key no_comm = 1), graph replay, this GPU; timing only'}
+    cfg = dict(LLAMA_7B, num_layers=args.layers)
+    qm = QM['sq'] | INT8_KV
+    stream = torch.cuda.current_stream().cuda_stream
+    for tp in (2, 4, 8):
+        try:
+            sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=tp, tp_rank=0, no_comm=1))
+            w = synth_weights(torch, cfg, 'sq', True, tp, 0, dev)
+            for k, v in w.items():
+                sess.set_tensor(k, v)
+            sess.finalize()
+            K = 64
+            sess.setup(1, args.context, K + 16)
+            sess.fake_context(args.context, seed=1, stream=stream)
+            sess.step(2, use_graph=False, stream=stream)
+            sess.step(4, use_graph=True, stream=stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sess.step(K, use_graph=True, stream=stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            nbytes = sess.step_bytes(args.context + 8 + K // 2)
+            out[f'tp{tp}'] = {'rank_ms_per_step_without_comm': dt * 1e3 / K, 'rank_hbm_bytes_per_step': nbytes,
+                              'hbm_floor_ms': nbytes / 6.3e12 * 1e3, 'tokens_per_s_if_comm_were_free': K / dt,
+                              'collectives_per_step': 2 * args.layers + 1}
+            sess.close()
+            del w
+            torch.cuda.empty_cache()
+        except Exception as e:  # the decode metric must not depend on the side report
+            out[f'tp{tp}'] = {'error': repr(e)}
+    return out
 
 
 def sq_gemm_mfma_report(torch, dev, M=1024):
@@ -746,6 +788,8 @@ def main():
         except Exception as e:  # the decode metric must not depend on the side report
             line.setdefault('sq_gemm_mfma', {'error': repr(e)})
             line['sq_gemm_mfma_large_m'] = {'error': repr(e)}
+    if world == 1 and args.config == 'sq' and getattr(args, 'tp_prediction', True):
+        line['tp_rank_prediction'] = tp_rank_prediction(torch, args, dev)
     if parity is not None:
         line['parity'] = parity
     if fp16 is not None:

@@ -187,7 +187,7 @@ def _forward(model, ids, lens, n_new, feed_ids=None, capture=None, taps=None, re
 
 
 def _fp16_model(cfg, w):
-    f = lambda k: w[k].astype(F32)
+    f = lambda k: np.asarray(w[k], dtype=F32)  # (no copy when the caller already holds fp32: the 65B-dimension tests are copy-bound)
     m = dict(cfg=cfg, sq=False, per_token=False, int8_kv=False, emb=f('vocab_embedding.weight'), lnf=f('ln_f.weight'),
              head=f('lm_head.weight'), layers=[])
     for i in range(cfg['num_layers']):
@@ -216,13 +216,12 @@ def quantise_model(cfg, w, mode, int8_kv, calib_ids, calib_lens, alpha=0.5):
     """mode in {fp16, woq8, woq4, sq_static, sq_static_pc, sq_dyn, sq_dyn_pc}.  Returns
     {'quant_mode', 'engine_tensors' (numpy, engine naming/layouts), 'oracle' (model for run_model)}."""
     L = cfg['num_layers']
-    base = _fp16_model(cfg, w)
     sq = mode.startswith('sq')
     woq_bits = {'woq8': 8, 'woq4': 4}.get(mode)
     per_token = 'dyn' in mode
     per_channel = mode.endswith('_pc')
     et = {k: w[k] for k in ('vocab_embedding.weight', 'ln_f.weight', 'lm_head.weight')}  # lm_head stays fp16
-    om = dict(base, sq=sq, per_token=per_token, int8_kv=bool(int8_kv), layers=[])
+    om = None  # filled from the (smoothed) fp16 model below
     qm = 0
     if woq_bits:
         qm = QM['INT4_WEIGHTS'] if woq_bits == 4 else QM['INT8_WEIGHTS']
@@ -236,7 +235,7 @@ def quantise_model(cfg, w, mode, int8_kv, calib_ids, calib_lens, alpha=0.5):
     work = {k: v.astype(F32) for k, v in w.items()}
     if sq:
         cap0 = {}
-        _forward(base, calib_ids, calib_lens, 1, capture=cap0)
+        _forward(_fp16_model(cfg, work), calib_ids, calib_lens, 1, capture=cap0)
         for i in range(L):
             p = f'layers.{i}.'
             (wq, ), s = O.smooth_gemm([work[p + 'attention.qkv.weight']], cap0[f'{i}.attention.qkv']['x'], alpha)
@@ -247,8 +246,10 @@ def quantise_model(cfg, w, mode, int8_kv, calib_ids, calib_lens, alpha=0.5):
             work[p + 'mlp.fc.weight'], work[p + 'mlp.gate.weight'] = O.f16(wf), O.f16(wg)
             work[p + 'post_layernorm.weight'] = O.f16(work[p + 'post_layernorm.weight'] / s2)
     smoothed = _fp16_model(cfg, work)
+    om = dict(smoothed, sq=sq, per_token=per_token, int8_kv=bool(int8_kv), layers=[])
     cap = {}
-    _forward(smoothed, calib_ids, calib_lens, 1, capture=cap)
+    if sq or int8_kv:  # activation ranges: the static SmoothQuant scales and the KV-cache scale (nothing else reads them)
+        _forward(smoothed, calib_ids, calib_lens, 1, capture=cap)
 
     for i in range(L):
         p = f'layers.{i}.'

@@ -67,6 +67,11 @@ def test_one_launch_generation_vs_oracle_across_the_envelope(mode, int8_kv, shap
         start = read_cache(s, 0, (1, 2, H, smax, DH), kv_dtype)
         if not int8_kv:
             assert np.isfinite(start.astype(np.float32)).all()
+        # the synthetic cache holds uniform random values up to vmax (int8: the full +-127 range x the dequantisation scale, several
+        # times what a real V row holds): the reference's absolute tolerances are stated for O(1) data and scale with it - the
+        # probabilities are rounded to fp16 relative to the lane group's own maximum here and to the row's in the oracle, a
+        # relative 2^-11 per term that does not average out over a 3-token context
+        vmax = max(1.0, float(np.abs(start[:, 1, :, :S].astype(np.float32)).max()) * (float(lw['kv_qo']) if int8_kv else 1.0))
         got_logits, got_taps = [], []
         for i in range(STEPS):
             s.step(1, use_graph=(i >= 2))
@@ -98,7 +103,7 @@ def test_one_launch_generation_vs_oracle_across_the_envelope(mode, int8_kv, shap
                     floor = dict(qkv_in=1.0, o_in=0.95, mlp_in=0.85, proj_in=0.85)[n]
                     assert d.max() <= dict(qkv_in=0, o_in=1, mlp_in=1, proj_in=2)[n] and same >= floor, (tag, n, int(d.max()), same)
                 else:
-                    tol = dict(qkv_in=(1e-3, 1e-3), o_in=(2e-3, 1e-3), mlp_in=(8e-3, 4e-3), proj_in=(8e-3, 8e-3))[n]
+                    tol = dict(qkv_in=(1e-3, 1e-3), o_in=(2e-3 * vmax, 1e-3), mlp_in=(8e-3 * vmax, 4e-3), proj_in=(8e-3 * vmax, 8e-3))[n]
                     np.testing.assert_allclose(g.astype(np.float32), w_.astype(np.float32), atol=tol[0], rtol=tol[1], err_msg=f'{tag} {n}')
             # the attention context before the O-projection's quantiser
             octx = taps['attn_ctx'][i][0][0]

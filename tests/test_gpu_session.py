@@ -4,6 +4,8 @@ sampler — against (a) the HF-CPU golden logits of tests/golden/hf_tiny_llama.n
 (atol 1e-1, T/tests/model/test_llama.py:286-288,352-354) and (b) the numpy oracle."""
 import os
 
+import functools
+
 import numpy as np
 import pytest
 
@@ -189,7 +191,9 @@ def test_tp_collectives_inside_the_captured_graph_single_rank():
         assert lib.tllm_comm_destroy_all() == 0
 
 
+@functools.lru_cache(maxsize=4)
 def synth_model(seed, L=2, H=4, D=256, I=512, V=512):
+    """(cached: a 7B- / 65B-dimension layer is drawn once per process, not once per parametrisation - callers do not modify it)"""
     r = np.random.default_rng(seed)
     xav = lambda n, k: r.uniform(-1, 1, (n, k)) * np.sqrt(6.0 / (n + k)) * 2
     w = {'vocab_embedding.weight': r.standard_normal((V, D)) * 0.5, 'ln_f.weight': 1 + 0.1 * r.uniform(-1, 1, D),

@@ -377,7 +377,8 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void glds16(const void* gptr, uint32_t lds_byte)
 {
     // inline asm on purpose: see gemm_glds.hip (the builtin makes hipcc drain the DMA before the next ds_read)
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
+    uint32_t m0_keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(gptr), "s"(lds_byte) : "memory");
 }
 
 __device__ __forceinline__ int swz128(int row, int c16)

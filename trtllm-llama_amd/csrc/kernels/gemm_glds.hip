@@ -52,13 +52,15 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 // that publishes the tile).
 __device__ __forceinline__ void glds16(const void* gptr, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
+    uint32_t m0_keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(gptr), "s"(lds_byte) : "memory");
 }
 
 // the same from a wave-uniform base + a per-lane 32-bit offset
 __device__ __forceinline__ void glds16s(const char* base, uint32_t off, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
+    uint32_t m0_keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(off), "s"(base), "s"(lds_byte) : "memory");
 }
 
 // byte offset of 16-byte piece c16 of tile row `row`: XOR swizzle so that the 16 lanes of a ds_read_b128 phase

@@ -43,19 +43,22 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // one LDS-DMA instruction: 64 lanes x 16 bytes, global (wave-uniform base + per-lane 32-bit offset) -> LDS [m0 + lane * 16]
 __device__ __forceinline__ void glds16s(const char* base, uint32_t off, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
+    uint32_t m0_keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(off), "s"(base), "s"(lds_byte) : "memory");
 }
 
 // 4 bytes per lane from per-lane 64-bit addresses (scales of two different tensors in one chunk)
 __device__ __forceinline__ void glds4v(const void* gptr, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
+    uint32_t m0_keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(gptr), "s"(lds_byte) : "memory");
 }
 
 // the same with 4 bytes per lane (scales)
 __device__ __forceinline__ void glds4s(const char* base, uint32_t off, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
+    uint32_t m0_keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(off), "s"(base), "s"(lds_byte) : "memory");
 }
 
 __device__ __forceinline__ int swz_g(int row)
@@ -930,6 +933,8 @@ int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
             || (reinterpret_cast<uintptr_t>(p.residual) & 15) || p.K < 256)
             return 1;
         return launch_sqp<4, 2, 2, 3, 2, 8, false, 16, 0, false, true, false, true>(p, stream);
+    // (r06: FOUR waves - one per SIMD, accumulators in AGPRs - with wave tiles of 128 x 96 / 128 x 64 / 64 x 128 measured against the
+    //  8-wave forms: 4 - 13 % slower at M = 1024 ... 4096, profiles/r06_sqgemm_wave_tiles.txt; ids 70, 71, 73 are gone)
     // ablations of the 256 x 192 shape (wrong results on purpose; microbench only)
     case 21: return launch_sqp<4, 2, 2, 3, 2, 8, false, 1>(p, stream); // no DMA in the loop
     case 22: return launch_sqp<4, 2, 2, 3, 2, 8, false, 2>(p, stream); // no MFMA

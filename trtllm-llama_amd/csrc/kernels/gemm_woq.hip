@@ -44,7 +44,8 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 __device__ __forceinline__ void glds16(const void* gptr, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
+    uint32_t m0_keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(gptr), "s"(lds_byte) : "memory");
 }
 
 template <int N>

@@ -53,7 +53,8 @@ __device__ __forceinline__ float silu_mul_fp16_(float g, float u)
 // one LDS-DMA instruction: 64 lanes x 16 bytes, global (wave-uniform base + per-lane 32-bit offset) -> LDS [lds_byte + lane * 16]
 __device__ __forceinline__ void glds16(const char* base, uint32_t off, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(off), "s"(base), "s"(lds_byte) : "memory");
+    uint32_t m0_keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(off), "s"(base), "s"(lds_byte) : "memory");
 }
 
 // NXV = 0: int8 activations as given (PRO_NONE); else RMSNorm + static quantiser, a thread keeps NXV 16-byte vectors of a row.

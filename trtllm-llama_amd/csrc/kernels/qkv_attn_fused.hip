@@ -76,10 +76,11 @@ __device__ __forceinline__ unsigned long long ld_granule(const gu64* g)
 
 // one LDS-DMA instruction: 64 lanes x 16 bytes, global (per-lane address) -> LDS [lds_byte + lane * 16].  (M0 cannot go on the
 // clobber list - hipcc: "reserved register, may not be preserved" - and __builtin_amdgcn_global_load_lds would hand the waits
-// to the compiler's own vmcnt accounting; the generated code of these kernels has no other user of M0.)
+// to the compiler's own vmcnt accounting: the statement saves M0 and puts it back itself)
 __device__ __forceinline__ void glds16(const void* gptr, uint32_t lds_byte)
 {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_byte) : "memory");
+    uint32_t m0_keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(m0_keep) : "v"(gptr), "s"(lds_byte) : "memory");
 }
 
 // RoPE (NeoX pairs (d, d + 64)) of the element pair (2l, 2l + 1) this lane of the sweeping wave holds: the partner pair sits in

@@ -168,6 +168,10 @@ struct tllm_session
     int tokens_per_block = 64, max_blocks = 0;
     size_t kv_elems = 0; // elements of one layer's cache / pool
     bool force_comm = false; // tests: run the TP collectives on a 1-rank communicator too (RCCL inside the captured graph)
+    // session key no_comm = 1: a rank's launches WITHOUT its collectives (all-reduces and the logits all-gather are skipped, nothing
+    // else changes) - the per-rank step time of a tensor-parallel shard on one GPU, bench.py's prediction for the first multi-GPU
+    // run.  TIMING ONLY: hidden states are one rank's partial sums.
+    bool no_comm = false;
     bool debug_taps = false; // tests: keep every layer's GEMV inputs of the last generation step (tllm_session_get_tap[_ex])
     // tap w of layer li: the activation exactly as GEMV w consumes it, behind its prologue (RMSNorm / split merge / quantiser):
     //   0 QKV input [B, D]   1 O-projection input [B, Dr]   2 gate|up input [B, D]   3 down-projection input [B, Ir]
@@ -552,7 +556,7 @@ struct tllm_session
 
     int allreduce(void* buf, int64_t n, hipStream_t st)
     {
-        if (tp == 1 && !force_comm)
+        if ((tp == 1 && !force_comm) || no_comm)
             return 0;
         if (comm::p2p::usable(tp, n * 2))
             return timed(PC_COMM, st, [&] { return comm::p2p::all_reduce_f16(buf, n, st) ? 1 : 0; });
@@ -784,7 +788,7 @@ struct tllm_session
             logits_local, Vr, DT_FLOAT, nullptr, st);
         gemv_cls = PC_GEMV_LAYER;
         RUN(head_rc);
-        if (tp > 1 || force_comm)
+        if ((tp > 1 || force_comm) && !no_comm)
         {
             const int64_t bytes = (int64_t) rows * Vr * 4;
             if (comm::p2p::usable(tp, bytes))
@@ -1159,6 +1163,7 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->quant_mode = geti("quant_mode", 0);
     s->neox = geti("neox_rotary_style", 1);
     s->force_comm = geti("force_comm", 0) != 0;
+    s->no_comm = geti("no_comm", 0) != 0;
     s->debug_taps = geti("debug_taps", 0) != 0;
     s->fuse_qkv_cfg = geti("fuse_qkv_attention", -1);
     s->fuse_o_cfg = geti("fuse_o_projection", -1);
@@ -1288,7 +1293,7 @@ int32_t tllm_session_finalize(tllm_session_t s)
             RUN(s->scalar_f32(p + "attention.kv_quant_orig_scale", &L.kv_qo));
         }
     }
-    if (s->tp > 1 && !comm::has_comm(s->group) && !comm::p2p::attached())
+    if (s->tp > 1 && !s->no_comm && !comm::has_comm(s->group) && !comm::p2p::attached())
     {
         set_error("session: tp_size=%d but no communicator registered (tllm_comm_init_rank / tllm_comm_p2p_attach)", s->tp);
         return 1;
