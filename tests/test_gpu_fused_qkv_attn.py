@@ -104,7 +104,7 @@ def test_fused_launch_equals_the_two_launches(S, pad, int8_kv, per_token):
         # one fp16 ulp on a handful of elements (observed: 2 of 5.1 M); the quantiser of the int8 cache hides that
         ca, cb = a['cache'][0].view(np.float16).astype(np.float32), b['cache'][0].view(np.float16).astype(np.float32)
         bad = ca != cb
-        assert bad.mean() < 1e-5 and np.all(np.abs(ca - cb)[bad] <= 2.0 ** -10 * np.maximum(np.abs(ca[bad]), 2.0 ** -14) * 1.01), bad.sum()
+        assert bad.sum() <= max(2, 1e-5 * bad.size) and np.all(np.abs(ca - cb)[bad] <= 2.0 ** -10 * np.maximum(np.abs(ca[bad]), 2.0 ** -14) * 1.01), bad.sum()
     for li in range(1, layers):
         ca = a['cache'][li].reshape(2, cfg['num_heads'], max_in + NEW, -1)
         cb = b['cache'][li].reshape(2, cfg['num_heads'], max_in + NEW, -1)
@@ -189,16 +189,19 @@ def test_o_projection_stage_equals_the_gemv_launch(S, pad, int8_kv):
     assert np.abs(a['logits'][-1]).max() > 0
 
 
-def woq_weights(layers, int8_kv):
+def woq_weights(layers, int8_kv, mode='woq8'):
     cfg = dict(bench.LLAMA_7B, num_layers=layers, vocab_size=2048, max_position_embeddings=4608)
     dev = torch.device('cuda', 0)
-    w = bench.synth_weights(torch, cfg, 'woq8', int8_kv, 1, 0, dev)
-    return cfg, w, bench.QM['woq8'] | (bench.INT8_KV if int8_kv else 0)
+    w = bench.synth_weights(torch, cfg, mode, int8_kv, 1, 0, dev)
+    return cfg, w, bench.QM[mode] | (bench.INT8_KV if int8_kv else 0)
 
 
-@pytest.mark.parametrize('S,pad,int8_kv', [(3, 0, 1), (40, 9, 1), (1100, 0, 1), (4000, 0, 1), (300, 5, 0)])
-def test_weight_only_int8_fused_launch_equals_the_two_launches(S, pad, int8_kv):
-    """The fused launch on WEIGHT-ONLY int8 projection weights (r05: BASELINE.json configs[2]; reference: the
+@pytest.mark.parametrize('S,pad,int8_kv,mode', [(3, 0, 1, 'woq8'), (40, 9, 1, 'woq8'), (1100, 0, 1, 'woq8'), (4000, 0, 1, 'woq8'), (300, 5, 0, 'woq8'),
+                                                 (3, 0, 0, 'fp16'), (40, 9, 0, 'fp16'), (1100, 0, 0, 'fp16'), (1900, 0, 0, 'fp16'), (2300, 0, 1, 'fp16')])
+def test_weight_only_int8_fused_launch_equals_the_two_launches(S, pad, int8_kv, mode):
+    """(mode fp16, r06: the same launch on FP16 projection weights - rows of 8 KB as two 8 KB tiles per row pair through the same
+    two-buffer ring, v_dot2_f32_f16 in the chunk order of gemv_kernel<W_FP16, PK_NORM>; BASELINE.json configs[1].)
+    The fused launch on WEIGHT-ONLY int8 projection weights (r05: BASELINE.json configs[2]; reference: the
     WeightOnlyQuantMatmul plugin in front of the attention plugin, P/weightOnlyQuantMatmulPlugin + MM/...Template.h) against the
     two launches it replaces (gemv_kernel<W_INT8_WOQ, PK_NORM> + mmha_partial_kernel).  The fused projection restates the unfused
     one's arithmetic AND summation order (raw byte splices, 1152 * sum(x) off once per row, the same per-lane runs and cross-lane
@@ -206,7 +209,7 @@ def test_weight_only_int8_fused_launch_equals_the_two_launches(S, pad, int8_kv):
     attention's fp32 re-association through the residual stream), the attention context within the reference's 2e-3, logits
     close, tokens equal wherever the margin allows."""
     layers, NEW = 2, 7
-    cfg, w, qm = woq_weights(layers, int8_kv)
+    cfg, w, qm = woq_weights(layers, int8_kv, mode)
     max_in = S + pad
     r = np.random.default_rng(200 + S)
     ids = np.full((1, max_in), 2, np.int32)
@@ -217,6 +220,7 @@ def test_weight_only_int8_fused_launch_equals_the_two_launches(S, pad, int8_kv):
     for fuse in (0, 1):
         s = make(cfg, w, qm, fuse)
         s.setup(1, max_in, NEW)
+        assert s.decode_form() & 1 == fuse
         s.context(ids, lens)
         rec = dict(qkv_in=[], o_in=[], logits=[s.logits()])
         for i in range(NEW - 1):
@@ -248,7 +252,7 @@ def test_weight_only_int8_fused_launch_equals_the_two_launches(S, pad, int8_kv):
     else:
         ca, cb = a['cache'][0].view(np.float16).astype(np.float32), b['cache'][0].view(np.float16).astype(np.float32)
         bad = ca != cb
-        assert bad.mean() < 1e-5 and np.all(np.abs(ca - cb)[bad] <= 2.0 ** -10 * np.maximum(np.abs(ca[bad]), 2.0 ** -14) * 1.01), bad.sum()
+        assert bad.sum() <= max(2, 1e-5 * bad.size) and np.all(np.abs(ca - cb)[bad] <= 2.0 ** -10 * np.maximum(np.abs(ca[bad]), 2.0 ** -14) * 1.01), bad.sum()
 
 
 @pytest.mark.parametrize('S,pad,int8_kv', [(3, 0, 1), (40, 9, 1), (1100, 0, 1), (4000, 0, 1), (300, 5, 0)])

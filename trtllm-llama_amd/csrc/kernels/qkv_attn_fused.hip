@@ -183,10 +183,19 @@ __device__ __forceinline__ float groups_max(float v)
 
 // WOQ (r05): weight-only int8 projection weights (u8 = q + 128, fp16 per-channel scales) against the NORMALISED fp16 row - no
 // quantiser in the prologue, raw byte splices in the dots (1024 + u), 1152 * sum(x) taken off once per row: the arithmetic and
-// the summation order of gemv_impl.h's W_INT8_WOQ path, so the projection is bit-identical to the unfused GEMV.  Two-stage form only.
-template <int NIT, bool INT8KV, bool WOQ = false>
+// the summation order of gemv_impl.h's W_INT8_WOQ path, so the projection is bit-identical to the unfused GEMV.
+// WK = 2 (r06): fp16 projection weights (BASELINE.json configs[1]) - rows of 8 KB = TWO 8 KB tiles per row pair, the same two-tile
+// ring (q.lo q.hi k.lo k.hi v.lo v.hi alternate through the two register buffers), the normalised fp16 row in LDS, v_dot2_f32_f16 in
+// the per-lane chunk order of gemv_impl.h's W_FP16 path, no scales: bit-identical projection.  Two-stage form (no O-projection stage:
+// 19 rows of 8 KB do not fit the row worker's LDS).
+constexpr int WK_SQ = 0, WK_WOQ8 = 1, WK_FP16 = 2;
+template <int NIT, bool INT8KV, int WK = WK_SQ>
 __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnParams p)
 {
+    constexpr bool WOQ = WK == WK_WOQ8, F16W = WK == WK_FP16;
+    constexpr bool HALFX = WK != WK_SQ; // the projection's operand row stays fp16 (no quantiser)
+    constexpr int KH = F16W ? 2 : 1;    // 8 KB tiles per row pair (4 x 1 KiB chunks x 2 rows each)
+    constexpr int NT = 3 * KH;          // tiles per wave: q, k, v
     constexpr int EPL = INT8KV ? 16 : 8; // cache elements per lane (16 bytes)
     constexpr int LPR = kDH / EPL;       // lanes per cache row
     constexpr int RPW = 64 / LPR;        // rows per wave instruction = lane groups per wave
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     constexpr int ESZ = INT8KV ? 1 : 2;
     constexpr int NQW = EPL / 2;         // 32-bit words of q per lane
 
-    constexpr int XSB = WOQ ? 8192 : 4096; // the projection's operand row: fp16 (weight-only) or int8
+    constexpr int XSB = HALFX ? 8192 : 4096; // the projection's operand row: fp16 (weight-only / fp16 weights) or int8
     __shared__ __attribute__((aligned(16))) char smem[XSB /* x */ + 256 /* red */ + 3 * 256 /* q', k', v as fp16 */
         + 3 * 256 /* raw q, k, v */ + kWavesF * (kDH + 8) * 4 /* wave partials */ + kMembers * (kDH + 8) * 4 /* head partials */ + 64];
     char* xs = smem;
@@ -285,6 +294,8 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         {
             if constexpr (WOQ)
                 cscale[i][r] = h2f(reinterpret_cast<const uint16_t*>(p.scale_col)[wrow[i] + r]);
+            else if constexpr (F16W)
+                cscale[i][r] = 1.f;
             else
                 cscale[i][r] = reinterpret_cast<const float*>(p.scale_col)[p.per_channel ? wrow[i] + r : 0];
         }
@@ -298,11 +309,15 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     //     instead of 3.4 (tools/fused_timeline.py).
     const char* wbase = reinterpret_cast<const char*>(p.w);
     uint4 wa[kKChunks][2], wb[kKChunks][2];
+    // tile t of the wave's stream: matrix t / KH (q, k, v), chunks [4 (t % KH), + 4) of its two rows
+    auto load_tile = [&](int t, uint4 (&wt)[kKChunks][2]) {
 #pragma unroll
-    for (int u = 0; u < kKChunks; ++u)
+        for (int u = 0; u < kKChunks; ++u)
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
-            wa[u][r] = ld_nt16(wbase + (int64_t) (wrow[0] + r) * p.ldw + u * 1024 + lane * 16);
+            for (int r = 0; r < 2; ++r)
+                wt[u][r] = ld_nt16(wbase + (int64_t) (wrow[t / KH] + r) * p.ldw + ((t % KH) * kKChunks + u) * 1024 + lane * 16);
+    };
+    load_tile(0, wa);
     __builtin_amdgcn_sched_barrier(0);
     TLLM_STAMP(0);
 
@@ -370,10 +385,11 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             const float bsum = wave_sum(1152.f * (sa + sb));
             if (lane == 0 && wid < 4)
                 red[8 + wid] = bsum;
-            *reinterpret_cast<uint4*>(xs + tid * 16) = make_uint4(xs4[0], xs4[1], xs4[2], xs4[3]);
         }
+        if constexpr (HALFX)
+            *reinterpret_cast<uint4*>(xs + tid * 16) = make_uint4(xs4[0], xs4[1], xs4[2], xs4[3]);
         float qs = pro_q;
-        if (!WOQ && q_dyn) // uniform: per-token scale amax / 127 (K/quantization.cu:94-118)
+        if (!HALFX && q_dyn) // uniform: per-token scale amax / 127 (K/quantization.cu:94-118)
         {
             amax = wave_max(amax);
             if (lane == 0)
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             const uint32_t b1 = (uint8_t) f2i8_rni_sat((float) hh.y * qs);
             o[q >> 1] |= (b0 | (b1 << 8)) << (16 * (q & 1));
         }
-        if constexpr (!WOQ)
+        if constexpr (!HALFX)
             *reinterpret_cast<uint2*>(xs + tid * 8) = make_uint2(o[0], o[1]);
     }
     __syncthreads();
@@ -406,11 +422,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     TLLM_STAMP(1);
     // (b2) the k rows, (c) the member's cache rows and masks
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < kKChunks; ++u)
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-            wb[u][r] = ld_nt16(wbase + (int64_t) (wrow[1] + r) * p.ldw + u * 1024 + lane * 16);
+    load_tile(1, wb);
     __builtin_amdgcn_sched_barrier(0);
     const int li = lane % LPR, grp = lane / LPR, gid = wid * RPW + grp;
     const int t0 = mem * TCHUNK;
@@ -479,19 +491,32 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         if (lane == 0)
             st_granule(gx + i * 64 + mem * 8 + wid, tag, v);
     };
-    project(wa, 0);
-    TLLM_STAMP(2);
-    __builtin_amdgcn_sched_barrier(0);
-    // the v rows, into the registers the q rows have left
+    // fp16 weights: half a row pair per tile - the per-lane sums run on across the two tiles of a matrix (chunk order 0 .. 7, the
+    // order of gemv_impl.h's two-tile row groups), one cross-lane sum and one granule per matrix
+    float h0 = 0.f, h1 = 0.f;
+    auto accum16 = [&](const uint4 (&wt)[kKChunks][2], int half) {
 #pragma unroll
-    for (int u = 0; u < kKChunks; ++u)
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-            wa[u][r] = ld_nt16(wbase + (int64_t) (wrow[2] + r) * p.ldw + u * 1024 + lane * 16);
-    __builtin_amdgcn_sched_barrier(0);
-    project(wb, 1);
-    TLLM_STAMP(3);
-    // The first look at the head's q (and, member 0, k) granules is requested HERE, behind the v rows in this wave's in-order
+        for (int u = 0; u < kKChunks; ++u)
+        {
+            const uint4 xr = *reinterpret_cast<const uint4*>(xs + ((half * kKChunks + u) * 64 + lane) * 16);
+            h0 = dot2(wt[u][0].x, xr.x, h0);
+            h0 = dot2(wt[u][0].y, xr.y, h0);
+            h0 = dot2(wt[u][0].z, xr.z, h0);
+            h0 = dot2(wt[u][0].w, xr.w, h0);
+            h1 = dot2(wt[u][1].x, xr.x, h1);
+            h1 = dot2(wt[u][1].y, xr.y, h1);
+            h1 = dot2(wt[u][1].z, xr.z, h1);
+            h1 = dot2(wt[u][1].w, xr.w, h1);
+        }
+    };
+    auto finish16 = [&](int i) {
+        // epilogue of the fp16 GEMV: fp16(sum) (gemv_impl.h: v0 * (1 * 1))
+        const uint32_t v = (uint32_t) f2h(wave_sum(h0) * (cscale[i][0] * 1.f)) | ((uint32_t) f2h(wave_sum(h1) * (cscale[i][1] * 1.f)) << 16);
+        if (lane == 0)
+            st_granule(gx + i * 64 + mem * 8 + wid, tag, v);
+        h0 = h1 = 0.f;
+    };
+    // The first look at the head's q (and, member 0, k) granules is requested behind the LAST tile in this wave's in-order
     // load queue: the siblings published them microseconds ago, the answer comes back with the v rows - when it is needed - and
     // costs nothing.  (Polling for them while the weights stream does: a poll takes ~2.2 us under load and slows the stream,
     // measured with a ninth "gather" wave: the q hand-off took 4.8 - 6.3 us and the launch 17 - 20 us.)
@@ -499,19 +524,61 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     // four lines with write-through loads made every poll slower, the launch 16.9 -> 18.7 us.  One sweeping wave per workgroup,
     // the others wait on an LDS flag.)
     unsigned long long gq = 0, gk = 0;
-    if (wid == 0)
+    auto first_look = [&]() {
+        if (wid == 0)
+        {
+            // (not at once: the load EXECUTES soon after it is issued - only its return is ordered behind the v rows - and the slowest
+            // sibling's q granule is ~1 us behind this wave's k rows; the v rows are ~2 us away, so the pause costs nothing.  Without
+            // it the first look missed often and the second took 1.8 us)
+            __builtin_amdgcn_s_sleep(64);
+            gq = ld_granule(gx + lane);
+            gk = ld_granule(gx + 64 + lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (!F16W)
     {
-        // (not at once: the load EXECUTES soon after it is issued - only its return is ordered behind the v rows - and the slowest
-        // sibling's q granule is ~1 us behind this wave's k rows; the v rows are ~2 us away, so the pause costs nothing.  Without
-        // it the first look missed often and the second took 1.8 us)
-        __builtin_amdgcn_s_sleep(64);
-        gq = ld_granule(gx + lane);
-        gk = ld_granule(gx + 64 + lane);
+        project(wa, 0);
+        TLLM_STAMP(2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(2, wa); // the v rows, into the registers the q rows have left
+        __builtin_amdgcn_sched_barrier(0);
+        project(wb, 1);
+        TLLM_STAMP(3);
+        first_look();
+        // -------------------------------------------------------------- 3. the v rows: the end of the weight stream
+        project(wa, 2);
+        TLLM_STAMP(6);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // ------------------------------------------------------------------ 3. the v rows: the end of the weight stream
-    project(wa, 2);
-    TLLM_STAMP(6);
+    else
+    {
+        // tiles: q.lo (wa, in flight since t = 0), q.hi (wb), k.lo, k.hi, v.lo, v.hi - each into the buffer the tile two back has left
+        accum16(wa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(2, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        accum16(wb, 1);
+        finish16(0);
+        TLLM_STAMP(2);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(3, wb);
+        __builtin_amdgcn_sched_barrier(0);
+        accum16(wa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(4, wa);
+        __builtin_amdgcn_sched_barrier(0);
+        accum16(wb, 1);
+        finish16(1);
+        TLLM_STAMP(3);
+        __builtin_amdgcn_sched_barrier(0);
+        load_tile(5, wb);
+        __builtin_amdgcn_sched_barrier(0);
+        first_look();
+        accum16(wa, 0);
+        accum16(wb, 1);
+        finish16(2);
+        TLLM_STAMP(6);
+    }
 
     // ------------------------------------------------------------------ 4. q' of the whole head -> LDS (wave 0; RoPE in the sweep).
     //          No workgroup barrier: the other waves wait on an LDS flag, each from the moment ITS v rows are done (the eight waves'
@@ -989,26 +1056,29 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
 #undef TLLM_STAMP
 
 // the instance that serves (cache rows per lane group, cache type, weight type)
-template <bool INT8KV, bool WOQ>
+template <bool INT8KV, int WK>
 const void* fused_kernel_of(int nit)
 {
     switch (nit)
     {
-    case 1: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<1, INT8KV, WOQ>);
-    case 2: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<2, INT8KV, WOQ>);
-    case 3: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<3, INT8KV, WOQ>);
-    case 4: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<4, INT8KV, WOQ>);
-    case 6: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<6, INT8KV, WOQ>);
-    case 8: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<8, INT8KV, WOQ>);
+    case 1: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<1, INT8KV, WK>);
+    case 2: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<2, INT8KV, WK>);
+    case 3: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<3, INT8KV, WK>);
+    case 4: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<4, INT8KV, WK>);
+    case 6: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<6, INT8KV, WK>);
+    case 8: return reinterpret_cast<const void*>(qkv_attn_fused_kernel<8, INT8KV, WK>);
     default: return nullptr;
     }
 }
 
-const void* fused_kernel(int nit, bool int8_kv, bool woq)
+const void* fused_kernel(int nit, bool int8_kv, int wk)
 {
-    if (woq)
-        return int8_kv ? fused_kernel_of<true, true>(nit) : fused_kernel_of<false, true>(nit);
-    return int8_kv ? fused_kernel_of<true, false>(nit) : fused_kernel_of<false, false>(nit);
+    switch (wk)
+    {
+    case WK_WOQ8: return int8_kv ? fused_kernel_of<true, WK_WOQ8>(nit) : fused_kernel_of<false, WK_WOQ8>(nit);
+    case WK_FP16: return int8_kv ? fused_kernel_of<true, WK_FP16>(nit) : fused_kernel_of<false, WK_FP16>(nit);
+    default: return int8_kv ? fused_kernel_of<true, WK_SQ>(nit) : fused_kernel_of<false, WK_SQ>(nit);
+    }
 }
 
 // Per-DEVICE launch state (a process may hold sessions on devices with different CU counts): the CU count, which
@@ -1092,13 +1162,16 @@ bool qkv_attn_fused_serves_o(int32_t num_heads, int32_t head_size, int32_t o_n, 
         && o_ldw % 16 == 0 && o_ldw >= o_k && o_n > 0 && (o_n + workers - 1) / workers <= kORowsMax;
 }
 
-bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int32_t max_seq_len, int32_t int8_kv, int32_t woq8,
+bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int32_t max_seq_len, int32_t int8_kv, int32_t weight_kind,
     int32_t o_stage)
 {
     const int nit = pick_nit(max_seq_len, int8_kv != 0);
-    if (K != kKChunks * 1024 || head_size != kDH || nit == 0)
+    // (K = 4096 elements: rows of 4 KiB int8 / 8 KiB fp16 = one / two tiles of 4 x 1 KiB chunks x 2 rows)
+    if (K != kKChunks * 1024 || head_size != kDH || nit == 0 || weight_kind < WK_SQ || weight_kind > WK_FP16)
         return false;
-    const void* kfn = fused_kernel(nit, int8_kv != 0, woq8 != 0);
+    if (weight_kind == WK_FP16 && o_stage)
+        return false; // the row worker's share of an fp16 dense projection does not fit its LDS
+    const void* kfn = fused_kernel(nit, int8_kv != 0, weight_kind);
     if (!kfn)
         return false;
     // every workgroup of a head waits for its siblings (and the row workers for every head's merger): the whole grid must be
@@ -1115,13 +1188,14 @@ bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int3
 int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream)
 {
     const bool o_stage = p.o_w != nullptr;
-    if (!qkv_attn_fused_serves(p.K, p.num_heads, p.head_size, p.max_seq_len, p.int8_kv, p.woq8, o_stage ? 1 : 0))
+    const int wk = p.fp16_w ? WK_FP16 : (p.woq8 ? WK_WOQ8 : WK_SQ);
+    if (!qkv_attn_fused_serves(p.K, p.num_heads, p.head_size, p.max_seq_len, p.int8_kv, wk, o_stage ? 1 : 0))
     {
         set_error("fused QKV + attention: shape not served or grid not resident (K %d, heads %d x %d, cache %d, O stage %d)", p.K,
             p.num_heads, p.head_size, p.max_seq_len, o_stage ? 1 : 0);
         return -1;
     }
-    if (!p.x || !p.gamma || !p.w || !p.scale_col || !p.kv_cache || !p.sequence_length || !p.rope_row || !p.xchg || !p.error || !p.out
+    if (!p.x || !p.gamma || !p.w || (!p.scale_col && !p.fp16_w) || !p.kv_cache || !p.sequence_length || !p.rope_row || !p.xchg || !p.error || !p.out
         || !p.epoch || (p.act_quant_scale && !p.act_dequant_scale) || (p.out_q8 && !p.out_quant_scale)
         || (p.int8_kv && (!p.kv_scale_orig_quant || !p.kv_scale_quant_orig)) || p.ldw % 16)
     {
@@ -1136,12 +1210,17 @@ int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream)
             p.num_heads * p.head_size, p.num_heads * p.head_size);
         return -1;
     }
-    if (p.woq8 && (p.out_q8 || p.act_quant_scale))
+    if ((p.woq8 || p.fp16_w) && (p.out_q8 || p.act_quant_scale))
     {
-        set_error("fused QKV + attention: the weight-only form has no quantiser");
+        set_error("fused QKV + attention: the weight-only / fp16 forms have no quantiser");
         return -1;
     }
-    const void* kfn = fused_kernel(pick_nit(p.max_seq_len, p.int8_kv != 0), p.int8_kv != 0, p.woq8 != 0);
+    if (p.fp16_w && (p.woq8 || p.ldw != (int64_t) p.K * 2))
+    {
+        set_error("fused QKV + attention: fp16 weights are dense rows of K halfs");
+        return -1;
+    }
+    const void* kfn = fused_kernel(pick_nit(p.max_seq_len, p.int8_kv != 0), p.int8_kv != 0, wk);
     const dim3 grid(p.num_heads * kMembers), block(64 * kWavesF);
     FusedQkvAttnParams q = p;
     void* args[] = {&q};
