@@ -413,6 +413,30 @@ def sq_gemm_mfma_report(torch, dev, M=1024):
         tops = 2.0 * M * N * K / us / 1e6
         out[name] = {'M': M, 'N': N, 'K': K, 'us': us, 'us_median': us_med, 'TOP/s': tops, 'frac_of_5POPs': tops / 5000.0,
                      'tactic': int(tactic.value), 'tactic_profile_us': float(tactic_us.value), 'static_rule_us': static_us}
+        # what the SAME pipeline does with every memory operation removed (ablation id 33 of the 256 x 192 phased kernel: MFMAs + epilogue
+        # only, wrong results on purpose): the ceiling of this kernel structure at this M - one round of workgroups, epilogue exposed
+        if name == 'qkv' and M == 1024:
+            try:
+                lib.tllm_gemm_set_tile_cfg.argtypes = [ctypes.c_int32]
+                lib.tllm_gemm_set_tile_cfg.restype = None
+                lib.tllm_gemm_set_tile_cfg(33)
+                for _ in range(3):
+                    lib.tllm_gemm(ctypes.byref(q), stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    lib.tllm_gemm(ctypes.byref(q), stream)
+                e1.record()
+                torch.cuda.synchronize()
+                mo = e0.elapsed_time(e1) * 1e3 / iters
+                out[name]['mfma_only_us'] = mo
+                out[name]['frac_of_the_mfma_only_form'] = mo / us
+            except Exception as e:
+                print(f'[bench] mfma-only ablation failed: {e!r}', file=sys.stderr)
+            finally:
+                lib.tllm_gemm_set_tile_cfg(0)
+                if tactic.value > 0:
+                    lib.tllm_gemm_tactics_import(f'3:{M}:{N}:{K}:{int(tactic.value)}:{float(tactic_us.value):.2f};'.encode())
         # the clock the chip held under this kernel (it clocks to its power budget: dense random-operand int8 MFMA work next to
         # the LDS / L2 traffic that feeds it runs well below 2.4 GHz): every workgroup reports its shader cycles against the
         # constant 100 MHz counter (tllm_gemm_set_clock_probe); 5 POP/s is the nominal peak AT 2.4 GHz

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 ( time python bench.py ) > gpurun_out/${R}_bench_default.log 2>&1
 rm -rf gpurun_out/prof_bench gpurun_out/prof_prefill
-( cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_bench -- python $ROOT/bench.py --steps 64 --no-cpu-baseline --no-fp16-ref --no-parity --no-prefill ) > gpurun_out/prof_bench.log 2>&1
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_bench -- python $ROOT/bench.py --steps 64 --no-cpu-baseline --no-fp16-ref --no-parity --no-prefill --no-batch-sweep --no-tp-prediction ) > gpurun_out/prof_bench.log 2>&1
 DB=$(find gpurun_out/prof_bench -name "*_results.db" | head -1)
 python tools/rocpd_summary.py "$DB" > gpurun_out/${R}_bench_kernel_stats.txt
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/prof_prefill -- python $ROOT/tools/prefill_probe.py ) > gpurun_out/prof_prefill.log 2>&1
