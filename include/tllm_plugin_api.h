@@ -19,6 +19,7 @@
 #ifndef TLLM_PLUGIN_API_H
 #define TLLM_PLUGIN_API_H
 
+#include <stdbool.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -88,9 +89,10 @@ typedef struct tllm_plugin* tllm_plugin_t;
  * Library init.  Replaces  bool initLibNvInferPlugins(void* logger, const char* libNamespace)
  * (P/api/InferPlugin.cpp:149-171), which PY/plugin/plugin.py:7-22 calls through ctypes and
  * asserts to be true.  Idempotent and thread-safe like the mutex-guarded registry
- * (P/api/InferPlugin.cpp:55-136).  `logger` may be NULL.
+ * (P/api/InferPlugin.cpp:55-136).  `logger` may be NULL.  Same signature as the reference's (bool: the reference's
+ * ctypes stub declares restype c_bool and needs no edit).
  * ---------------------------------------------------------------------------------------------- */
-int initLibNvInferPlugins(void* logger, const char* libNamespace);
+bool initLibNvInferPlugins(void* logger, const char* libNamespace);
 
 /* getInferLibVersion of P/exports.map:19-32 — here: 10000*major + 100*minor + patch of this library. */
 int32_t getInferLibVersion(void);

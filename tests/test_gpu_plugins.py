@@ -874,3 +874,77 @@ def test_persistent_prefill_gemm_several_tiles_per_workgroup(cfg, m, n, k, resid
                 np.testing.assert_allclose(c.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-3, atol=4e-3 if residual else 2e-3)
     finally:
         lib.tllm_gemm_set_tile_cfg(0)
+
+
+# ---------------------------------------------------------------------------------------------- split-K-2 prefill GEMM (r06)
+@pytest.mark.parametrize('cfg,m,n,k,residual', [
+    (64, 1024, 4096, 4096, True),    # the O-projection of a 1024-token prefill: 128 tiles of 256 x 128 -> 256 workgroups, residual epilogue
+    (64, 1024, 4096, 11008, True),   # the down-projection: 86 K-tiles, 43 per half
+    (64, 1000, 4000, 1664, False),   # ragged rows and columns, 13 K-tiles (7 + 6)
+    (64, 300, 1000, 512, False),     # 2 x 8 tiles: a few pairs only
+    (57, 1024, 4096, 4096, True),    # fp16 operands
+    (57, 1000, 4000, 832, False)])   # fp16, ragged, 13 K-tiles
+def test_split_k_prefill_gemm_equals_the_one_pass_form(cfg, m, n, k, residual):
+    """gemm_sqp.hip KSPLIT (ids 64 / 57): two workgroups per 256 x 128 tile, each half of the K-tiles, the accumulators of the other
+    X-half handed to the partner through write-through slabs + a drained flag (guide G16 R1).  SmoothQuant: int32 partial sums are
+    exact, so every output equals the fp64-accumulated integer product with the reference's epilogue (cutlass_extensions/.../
+    epilogue_per_row_per_col_scale.h:279-347) - and the one-pass kernel's - bit for bit; fp16: the GEMM tolerance.  Launched several
+    times in a row (the flags re-arm themselves), on two streams (a workspace per stream)."""
+    lib = capi.load_library()
+
+    class GemmParams(ctypes.Structure):
+        _fields_ = [('wtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32), ('M', ctypes.c_int32), ('N', ctypes.c_int32),
+                    ('K', ctypes.c_int32), ('a', ctypes.c_void_p), ('lda', ctypes.c_int64), ('w', ctypes.c_void_p),
+                    ('ldw', ctypes.c_int64), ('scale_col', ctypes.c_void_p), ('scale_row', ctypes.c_void_p),
+                    ('per_channel', ctypes.c_int32), ('per_token', ctypes.c_int32), ('c', ctypes.c_void_p), ('ldc', ctypes.c_int64)]
+
+    lib.tllm_gemm.argtypes = [ctypes.POINTER(GemmParams), ctypes.c_void_p]
+    lib.tllm_gemm.restype = ctypes.c_int32
+    lib.tllm_gemm_residual.argtypes = [ctypes.POINTER(GemmParams), ctypes.c_void_p, ctypes.c_void_p]
+    lib.tllm_gemm_residual.restype = ctypes.c_int32
+    lib.tllm_gemm_set_tile_cfg.argtypes = [ctypes.c_int32]
+    lib.tllm_gemm_set_tile_cfg.restype = None
+    dev = torch.device('cuda', 0)
+    torch.manual_seed(cfg + m + k)
+    sq = cfg == 64
+    res = (torch.randn((m, n), device=dev) * 3).half() if residual else None
+    if sq:
+        a = torch.randint(-128, 128, (m, k), dtype=torch.int8, device=dev)
+        w = torch.randint(-128, 128, (n, k), dtype=torch.int8, device=dev)
+        sc = torch.randint(1, 13, (n, ), device=dev).float() * 1e-4
+        sr = torch.randint(1, 13, (m, ), device=dev).float() * 1e-3
+        acc = torch.zeros((m, n), dtype=torch.float64, device=dev)
+        for k0 in range(0, k, 2048):
+            acc += a[:, k0:k0 + 2048].double() @ w[:, k0:k0 + 2048].double().t()
+        ref = (acc.float() * (sc[None, :] * sr[:, None])).half()
+    else:
+        a = torch.randn((m, k), dtype=torch.float16, device=dev)
+        w = (torch.randn((n, k), device=dev) / np.sqrt(k)).half()
+        ref = (a.double() @ w.double().t()).half()
+    if residual:
+        ref = (ref.float() + res.float()).half()
+    streams = [torch.cuda.current_stream(), torch.cuda.Stream(device=dev)]
+    outs = []
+    for st in streams:
+        with torch.cuda.stream(st):
+            c = torch.full((m, n), 7.0, dtype=torch.float16, device=dev)
+            if sq:
+                q = GemmParams(3, 1, m, n, k, a.data_ptr(), k, w.data_ptr(), k, sc.data_ptr(), sr.data_ptr(), 1, 1, c.data_ptr(), n)
+            else:
+                q = GemmParams(0, 1, m, n, k, a.data_ptr(), k, w.data_ptr(), 2 * k, None, None, 0, 0, c.data_ptr(), n)
+            for cfg_now in (cfg, 62 if sq else 56, cfg, cfg):  # split-K, the persistent one-pass form, split-K twice more
+                lib.tllm_gemm_set_tile_cfg(cfg_now)
+                try:
+                    c.fill_(7.0)
+                    rc = (lib.tllm_gemm_residual(ctypes.byref(q), res.data_ptr(), st.cuda_stream) if residual
+                          else lib.tllm_gemm(ctypes.byref(q), st.cuda_stream))
+                    assert rc == 0, capi.last_error()
+                    st.synchronize()
+                finally:
+                    lib.tllm_gemm_set_tile_cfg(0)
+                if sq:
+                    assert torch.equal(c, ref), (cfg_now, int((c != ref).sum()))
+                else:
+                    np.testing.assert_allclose(c.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-3, atol=4e-3 if residual else 2e-3)
+            outs.append(c.clone())
+    assert torch.equal(outs[0], outs[1])

@@ -9,7 +9,7 @@ ROOT=$(pwd); export TMPDIR=/tmp
 mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
-  ( cd /tmp && rocprofv3 --kernel-trace --pmc $c -d $ROOT/gpurun_out/pmc_$c -o pmc -- python $ROOT/bench.py --config $CFG --steps 8 --warmup 2 --no-cpu-baseline --no-fp16-ref --no-prefill --no-parity ) > gpurun_out/pmc_$c.log 2>&1
+  ( cd /tmp && rocprofv3 --kernel-trace --pmc $c -d $ROOT/gpurun_out/pmc_$c -o pmc -- python $ROOT/bench.py --config $CFG --steps 8 --warmup 2 --no-cpu-baseline --no-fp16-ref --no-prefill --no-parity --no-batch-sweep --no-tp-prediction ) > gpurun_out/pmc_$c.log 2>&1
 done
 F=$(find gpurun_out/pmc_FETCH_SIZE -name "*_results.db" | head -1); W=$(find gpurun_out/pmc_WRITE_SIZE -name "*_results.db" | head -1)
 cp profiles/${R}_pmc_summary.json gpurun_out/${R}_pmc_summary.json 2>/dev/null

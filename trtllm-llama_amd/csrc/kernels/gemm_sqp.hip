@@ -25,6 +25,8 @@
 #include "kernels.h"
 #include <atomic>
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 namespace tllm
 {
@@ -39,6 +41,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) unsigned gu32;
 
 // one LDS-DMA instruction: 64 lanes x 16 bytes, global (wave-uniform base + per-lane 32-bit offset) -> LDS [m0 + lane * 16]
 __device__ __forceinline__ void glds16s(const char* base, uint32_t off, uint32_t lds_byte)
@@ -76,10 +79,16 @@ __device__ __forceinline__ int swz_g(int row)
 // PERSIST (r05): one workgroup per CU walks tiles wg, wg + grid, ...; the fp16 tile leaves through a STAGING area of its own
 // (quarter-tile rounds) instead of the operand buffers, so the next tile's scales and its first two K-tiles are requested BEFORE
 // the epilogue and land under it; the epilogue's stores stay in the vmcnt queue across the next tile's first waits (counted).
+// KSPLIT (r06): TWO workgroups per tile, each walks half of the K-tiles; then workgroup h hands the accumulators of X-half 1 - h to
+// its partner (write-through 16-byte stores into the tile's slab, a drained flag: guide G16 R1), adds the partner's X-half h sums to its
+// own (sc1 loads) and finishes rows [h AH, (h + 1) AH) of the tile - int32 sums are exact, so the SmoothQuant result is bit-identical
+// to the one-pass form.  For problems whose 256-row tiles leave half the chip idle (N = 4096 at M = 1024: 128 tiles on 256 CUs);
+// the pair sits on one XCD (workgroup ids are remapped to XCD-contiguous), both must be resident: grid <= CUs, checked by the launcher.
 template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRIO, int ABL, int RSP, bool DUAL = false, bool SCL = true,
-    bool F16 = false, bool PERSIST = false>
+    bool F16 = false, bool PERSIST = false, bool KSPLIT = false>
 __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams p)
 {
+    static_assert(!KSPLIT || (!PERSIST && !DUAL), "split-K: the one-tile form, single GEMM");
     static_assert(SCL || !DUAL, "the fused SwiGLU epilogue reads its scales from LDS");
     static_assert(!PERSIST || SCL || F16, "the persistent form: SmoothQuant with staged scales (fp16 out, or the fused SwiGLU int8 out), or fp16 operands");
     static_assert(!F16 || (!DUAL && !SCL), "the fp16 variant has no dual / staged-scale form");
@@ -116,15 +125,21 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
     const int M = p.M, N = p.N;
     const int tiles_n = (N + (DUAL ? BH : BN) - 1) / (DUAL ? BH : BN);
     const int total_tiles = tiles_m * tiles_n;
-    const int ntile = p.K * ES / 128;
+    // split-K: workgroup 2 t + h = K-half h of tile t
+    const int khalf = KSPLIT ? (wg & 1) : 0;
+    if constexpr (KSPLIT)
+        wg >>= 1;
+    const int ntile_all = p.K * ES / 128;
+    const int kt0 = KSPLIT ? (khalf ? (ntile_all + 1) / 2 : 0) : 0;
+    const int ntile = KSPLIT ? (khalf ? ntile_all - (ntile_all + 1) / 2 : (ntile_all + 1) / 2) : ntile_all;
     // DUAL: W-half 0 = rows [n0, n0 + BH) of the first matrix, W-half 1 = the SAME rows of the second one; BH output columns
     int m0, n0;
 
     // ---- DMA sources.  Unit kinds: 0 = X0, 1 = W0, 2 = W1, 3 = X1 (issue order inside a K-tile).  Chunk c of a unit
     // covers rows [8c, 8c+8); lane l -> row 8c + (l >> 3), LDS piece l & 7 <- global piece (l & 7) ^ g(row).
     // W-halves may have fewer chunks than 2 per wave: W0 hands its surplus to the low waves, W1 to the high waves.
-    const char* xb = reinterpret_cast<const char*>(p.a);
-    const char* wb = reinterpret_cast<const char*>(p.w);
+    const char* xb = reinterpret_cast<const char*>(p.a) + (int64_t) kt0 * 128;
+    const char* wb = reinterpret_cast<const char*>(p.w) + (int64_t) kt0 * 128;
     const char* wb2 = DUAL ? reinterpret_cast<const char*>(p.w2) : wb;
     uint32_t xo[2][APW], wo[2][BPW];
     const int wrev = NW - 1 - wid;
@@ -610,6 +625,76 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         dbg[0] = __builtin_readcyclecounter() - clk0;
         dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0;
     }
+    if constexpr (KSPLIT)
+    {
+        // slabs: [tile][receiving half][(j, m, n)][thread] 16 bytes; behind them the flags [tile][receiving half] (zero between launches:
+        // the reader re-arms its own).  Stores and loads bypass the caches that are not shared (sc1: write-through / L2-served), the
+        // flag is stored behind a drained vmcnt - guide G16 R1; no fence, no cache invalidation.
+        constexpr int VSTRIDE = NW * 64 * 16, SLAB = 2 * MTH * NTH * VSTRIDE;
+        char* ws = reinterpret_cast<char*>(p.ksplit_ws);
+        char* out_slab = ws + ((size_t) wg * 2 + (1 - khalf)) * SLAB + tid * 16;
+        const char* in_slab = ws + ((size_t) wg * 2 + khalf) * SLAB + tid * 16;
+        gu32* flags = (gu32*) (ws + (size_t) total_tiles * 2 * SLAB);
+        auto exchange = [&](auto hc) {
+            constexpr int HK = decltype(hc)::value; // the X-half this workgroup keeps and finishes
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int m = 0; m < MTH; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTH; ++n)
+                    {
+                        const acc_t v = acc[1 - HK][j][m][n];
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(out_slab + ((j * MTH + m) * NTH + n) * VSTRIDE), "v"(v)
+                                     : "memory");
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+            {
+                __hip_atomic_store(flags + wg * 2 + (1 - khalf), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // the partner is resident (the launcher sizes the grid to the chip): this wait is a few microseconds.  Should it never
+                // end, the launch is killed loudly rather than left to write half a sum
+                long spins = 0;
+                while (__hip_atomic_load(flags + wg * 2 + khalf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+                {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > 200000000L)
+                        __builtin_trap();
+                }
+                __hip_atomic_store(flags + wg * 2 + khalf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            acc_t in[2][MTH][NTH];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int m = 0; m < MTH; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTH; ++n)
+                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(in[j][m][n]) : "v"(in_slab + ((j * MTH + m) * NTH + n) * VSTRIDE) : "memory");
+            // (the loads are invisible to hipcc's vmcnt bookkeeping: wait here, naming every destination - guide section 5.7 form (ii))
+            if constexpr (MTH == 2 && NTH == 2)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(in[0][0][0]), "+v"(in[0][0][1]), "+v"(in[0][1][0]), "+v"(in[0][1][1]), "+v"(in[1][0][0]), "+v"(in[1][0][1]),
+                             "+v"(in[1][1][0]), "+v"(in[1][1][1])
+                             :
+                             : "memory");
+            else
+                static_assert(MTH == 2 && NTH == 2, "split-K is instantiated for the 256 x 128 tile");
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int m = 0; m < MTH; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTH; ++n)
+                        acc[HK][j][m][n] += in[j][m][n];
+        };
+        if (khalf == 0) // workgroup-uniform
+            exchange(P0{});
+        else
+            exchange(P1{});
+    }
     const float* sc_l = reinterpret_cast<const float*>(lds + SC_OFF);
     const float* sr_l = sc_l + BN;
     // the four column scales of output columns [cl, cl + 4) / the row scale of tile row rl
@@ -752,6 +837,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
 #pragma unroll
                     for (int m = 0; m < MTH; ++m)
                     {
+                        if (KSPLIT && i != khalf) // (uniform: the other X-half is the partner's)
+                            continue;
                         const int rl = i * AH + (wr * MTH + m) * 16 + (lane & 15);
                         const float sr = row_scale(rl);
                         const acc_t a = acc[i][j][m][n];
@@ -767,6 +854,8 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         {
             const int rl = k / PPR, pc = k % PPR;
             const int grow = m0 + rl, gcol = n0 + pc * 8;
+            if (KSPLIT && rl / AH != khalf)
+                continue;
             if (grow < M && gcol < N)
             {
                 uint4 v = *reinterpret_cast<const uint4*>(ot + rl * PITCH + pc * 16);
@@ -810,7 +899,7 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                 {
                     const int rl = i * AH + (wr * MTH + m) * 16 + (lane & 15);
                     const int row = m0 + rl;
-                    if (row >= M)
+                    if (row >= M || (KSPLIT && i != khalf))
                         continue;
                     const float sr = row_scale(rl);
                     const float4 sc4 = col_scales(cl);
@@ -841,16 +930,39 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         }
 }
 
-template <int WR, int WC, int MTH, int NTH, int DP0, int DP1, bool PRIO, int ABL = 0, int RSP = 0, bool DUAL = false, bool SCL = true,
-    bool F16 = false, bool PERSIST = false>
-int launch_sqp(const GemmParams& p, hipStream_t stream)
+// split-K workspace of a stream (two GEMMs of one stream never overlap; two streams must not share the slabs), per device
+void* ksplit_workspace(hipStream_t stream, size_t bytes)
 {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> ws;
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    auto& e = ws[std::make_pair(dev, stream)];
+    if (e.second < bytes)
+    {
+        // (a hipMalloc: not inside a stream capture - the first use of a shape comes from the tactic profile or an eager prefill)
+        void* d = nullptr;
+        if (hipMalloc(&d, bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess)
+            return nullptr;
+        if (e.first)
+            (void) hipFree(e.first);
+        e = std::make_pair(d, bytes);
+    }
+    return e.first;
+}
+
+template <int WR, int WC, int MTH, int NTH, int DP0, int DP1, bool PRIO, int ABL = 0, int RSP = 0, bool DUAL = false, bool SCL = true,
+    bool F16 = false, bool PERSIST = false, bool KSPLIT = false>
+int launch_sqp(const GemmParams& pin, hipStream_t stream)
+{
+    GemmParams p = pin;
     constexpr int BM = 2 * WR * MTH * 16, BN = 2 * WC * NTH * 16;
     // operand buffers + the tile's scales (PERSIST: two scale areas + the staging rows of one output round)
     constexpr size_t smem = (size_t) 2 * (BM + BN) * 128 + (SCL ? (BM + BN) * 4 : 0) * (PERSIST ? 2 : 1)
         + (PERSIST ? (DUAL ? BM * (BN / 2 + 16) : WR * 16 * (BN * 2 + 16)) : 0);
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP, DUAL, SCL, F16, PERSIST>;
+    auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP, DUAL, SCL, F16, PERSIST, KSPLIT>;
     static std::atomic<bool> attr_done{false};
     if (!attr_done)
     {
@@ -874,6 +986,23 @@ int launch_sqp(const GemmParams& p, hipStream_t stream)
         }
         const int rounds = (tiles + cus - 1) / cus;
         grid = (tiles + rounds - 1) / rounds;
+    }
+    if constexpr (KSPLIT)
+    {
+        // two workgroups per tile, one per CU (the tile's LDS leaves no room for a second), both resident: 2 x tiles <= CUs
+        int dev = 0, cus = 0;
+        (void) hipGetDevice(&dev);
+        (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (2 * tiles > cus || p.K * (F16 ? 2 : 1) / 128 < 4)
+            return 1;
+        grid = 2 * tiles;
+        constexpr size_t SLAB = (size_t) 2 * MTH * NTH * WR * WC * 64 * 16;
+        p.ksplit_ws = ksplit_workspace(stream, (size_t) tiles * 2 * SLAB + (size_t) tiles * 2 * 4);
+        if (!p.ksplit_ws)
+        {
+            set_error("gemm_sqp: no split-K workspace");
+            return -1;
+        }
     }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * WR * WC), smem, stream, p);
     hipError_t e = hipGetLastError();
@@ -928,6 +1057,11 @@ int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
             return 1;
         return cfg == 60 ? launch_sqp<4, 2, 2, 3, 0, 6, false, 16, 0, false, true, false, true>(p, stream)
                          : launch_sqp<4, 2, 2, 2, 0, 4, false, 16, 0, false, true, false, true>(p, stream);
+    case 64: // r06: 256 x 128 as TWO workgroups per tile, each half of K (for N = 4096 at M = 1024: 128 tiles on 256 CUs)
+        if (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.residual) & 15))
+            return 1;
+        return launch_sqp<4, 2, 2, 2, 0, 4, false, 16, 0, false, true, false, false, true>(p, stream);
     case 63: // the same with the DMA slots of id 13 (after MFMA 2 / 8 of a phase): the production form
         if (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
             || (reinterpret_cast<uintptr_t>(p.residual) & 15) || p.K < 256)
@@ -985,6 +1119,11 @@ int launch_gemm_f16p(const GemmParams& pin, int cfg, hipStream_t stream)
             return 1;
         return cfg == 55 ? launch_sqp<4, 2, 2, 3, 2, 8, false, 16, 0, false, false, true, true>(p, stream)  // 256 x 192
                          : launch_sqp<4, 2, 2, 2, 0, 4, false, 16, 0, false, false, true, true>(p, stream); // 256 x 128
+    case 57: // r06: 256 x 128 as two workgroups per tile, each half of K
+        if (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.residual) & 15) || (reinterpret_cast<uintptr_t>(p.silu_gate) & 15))
+            return 1;
+        return launch_sqp<4, 2, 2, 2, 0, 4, false, 16, 0, false, false, true, false, true>(p, stream);
     default: return 1;
     }
 }

@@ -312,6 +312,8 @@ struct GemmParams
     const float* swiglu_qscale = nullptr;
     // microbench hook (tllm_gemm_set_clock_probe), set by the launchers only: 2 x uint64 per workgroup {shader cycles, 100 MHz ticks}
     void* clock_probe = nullptr;
+    // split-K-2 forms of gemm_sqp.hip (r06), set by the launcher only: per tile two slabs of AH x BN accumulators + two flag words
+    void* ksplit_ws = nullptr;
 };
 int launch_gemm(const GemmParams& p, hipStream_t stream);
 // fc and gate projections of the SmoothQuant MLP in one kernel with SwiGLU + static int8 quantisation in its epilogue

@@ -108,7 +108,7 @@ inline uint16_t float_to_half_bits(float x)
 
 extern "C" {
 
-int initLibNvInferPlugins(void* logger, const char* libNamespace)
+bool initLibNvInferPlugins(void* logger, const char* libNamespace)
 {
     (void) logger;
     (void) libNamespace;
@@ -116,7 +116,7 @@ int initLibNvInferPlugins(void* logger, const char* libNamespace)
         (void) registry();
         g_inited = true;
     });
-    return g_inited ? 1 : 0;
+    return g_inited;
 }
 
 int32_t getInferLibVersion(void)

@@ -85,7 +85,7 @@ def load_library():
     lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     c = ctypes
     lib.initLibNvInferPlugins.argtypes = [c.c_void_p, c.c_char_p]
-    lib.initLibNvInferPlugins.restype = c.c_int
+    lib.initLibNvInferPlugins.restype = c.c_bool  # the reference's signature (P/api/InferPlugin.cpp:149)
     lib.getInferLibVersion.restype = c.c_int32
     lib.tllm_last_error.restype = c.c_char_p
     lib.tllm_plugin_registry_size.restype = c.c_int32
