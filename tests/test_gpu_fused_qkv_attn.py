@@ -321,3 +321,49 @@ def test_expired_in_launch_wait_falls_back_and_repeats_the_request(fuse_o):
     np.testing.assert_array_equal(s.generate(ids, lens, NEW), want)
     assert s.fused_retries() == 1
     s.close()
+
+
+def test_two_sessions_generating_at_the_same_time_both_return_the_right_tokens():
+    """the one-launch form needs its whole grid resident, and nothing guarantees that when ANOTHER stream's kernels hold
+    CUs - two batch-1 sessions generating concurrently (two host threads, two streams) can each get part of their grid resident.
+    Whatever happens - both run through, or bounded waits expire, the sessions fall back and tllm_session_generate repeats the
+    request - each caller must get exactly the tokens of a session that never used the one-launch form, and nothing may hang."""
+    import threading
+    cfg, w, qm = weights(8, 1)
+    S, NEW = 300, 48
+    lens = np.array([S], np.int32)
+    prompts = [np.random.default_rng(90 + i).integers(3, cfg['vocab_size'], (1, S)).astype(np.int32) for i in range(2)]
+    want = []
+    ref = make(cfg, w, qm, 0, taps=False)
+    for ids in prompts:
+        ref.setup(1, S, NEW)
+        want.append(ref.generate(ids, lens, NEW))
+    ref.close()
+    sessions = [make(cfg, w, qm, 1, taps=False, fused_max_spins=3000) for _ in range(2)]  # (~3 ms per wait: a contended run stays short)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    for s_ in sessions:
+        s_.setup(1, S, NEW)
+        assert s_.decode_form() & 1
+    got, errs = [None, None], [None, None]
+    start = threading.Barrier(2)
+
+    def run(i):
+        try:
+            start.wait()
+            for _ in range(3):  # several requests back to back: the two sessions' launches interleave on the chip
+                got[i] = sessions[i].generate(prompts[i], lens, NEW, stream=streams[i].cuda_stream)
+        except BaseException as e:  # noqa: BLE001 - reported below
+            errs[i] = e
+
+    th = [threading.Thread(target=run, args=(i, )) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+        assert not t.is_alive(), 'a generate call hangs'
+    assert errs == [None, None], errs
+    for i in range(2):
+        np.testing.assert_array_equal(got[i], want[i])
+    print('retries behind expired waits:', [s_.fused_retries() for s_ in sessions], 'forms after the run:', [s_.decode_form() for s_ in sessions])
+    for s_ in sessions:
+        s_.close()
