@@ -333,25 +333,31 @@ def test_two_sessions_generating_at_the_same_time_both_return_the_right_tokens()
     S, NEW = 300, 48
     lens = np.array([S], np.int32)
     prompts = [np.random.default_rng(90 + i).integers(3, cfg['vocab_size'], (1, S)).astype(np.int32) for i in range(2)]
-    want = []
-    ref = make(cfg, w, qm, 0, taps=False)
-    for ids in prompts:
-        ref.setup(1, S, NEW)
-        want.append(ref.generate(ids, lens, NEW))
-    ref.close()
+    # two references per prompt: a session that never uses the one-launch form, and one that runs it undisturbed (the two differ by
+    # fp32 association in the attention merge, and random weights have near-ties: a request must equal the one whose path it took)
+    want = {0: [], 1: []}
+    for fuse in (0, 1):
+        ref = make(cfg, w, qm, fuse, taps=False)
+        for ids in prompts:
+            ref.setup(1, S, NEW)
+            want[fuse].append(ref.generate(ids, lens, NEW))
+        assert ref.fused_retries() == 0
+        ref.close()
     sessions = [make(cfg, w, qm, 1, taps=False, fused_max_spins=3000) for _ in range(2)]  # (~3 ms per wait: a contended run stays short)
     streams = [torch.cuda.Stream() for _ in range(2)]
     for s_ in sessions:
         s_.setup(1, S, NEW)
         assert s_.decode_form() & 1
-    got, errs = [None, None], [None, None]
+    took, errs = [[], []], [None, None]
     start = threading.Barrier(2)
 
     def run(i):
         try:
             start.wait()
-            for _ in range(3):  # several requests back to back: the two sessions' launches interleave on the chip
-                got[i] = sessions[i].generate(prompts[i], lens, NEW, stream=streams[i].cuda_stream)
+            for _ in range(4):  # several requests back to back: the two sessions' launches interleave on the chip
+                out = sessions[i].generate(prompts[i], lens, NEW, stream=streams[i].cuda_stream)
+                # the path this request's RESULT came from: still the one-launch form afterwards = it ran through undisturbed
+                took[i].append((1 if sessions[i].decode_form() & 1 else 0, out))
         except BaseException as e:  # noqa: BLE001 - reported below
             errs[i] = e
 
@@ -363,7 +369,9 @@ def test_two_sessions_generating_at_the_same_time_both_return_the_right_tokens()
         assert not t.is_alive(), 'a generate call hangs'
     assert errs == [None, None], errs
     for i in range(2):
-        np.testing.assert_array_equal(got[i], want[i])
-    print('retries behind expired waits:', [s_.fused_retries() for s_ in sessions], 'forms after the run:', [s_.decode_form() for s_ in sessions])
+        assert len(took[i]) == 4
+        for path, out in took[i]:
+            np.testing.assert_array_equal(out, want[path][i])
+    print('retries behind expired waits:', [s_.fused_retries() for s_ in sessions], 'paths per request:', [[p_ for p_, _ in t_] for t_ in took])
     for s_ in sessions:
         s_.close()
