@@ -148,7 +148,7 @@ def step_launches(cfg, mode, world, form, l_mean, int8_kv, smax):
     out = []
     if form & 1:
         nit = _fused_nit(smax, int8_kv)
-        name = 'qkv_attn_fused_kernel<%d, %s, %d>' % (nit, 'true' if int8_kv else 'false', {'sq': 0, 'woq8': 1, 'fp16': 2}.get(mode, 0))
+        name = 'qkv_attn_fused_kernel<%d, %s, %d>' % (nit, 'true' if int8_kv else 'false', {'sq': 0, 'woq8': 1, 'fp16': 2, 'woq4': 3}.get(mode, 0))
         b, what = qkv + kv - 3 * Dr * 2, 'RMSNorm -> QKV GEMV -> RoPE -> cache append -> attention'
         if form & 2:
             b, what = b + o - Dr * (1 if mode == 'sq' else 2), what + ' -> O-projection + residual'

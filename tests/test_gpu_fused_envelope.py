@@ -2,7 +2,7 @@
 O-projection stage where the session runs it) against the ORACLE across its envelope - not against
 the two-launch HIP path (tests/test_gpu_fused_qkv_attn.py does that, bit for bit): one decoder layer at LLaMA-7B dimensions,
 batch 1, contexts 3 / 40 of 49 padded / 700 / 2300 / 4000 (fp16 cache: up to 2000), static and per-token SmoothQuant,
-weight-only int8, fp16 weights, int8 and fp16 KV cache.
+weight-only int8 / int4, fp16 weights, int8 and fp16 KV cache.
 
 Both sides start from the SAME cache bytes (the session's synthetic context, read back and handed to the oracle as
 `start_caches`), so no 4000-token numpy prefill is needed and what is compared is the generation kernels alone.  Per step:
@@ -46,7 +46,8 @@ CASES = [('sq_static_pc', 1, [(3, 3), (49, 40), (700, 700), (2300, 2300), (4000,
          ('woq8', 0, [(49, 40), (2000, 2000)]),
          # fp16 weights (r06: two 8 KB tiles per row pair), BASELINE.json configs[1] = fp16 + fp16 cache; and with the int8 cache
          ('fp16', 0, [(3, 3), (49, 40), (700, 700), (2000, 2000)]),
-         ('fp16', 1, [(49, 40), (2300, 2300)])]
+         ('fp16', 1, [(49, 40), (2300, 2300)]),
+         ('woq4', 1, [(3, 3), (49, 40), (2300, 2300)])]
 
 
 @pytest.mark.parametrize('mode,int8_kv,shapes', CASES, ids=[f'{m}-kv{"8" if k else "16"}' for m, k, _ in CASES])

@@ -197,10 +197,12 @@ def woq_weights(layers, int8_kv, mode='woq8'):
 
 
 @pytest.mark.parametrize('S,pad,int8_kv,mode', [(3, 0, 1, 'woq8'), (40, 9, 1, 'woq8'), (1100, 0, 1, 'woq8'), (4000, 0, 1, 'woq8'), (300, 5, 0, 'woq8'),
-                                                 (3, 0, 0, 'fp16'), (40, 9, 0, 'fp16'), (1100, 0, 0, 'fp16'), (1900, 0, 0, 'fp16'), (2300, 0, 1, 'fp16')])
+                                                 (3, 0, 0, 'fp16'), (40, 9, 0, 'fp16'), (1100, 0, 0, 'fp16'), (1900, 0, 0, 'fp16'), (2300, 0, 1, 'fp16'),
+                                                 (3, 0, 1, 'woq4'), (40, 9, 1, 'woq4'), (1100, 0, 1, 'woq4'), (4000, 0, 1, 'woq4'), (300, 5, 0, 'woq4')])
 def test_weight_only_int8_fused_launch_equals_the_two_launches(S, pad, int8_kv, mode):
     """(mode fp16, r06: the same launch on FP16 projection weights - rows of 8 KB as two 8 KB tiles per row pair through the same
-    two-buffer ring, v_dot2_f32_f16 in the chunk order of gemv_kernel<W_FP16, PK_NORM>; BASELINE.json configs[1].)
+    two-buffer ring, v_dot2_f32_f16 in the chunk order of gemv_kernel<W_FP16, PK_NORM>; BASELINE.json configs[1].  mode woq4: weight-only
+    int4 rows of 2 KB, the half-raw nibble splices and the two running sums of gemv_kernel<W_INT4_WOQ, PK_NORM>.)
     The fused launch on WEIGHT-ONLY int8 projection weights (r05: BASELINE.json configs[2]; reference: the
     WeightOnlyQuantMatmul plugin in front of the attention plugin, P/weightOnlyQuantMatmulPlugin + MM/...Template.h) against the
     two launches it replaces (gemv_kernel<W_INT8_WOQ, PK_NORM> + mmha_partial_kernel).  The fused projection restates the unfused
@@ -255,14 +257,15 @@ def test_weight_only_int8_fused_launch_equals_the_two_launches(S, pad, int8_kv, 
         assert bad.sum() <= max(2, 1e-5 * bad.size) and np.all(np.abs(ca - cb)[bad] <= 2.0 ** -10 * np.maximum(np.abs(ca[bad]), 2.0 ** -14) * 1.01), bad.sum()
 
 
-@pytest.mark.parametrize('S,pad,int8_kv', [(3, 0, 1), (40, 9, 1), (1100, 0, 1), (4000, 0, 1), (300, 5, 0)])
-def test_weight_only_o_projection_stage_equals_the_gemv_launch(S, pad, int8_kv):
+@pytest.mark.parametrize('S,pad,int8_kv,mode', [(3, 0, 1, 'woq8'), (40, 9, 1, 'woq8'), (1100, 0, 1, 'woq8'), (4000, 0, 1, 'woq8'), (300, 5, 0, 'woq8'),
+                                                 (3, 0, 1, 'woq4'), (40, 9, 1, 'woq4'), (1100, 0, 1, 'woq4'), (4000, 0, 1, 'woq4'), (300, 5, 0, 'woq4')])
+def test_weight_only_o_projection_stage_equals_the_gemv_launch(S, pad, int8_kv, mode):
     """The O-projection stage on weight-only int8 weights (the context row travels as fp16, two elements per granule) against the
     GEMV launch it replaces (gemv_kernel<W_INT8_WOQ, PK_NONE, EK_RESIDUAL>): the row workers restate that kernel's arithmetic AND
     order - raw byte splices, per-lane runs over the four 1 KiB chunks of a row, the cross-lane sum, 1152 * sum(ctx) in the
     prologue's association - so everything behind it is identical: logits of every step, tokens, every cache byte."""
     layers, NEW = 2, 7
-    cfg, w, qm = woq_weights(layers, int8_kv)
+    cfg, w, qm = woq_weights(layers, int8_kv, mode)  # (woq4, r06: rows of 2 KB, gemv_kernel<W_INT4_WOQ, PK_NONE, EK_RESIDUAL> restated)
     max_in = S + pad
     r = np.random.default_rng(400 + S)
     ids = np.full((1, max_in), 2, np.int32)
@@ -273,6 +276,7 @@ def test_weight_only_o_projection_stage_equals_the_gemv_launch(S, pad, int8_kv):
     for fuse_o in (0, 1):
         s = make(cfg, w, qm, 1, fuse_o=fuse_o)
         s.setup(1, max_in, NEW)
+        assert s.decode_form() == (3 if fuse_o else 1)
         s.context(ids, lens)
         rec = dict(o_in=[], mlp_in=[], logits=[s.logits()])
         for i in range(NEW - 1):

@@ -119,23 +119,7 @@ __device__ __forceinline__ float dot_u4x8(uint32_t w, const uint4& x, float acc)
     return acc;
 }
 
-// Half raw: the nibbles spliced as 1024 + 16 n (elements 2 3 6 7 of the word) go into the dot product as they are and
-// 72 * sum(x_b) - one number per activation row - comes off the finished sum:  sum_k (n_k - 8) x_k = a + b / 16 - 72 sum(x_b).
-// The nibbles spliced as 1024 + n (elements 0 1 4 5) are brought to n - 8 exactly before the dot product: taken raw as well
-// (r02: 1032 * sum(x_a) off the sum) their bias is 220 x the signal, and with a DC offset in the activations (x = 3 + N(0, 1),
-// K = 11008) the fp32 rounding of that sum no longer cancels: 1.5 fp16 ulp of error at the output (ADVICE r2,
-// tests/test_gpu_plugins.py::test_weight_only_gemv_with_a_dc_offset_in_the_activations).  The 1024 + 16 n splice has the
-// bias : signal ratio of the int8 path (16 x) and stays raw.  2 of 12 VALU per 8 weights saved instead of 4.
-__device__ __forceinline__ void dot_u4x8_raw(uint32_t w, const uint4& x, float& a, float& b)
-{
-    const uint32_t m = 0x64006400u;
-    const uint32_t w8 = w >> 8;
-    const h2_t b0 = {(_Float16) 1032.f, (_Float16) 1032.f}; // 1024 + 8
-    a = __builtin_amdgcn_fdot2(u32_as_h2((w & 0x000f000fu) | m) - b0, u32_as_h2(x.x), a, false);
-    b = __builtin_amdgcn_fdot2(u32_as_h2((w & 0x00f000f0u) | m), u32_as_h2(x.y), b, false);
-    a = __builtin_amdgcn_fdot2(u32_as_h2((w8 & 0x000f000fu) | m) - b0, u32_as_h2(x.z), a, false);
-    b = __builtin_amdgcn_fdot2(u32_as_h2((w8 & 0x00f000f0u) | m), u32_as_h2(x.w), b, false);
-}
+// (dot_u4x8_raw - the half-raw int4 splice - lives in dev_utils.h next to dot_woq8_raw: qkv_attn_fused.hip restates this path too)
 
 __device__ __forceinline__ int dot_sq(const uint4& w, const uint4& x, int acc)
 {

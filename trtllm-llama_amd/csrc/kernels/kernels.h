@@ -195,6 +195,7 @@ struct FusedQkvAttnParams
     const void* scale_col = nullptr; // SmoothQuant: f32 [3 * H * Dh] (per_channel) or [1]; weight-only: fp16 [3 * H * Dh]
     int32_t per_channel = 0;
     int32_t woq8 = 0; // 1: weight-only int8 rows (u8 = q + 128) against the normalised fp16 row; no quantiser
+    int32_t woq4 = 0;   // 1 (r06): weight-only int4 rows (ldw = K / 2 bytes, fp16 scales) against the normalised fp16 row; two-stage form
     int32_t fp16_w = 0; // 1 (r06): fp16 rows (ldw = 2 K bytes, no scales) against the normalised fp16 row; no quantiser, no O-projection stage
     const float* act_quant_scale = nullptr;   // f32 [1]: static quantiser of the normalised row; null -> per-token (amax / 127)
     const float* act_dequant_scale = nullptr; // f32 [1]: the static activation scale of the dequantisation
@@ -231,10 +232,10 @@ struct FusedQkvAttnParams
     void* x_out = nullptr;                 // fp16 [o_n]: may be x itself (every workgroup has consumed x long before)
 };
 size_t qkv_attn_fused_xchg_bytes(int32_t num_heads);
-bool qkv_attn_fused_serves_o(int32_t num_heads, int32_t head_size, int32_t o_n, int32_t o_k, int64_t o_ldw);
+bool qkv_attn_fused_serves_o(int32_t num_heads, int32_t head_size, int32_t o_n, int32_t o_k, int64_t o_ldw, int32_t weight_kind = 0);
 // (woq8 / o_stage decide the instance and its dynamic LDS: the residency check - occupancy query x CUs of the current device >= grid
 // - is made for exactly the launch that will run)
-// weight_kind: 0 SmoothQuant int8, 1 weight-only int8, 2 fp16
+// weight_kind: 0 SmoothQuant int8, 1 weight-only int8, 2 fp16, 3 weight-only int4
 bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int32_t max_seq_len, int32_t int8_kv, int32_t weight_kind = 0,
     int32_t o_stage = 0);
 int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream);

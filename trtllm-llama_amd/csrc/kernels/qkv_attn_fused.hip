@@ -188,13 +188,18 @@ __device__ __forceinline__ float groups_max(float v)
 // ring (q.lo q.hi k.lo k.hi v.lo v.hi alternate through the two register buffers), the normalised fp16 row in LDS, v_dot2_f32_f16 in
 // the per-lane chunk order of gemv_impl.h's W_FP16 path, no scales: bit-identical projection.  Two-stage form (no O-projection stage:
 // 19 rows of 8 KB do not fit the row worker's LDS).
-constexpr int WK_SQ = 0, WK_WOQ8 = 1, WK_FP16 = 2;
+// WK = 3 (r06): weight-only int4 (nibble = q + 8 in the even / odd word order of weight_layout.h) - rows of 2 KB = HALF a tile per row
+// pair (two 1 KiB chunks), the half-raw splices of gemv_impl.h's W_INT4_WOQ path (two running sums per row, 72 * sum(x_b) off once per
+// row): bit-identical projection.  Two-stage form.
+constexpr int WK_SQ = 0, WK_WOQ8 = 1, WK_FP16 = 2, WK_WOQ4 = 3;
 template <int NIT, bool INT8KV, int WK = WK_SQ>
 __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnParams p)
 {
-    constexpr bool WOQ = WK == WK_WOQ8, F16W = WK == WK_FP16;
+    constexpr bool WOQ = WK == WK_WOQ8, F16W = WK == WK_FP16, WOQ4 = WK == WK_WOQ4;
     constexpr bool HALFX = WK != WK_SQ; // the projection's operand row stays fp16 (no quantiser)
-    constexpr int KH = F16W ? 2 : 1;    // 8 KB tiles per row pair (4 x 1 KiB chunks x 2 rows each)
+    constexpr int KH = F16W ? 2 : 1;    // tiles per row pair
+    constexpr int KCT = WOQ4 ? 2 : kKChunks; // 1 KiB chunks per tile and row (int4: a row is 2 KiB)
+    constexpr bool WOQX = WOQ || WOQ4;       // weight-only: fp16 scales, the context row travels to the row workers as fp16
     constexpr int NT = 3 * KH;          // tiles per wave: q, k, v
     constexpr int EPL = INT8KV ? 16 : 8; // cache elements per lane (16 bytes)
     constexpr int LPR = kDH / EPL;       // lanes per cache row
@@ -251,13 +256,13 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     {
         const int row = o_r0 + wid + 8 * i;
         const bool on = row < o_r1; // wave-uniform
-        if constexpr (WOQ)
+        if constexpr (WOQX)
             o_cs[i] = on ? h2f(reinterpret_cast<const uint16_t*>(p.o_scale_col)[row]) : 0.f;
         else
             o_cs[i] = on ? reinterpret_cast<const float*>(p.o_scale_col)[p.o_per_channel ? row : 0] : 0.f;
         o_res[i] = on ? h2f(reinterpret_cast<const uint16_t*>(p.x)[row]) : 0.f;
     }
-    if (o_stage && !WOQ)
+    if (o_stage && WK == WK_SQ)
         o_rs = p.o_scale_row[0];
     // launch constants, requested before anything else (and before the kernel's first store: behind one hipcc no longer uses the
     // scalar path for them, and as vector loads behind the q rows they held the prologue until the q rows had arrived)
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
 #pragma unroll
         for (int r = 0; r < 2; ++r)
         {
-            if constexpr (WOQ)
+            if constexpr (WOQ || WOQ4)
                 cscale[i][r] = h2f(reinterpret_cast<const uint16_t*>(p.scale_col)[wrow[i] + r]);
             else if constexpr (F16W)
                 cscale[i][r] = 1.f;
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     // tile t of the wave's stream: matrix t / KH (q, k, v), chunks [4 (t % KH), + 4) of its two rows
     auto load_tile = [&](int t, uint4 (&wt)[kKChunks][2]) {
 #pragma unroll
-        for (int u = 0; u < kKChunks; ++u)
+        for (int u = 0; u < KCT; ++u)
 #pragma unroll
             for (int r = 0; r < 2; ++r)
                 wt[u][r] = ld_nt16(wbase + (int64_t) (wrow[t / KH] + r) * p.ldw + ((t % KH) * kKChunks + u) * 1024 + lane * 16);
@@ -358,9 +363,9 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             xs4[q] = h2_as_u32(hh);
             amax = fmaxf(amax, fmaxf(fabsf((float) hh.x), fabsf((float) hh.y)));
         }
-        if constexpr (WOQ)
+        if constexpr (WOQ || WOQ4)
         {
-            // the splice bias 1152 * sum of the normalised row (fp16 values, fp32 sums) in the unfused prologue's order: thread
+            // the splice bias 1152 * sum of the normalised row (int4: 72 * the sum over the halves that face the 1024 + 16 n splices) (fp16 values, fp32 sums) in the unfused prologue's order: thread
             // t < 256 of that kernel owns vectors t and t + 256 - both are in this thread's registers (t2 = tid & 255), so waves
             // 0 - 3 restate its sums and waves 4 - 7 repeat them
             const uint4 ga = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(p.gamma) + t2 * 8);
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
                     else
                         sa += y0 + y1;
                 }
-            const float bsum = wave_sum(1152.f * (sa + sb));
+            const float bsum = wave_sum(WOQ4 ? 72.f * sb : 1152.f * (sa + sb));
             if (lane == 0 && wid < 4)
                 red[8 + wid] = bsum;
         }
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     }
     __syncthreads();
     float xbias = 0.f;
-    if constexpr (WOQ)
+    if constexpr (WOQ || WOQ4)
         xbias = red[8] + red[9] + red[10] + red[11];
     TLLM_STAMP(1);
     // (b2) the k rows, (c) the member's cache rows and masks
@@ -450,6 +455,36 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
 
     // ------------------------------------------------------------------ 2. the projections, one granule per wave and matrix
     auto project = [&](const uint4 (&wt)[kKChunks][2], int i) {
+        if constexpr (WOQ4)
+        {
+            // lane l, chunk u: 32 nibbles k = (u * 64 + l) * 32 .. + 32 against the 32 halfs of x at the same k (four LDS vectors)
+            float fa0 = 0.f, fb0 = 0.f, fa1 = 0.f, fb1 = 0.f;
+#pragma unroll
+            for (int u = 0; u < KCT; ++u)
+            {
+                const char* xr = xs + (u * 64 + lane) * 64;
+                const uint4 x0 = *reinterpret_cast<const uint4*>(xr), x1 = *reinterpret_cast<const uint4*>(xr + 16);
+                const uint4 x2 = *reinterpret_cast<const uint4*>(xr + 32), x3 = *reinterpret_cast<const uint4*>(xr + 48);
+                dot_u4x8_raw(wt[u][0].x, x0, fa0, fb0);
+                dot_u4x8_raw(wt[u][0].y, x1, fa0, fb0);
+                dot_u4x8_raw(wt[u][0].z, x2, fa0, fb0);
+                dot_u4x8_raw(wt[u][0].w, x3, fa0, fb0);
+                dot_u4x8_raw(wt[u][1].x, x0, fa1, fb1);
+                dot_u4x8_raw(wt[u][1].y, x1, fa1, fb1);
+                dot_u4x8_raw(wt[u][1].z, x2, fa1, fb1);
+                dot_u4x8_raw(wt[u][1].w, x3, fa1, fb1);
+            }
+            // gemv_impl.h: tot = sum(a) + sum(b) / 16, then the bias, then fp16(. * scale)
+            float t0 = wave_sum(fa0), t1 = wave_sum(fa1);
+            t0 += wave_sum(fb0) * 0.0625f;
+            t1 += wave_sum(fb1) * 0.0625f;
+            t0 -= xbias;
+            t1 -= xbias;
+            const uint32_t v = (uint32_t) f2h(t0 * (cscale[i][0] * 1.f)) | ((uint32_t) f2h(t1 * (cscale[i][1] * 1.f)) << 16);
+            if (lane == 0)
+                st_granule(gx + i * 64 + mem * 8 + wid, tag, v);
+            return;
+        }
         if constexpr (WOQ)
         {
             // lane l, chunk u: weights k = (u * 64 + l) * 16 .. + 16 against the 16 halfs of x at the same k (two LDS vectors)
@@ -754,8 +789,8 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             if (o_r0 + slot < o_r1) // wave-uniform
             {
 #pragma unroll
-                for (int u = 0; u < kKChunks; ++u)
-                    glds16(owb + (int64_t) (o_r0 + slot) * p.o_ldw + u * 1024 + lane * 16, wo_base + (slot * kKChunks + u) * 1024);
+                for (int u = 0; u < KCT; ++u)
+                    glds16(owb + (int64_t) (o_r0 + slot) * p.o_ldw + u * 1024 + lane * 16, wo_base + (slot * KCT + u) * 1024);
             }
         }
     }
@@ -787,7 +822,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         // every head's context row - int8, four elements per granule: 1024 granules, two per thread; weight-only: fp16, two per
         // granule: 2048, four per thread - behind the DMA in the queue
         {
-            constexpr int NG = WOQ ? 4 : 2;
+            constexpr int NG = WOQX ? 4 : 2;
             const gu64* gbase = gc + tid;
             unsigned long long g[NG];
             int spins = 0;
@@ -825,7 +860,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             return;
         }
         float obias = 0.f;
-        if constexpr (WOQ)
+        if constexpr (WOQX)
         {
             // the splice bias 1152 * sum(ctx) in the unfused GEMV's order (thread t < 256 owns vectors t and t + 256 of the row)
             if (wid < 4)
@@ -845,7 +880,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
                         else
                             sa += (float) hh.x + (float) hh.y;
                     }
-                const float bsum = wave_sum(1152.f * (sa + sb));
+                const float bsum = wave_sum(WOQ4 ? 72.f * sb : 1152.f * (sa + sb));
                 if (lane == 0)
                     red[8 + wid] = bsum;
             }
@@ -854,13 +889,22 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         }
         // rows r0 + wid, + 8, + 16 of the worker (any wave reads any row: the barrier above is behind every wave's vmcnt(0)); the
         // three dot products and their cross-lane sums side by side
-        using oacc_t = typename std::conditional<WOQ, float, int>::type;
+        using oacc_t = typename std::conditional<WOQX, float, int>::type;
         oacc_t acc[3] = {0, 0, 0};
+        float accb[3] = {0.f, 0.f, 0.f}; // int4: the running sums over the 1024 + 16 n splices
 #pragma unroll
-        for (int u = 0; u < kKChunks; ++u)
+        for (int u = 0; u < KCT; ++u)
         {
-            uint4 xr, xr2;
-            if constexpr (WOQ)
+            uint4 xr, xr2, xr3, xr4;
+            if constexpr (WOQ4)
+            {
+                const char* xp = xs + (u * 64 + lane) * 64;
+                xr = *reinterpret_cast<const uint4*>(xp);
+                xr2 = *reinterpret_cast<const uint4*>(xp + 16);
+                xr3 = *reinterpret_cast<const uint4*>(xp + 32);
+                xr4 = *reinterpret_cast<const uint4*>(xp + 48);
+            }
+            else if constexpr (WOQ)
             {
                 xr = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * 32);
                 xr2 = *reinterpret_cast<const uint4*>(xs + (u * 64 + lane) * 32 + 16);
@@ -871,8 +915,15 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             for (int i = 0; i < 3; ++i)
             {
                 const int slot = wid + 8 * i < o_r1 - o_r0 ? wid + 8 * i : 0; // (a row that does not exist: slot 0, result dropped)
-                const uint4 wv = *reinterpret_cast<const uint4*>(wo_lds + (slot * kKChunks + u) * 1024 + lane * 16);
-                if constexpr (WOQ)
+                const uint4 wv = *reinterpret_cast<const uint4*>(wo_lds + (slot * KCT + u) * 1024 + lane * 16);
+                if constexpr (WOQ4)
+                {
+                    dot_u4x8_raw(wv.x, xr, acc[i], accb[i]);
+                    dot_u4x8_raw(wv.y, xr2, acc[i], accb[i]);
+                    dot_u4x8_raw(wv.z, xr3, acc[i], accb[i]);
+                    dot_u4x8_raw(wv.w, xr4, acc[i], accb[i]);
+                }
+                else if constexpr (WOQ)
                     acc[i] = dot_woq8_raw(wv, xr, xr2, acc[i]);
                 else
                 {
@@ -885,7 +936,11 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
+        {
             acc[i] = wave_sum(acc[i]);
+            if constexpr (WOQ4)
+                acc[i] += wave_sum(accb[i]) * 0.0625f; // (gemv_impl.h: tot = sum(a) + sum(b) / 16)
+        }
         // epilogue of the unfused GEMV (gemv_impl.h, EPI_RESIDUAL): fp16(fp16(float(acc) * (scale_col * scale_row)) + residual)
         // (weight-only: (sum - bias) * scale, scale_row = 1)
         if (lane < 3)
@@ -1004,7 +1059,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
             reinterpret_cast<int8_t*>(p.out_q8)[oi] = q8;
             reinterpret_cast<int8_t*>(red)[d] = q8; // (the prologue's scratch: free since the first barrier)
         }
-        if constexpr (WOQ)
+        if constexpr (WOQX)
             reinterpret_cast<uint16_t*>(red)[d] = h16; // weight-only: the row travels as fp16
     }
     else if (tid < kDH + 16)
@@ -1047,7 +1102,7 @@ __global__ __launch_bounds__(512) void qkv_attn_fused_kernel(const FusedQkvAttnP
     if (o_stage) // uniform: the context row to the row workers, four int8 per granule
     {
         __syncthreads(); // F
-        constexpr int CG = WOQ ? kCtxGranulesH : kCtxGranules;
+        constexpr int CG = WOQX ? kCtxGranulesH : kCtxGranules;
         if (tid < CG)
             st_granule(gc + h * CG + tid, tag, reinterpret_cast<const uint32_t*>(red)[tid]);
     }
@@ -1077,6 +1132,7 @@ const void* fused_kernel(int nit, bool int8_kv, int wk)
     {
     case WK_WOQ8: return int8_kv ? fused_kernel_of<true, WK_WOQ8>(nit) : fused_kernel_of<false, WK_WOQ8>(nit);
     case WK_FP16: return int8_kv ? fused_kernel_of<true, WK_FP16>(nit) : fused_kernel_of<false, WK_FP16>(nit);
+    case WK_WOQ4: return int8_kv ? fused_kernel_of<true, WK_WOQ4>(nit) : fused_kernel_of<false, WK_WOQ4>(nit);
     default: return int8_kv ? fused_kernel_of<true, WK_SQ>(nit) : fused_kernel_of<false, WK_SQ>(nit);
     }
 }
@@ -1155,11 +1211,12 @@ size_t qkv_attn_fused_xchg_bytes(int32_t num_heads)
 
 // the O-projection stage: K = H * Dh = 4 KiB rows (the context row is swept by 512 threads x two granules), every row worker's
 // share of the rows fits its LDS area
-bool qkv_attn_fused_serves_o(int32_t num_heads, int32_t head_size, int32_t o_n, int32_t o_k, int64_t o_ldw)
+bool qkv_attn_fused_serves_o(int32_t num_heads, int32_t head_size, int32_t o_n, int32_t o_k, int64_t o_ldw, int32_t weight_kind)
 {
     const int workers = (kMembers - 1) * num_heads;
+    const int64_t row_bytes = weight_kind == WK_WOQ4 ? o_k / 2 : o_k; // (int8 kinds; fp16 has no such stage)
     return head_size == kDH && o_k == num_heads * head_size && o_k == kKChunks * 1024 && num_heads * kCtxGranules == 1024
-        && o_ldw % 16 == 0 && o_ldw >= o_k && o_n > 0 && (o_n + workers - 1) / workers <= kORowsMax;
+        && o_ldw % 16 == 0 && o_ldw >= row_bytes && o_n > 0 && (o_n + workers - 1) / workers <= kORowsMax && weight_kind != WK_FP16;
 }
 
 bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int32_t max_seq_len, int32_t int8_kv, int32_t weight_kind,
@@ -1167,7 +1224,7 @@ bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int3
 {
     const int nit = pick_nit(max_seq_len, int8_kv != 0);
     // (K = 4096 elements: rows of 4 KiB int8 / 8 KiB fp16 = one / two tiles of 4 x 1 KiB chunks x 2 rows)
-    if (K != kKChunks * 1024 || head_size != kDH || nit == 0 || weight_kind < WK_SQ || weight_kind > WK_FP16)
+    if (K != kKChunks * 1024 || head_size != kDH || nit == 0 || weight_kind < WK_SQ || weight_kind > WK_WOQ4)
         return false;
     if (weight_kind == WK_FP16 && o_stage)
         return false; // the row worker's share of an fp16 dense projection does not fit its LDS
@@ -1188,7 +1245,7 @@ bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int3
 int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream)
 {
     const bool o_stage = p.o_w != nullptr;
-    const int wk = p.fp16_w ? WK_FP16 : (p.woq8 ? WK_WOQ8 : WK_SQ);
+    const int wk = p.fp16_w ? WK_FP16 : (p.woq4 ? WK_WOQ4 : (p.woq8 ? WK_WOQ8 : WK_SQ));
     if (!qkv_attn_fused_serves(p.K, p.num_heads, p.head_size, p.max_seq_len, p.int8_kv, wk, o_stage ? 1 : 0))
     {
         set_error("fused QKV + attention: shape not served or grid not resident (K %d, heads %d x %d, cache %d, O stage %d)", p.K,
@@ -1203,21 +1260,26 @@ int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream)
         return -1;
     }
     if (p.o_w
-        && ((!p.woq8 && (!p.out_q8 || !p.o_scale_row)) || !p.o_scale_col || !p.x_out
-            || !qkv_attn_fused_serves_o(p.num_heads, p.head_size, p.o_n, p.num_heads * p.head_size, p.o_ldw)))
+        && ((!p.woq8 && !p.woq4 && (!p.out_q8 || !p.o_scale_row)) || !p.o_scale_col || !p.x_out
+            || !qkv_attn_fused_serves_o(p.num_heads, p.head_size, p.o_n, p.num_heads * p.head_size, p.o_ldw, wk)))
     {
         set_error("fused QKV + attention: the O-projection stage needs the static int8 context row and a dense projection of %d x %d",
             p.num_heads * p.head_size, p.num_heads * p.head_size);
         return -1;
     }
-    if ((p.woq8 || p.fp16_w) && (p.out_q8 || p.act_quant_scale))
+    if ((p.woq8 || p.fp16_w || p.woq4) && (p.out_q8 || p.act_quant_scale))
     {
         set_error("fused QKV + attention: the weight-only / fp16 forms have no quantiser");
         return -1;
     }
-    if (p.fp16_w && (p.woq8 || p.ldw != (int64_t) p.K * 2))
+    if (p.fp16_w && (p.woq8 || p.woq4 || p.ldw != (int64_t) p.K * 2))
     {
         set_error("fused QKV + attention: fp16 weights are dense rows of K halfs");
+        return -1;
+    }
+    if (p.woq4 && (p.woq8 || p.ldw != (int64_t) p.K / 2))
+    {
+        set_error("fused QKV + attention: int4 weights are dense rows of K / 2 bytes");
         return -1;
     }
     const void* kfn = fused_kernel(pick_nit(p.max_seq_len, p.int8_kv != 0), p.int8_kv != 0, wk);

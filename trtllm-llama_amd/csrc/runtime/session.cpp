@@ -920,6 +920,7 @@ struct tllm_session
                     f.per_channel = L.qkv.per_channel;
                     f.woq8 = L.qkv.wtype == W_INT8_WOQ ? 1 : 0;
                     f.fp16_w = L.qkv.wtype == W_FP16 ? 1 : 0;
+                    f.woq4 = L.qkv.wtype == W_INT4_WOQ ? 1 : 0;
                     f.act_quant_scale = (per_token || !sq) ? nullptr : L.ln1_scale;
                     f.act_dequant_scale = (per_token || !sq) ? nullptr : L.qkv.act_scale;
                     f.int8_kv = int8_kv;
@@ -1630,14 +1631,16 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
     // (... or - r06 - fp16: rows of 8 KB, two tiles per row pair; BASELINE.json configs[1])
     const bool woq8_all = !s->sq && !s->layers.empty() && s->layers[0].qkv.wtype == W_INT8_WOQ;
     const bool fp16_all = !s->sq && !s->layers.empty() && s->layers[0].qkv.wtype == W_FP16;
-    const int wkind = s->sq ? 0 : (woq8_all ? 1 : 2); // qkv_attn_fused_serves' weight_kind
-    if (s->fuse_qkv_cfg != 0 && s->attn_tail && B == 1 && s->beam == 1 && !s->paged_kv && s->tp == 1 && (s->sq || woq8_all || fp16_all)
+    const bool woq4_all = !s->sq && !s->layers.empty() && s->layers[0].qkv.wtype == W_INT4_WOQ;
+    const int wkind = s->sq ? 0 : (woq8_all ? 1 : (fp16_all ? 2 : 3)); // qkv_attn_fused_serves' weight_kind
+    if (s->fuse_qkv_cfg != 0 && s->attn_tail && B == 1 && s->beam == 1 && !s->paged_kv && s->tp == 1
+        && (s->sq || woq8_all || fp16_all || woq4_all)
         && s->neox && qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, wkind, 0))
     {
         bool ok = true;
         for (auto& L : s->layers)
-            ok = ok && L.qkv.wtype == (s->sq ? W_INT8_SQ : (woq8_all ? W_INT8_WOQ : W_FP16)) && L.qkv.K == D
-                && L.qkv.ldw == (fp16_all ? 2 * D : D) && L.qkv.N == 3 * s->Dr && (L.qkv.scale_col || fp16_all);
+            ok = ok && L.qkv.wtype == (s->sq ? W_INT8_SQ : (woq8_all ? W_INT8_WOQ : (fp16_all ? W_FP16 : W_INT4_WOQ))) && L.qkv.K == D
+                && L.qkv.ldw == (fp16_all ? 2 * D : (woq4_all ? D / 2 : D)) && L.qkv.N == 3 * s->Dr && (L.qkv.scale_col || fp16_all);
         if (ok)
         {
             const size_t xb = qkv_attn_fused_xchg_bytes(s->Hr);
@@ -1645,11 +1648,14 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
             HIP_OK(hipMemset(s->fused_xchg, 0, xb));
             s->qkv_attn_fused = true;
             // (tp == 1 here: no all-reduce behind the projection.  Weight-only int8: the context row travels as fp16)
-            s->o_fused = s->fuse_o_cfg != 0 && !fp16_all && (s->sq ? !s->per_token : true);
+            // (int4: the stage is built and bit-identical but measures at par with the GEMV launch it replaces - 724 vs 721 - 735 tokens/s -
+            //  so it is on only when asked for: fuse_o_projection = 1)
+            s->o_fused = s->fuse_o_cfg != 0 && !fp16_all && (woq4_all ? s->fuse_o_cfg > 0 : true) && (s->sq ? !s->per_token : true);
             for (auto& L : s->layers)
                 s->o_fused = s->o_fused && L.dense.N == D && L.dense.scale_col
-                    && (s->sq ? (L.dense.wtype == W_INT8_SQ && L.dense.act_scale && L.attn_qscale) : L.dense.wtype == W_INT8_WOQ)
-                    && qkv_attn_fused_serves_o(s->Hr, s->Dh, L.dense.N, L.dense.K, L.dense.ldw);
+                    && (s->sq ? (L.dense.wtype == W_INT8_SQ && L.dense.act_scale && L.attn_qscale)
+                              : L.dense.wtype == (woq4_all ? W_INT4_WOQ : W_INT8_WOQ))
+                    && qkv_attn_fused_serves_o(s->Hr, s->Dh, L.dense.N, L.dense.K, L.dense.ldw, wkind);
             // ... and the instance that will run must be resident as a whole (occupancy query x CUs of this device >= its grid)
             if (!qkv_attn_fused_serves(D, s->Hr, s->Dh, Smax, s->int8_kv ? 1 : 0, wkind, s->o_fused ? 1 : 0))
             {
