@@ -948,3 +948,50 @@ def test_split_k_prefill_gemm_equals_the_one_pass_form(cfg, m, n, k, residual):
                     np.testing.assert_allclose(c.float().cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-3, atol=4e-3 if residual else 2e-3)
             outs.append(c.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_split_k_gemm_alternating_tile_counts_on_one_workspace():
+    """Regression (r06): the split-K pair flags once sat BEHIND the slabs, so their place moved with the tile count - a launch with
+    fewer tiles than an earlier one on the same stream found its flags inside old slab data, skipped the wait, and added a partner's
+    sums that were not there yet (seen as a wrong FIRST prefill of a session behind other tests).  Large and small problems alternate
+    on one stream, every output exact."""
+    lib = capi.load_library()
+
+    class GemmParams(ctypes.Structure):
+        _fields_ = [('wtype', ctypes.c_int32), ('out_dtype', ctypes.c_int32), ('M', ctypes.c_int32), ('N', ctypes.c_int32),
+                    ('K', ctypes.c_int32), ('a', ctypes.c_void_p), ('lda', ctypes.c_int64), ('w', ctypes.c_void_p),
+                    ('ldw', ctypes.c_int64), ('scale_col', ctypes.c_void_p), ('scale_row', ctypes.c_void_p),
+                    ('per_channel', ctypes.c_int32), ('per_token', ctypes.c_int32), ('c', ctypes.c_void_p), ('ldc', ctypes.c_int64)]
+
+    lib.tllm_gemm.argtypes = [ctypes.POINTER(GemmParams), ctypes.c_void_p]
+    lib.tllm_gemm.restype = ctypes.c_int32
+    lib.tllm_gemm_set_tile_cfg.argtypes = [ctypes.c_int32]
+    lib.tllm_gemm_set_tile_cfg.restype = None
+    dev = torch.device('cuda', 0)
+    st = torch.cuda.Stream(device=dev)
+    probs = []
+    for m, n, k in ((1024, 4096, 2048), (200, 4096, 11008), (300, 1000, 512), (1024, 4096, 4096), (64, 4096, 1024)):
+        torch.manual_seed(m * 7 + k)
+        a = torch.randint(-128, 128, (m, k), dtype=torch.int8, device=dev)
+        w = torch.randint(-128, 128, (n, k), dtype=torch.int8, device=dev)
+        sc = torch.randint(1, 13, (n, ), device=dev).float() * 1e-4
+        sr = torch.randint(1, 13, (m, ), device=dev).float() * 1e-3
+        acc = torch.zeros((m, n), dtype=torch.float64, device=dev)
+        for k0 in range(0, k, 2048):
+            acc += a[:, k0:k0 + 2048].double() @ w[:, k0:k0 + 2048].double().t()
+        ref = (acc.float() * (sc[None, :] * sr[:, None])).half()
+        c = torch.empty((m, n), dtype=torch.float16, device=dev)
+        probs.append((GemmParams(3, 1, m, n, k, a.data_ptr(), k, w.data_ptr(), k, sc.data_ptr(), sr.data_ptr(), 1, 1, c.data_ptr(), n),
+                      c, ref, (a, w, sc, sr)))
+    torch.cuda.synchronize()
+    lib.tllm_gemm_set_tile_cfg(64)
+    try:
+        with torch.cuda.stream(st):
+            for rnd in range(6):
+                for q, c, ref, _ in probs:
+                    c.fill_(3.0)
+                    assert lib.tllm_gemm(ctypes.byref(q), st.cuda_stream) == 0, capi.last_error()
+                    st.synchronize()
+                    assert torch.equal(c, ref), (rnd, q.M, q.N, q.K, int((c != ref).sum()))
+    finally:
+        lib.tllm_gemm_set_tile_cfg(0)

@@ -677,3 +677,43 @@ def test_awkward_dimensions_vs_oracle(mode, int8_kv):
     for g, rr in ((got[0], ref_logits[0]), (got[1], ref_logits[1]), (got[2], ref_logits[3])):
         assert np.isfinite(g).all()
         np.testing.assert_allclose(g, rr, atol=(6e-2 if sq else 1e-2) * scale)
+
+
+def test_a_tensor_parallel_rank_without_its_collectives_runs_alone():
+    """Session key no_comm = 1 (bench.py's `tp_rank_prediction`): one rank of a tensor-parallel group - sharded heads, FFN columns and
+    vocabulary - runs its launches WITHOUT a communicator, every collective skipped.  Timing only (the hidden states are one rank's
+    partial sums), so what is checked is that it finalises, steps eagerly and from the graph, stays finite, and that the SAME shard with
+    collectives required refuses to finalise without a communicator."""
+    cfg, w = synth_model(5, L=2, H=4, D=256, I=512, V=512)
+    tp = 2
+    H, D, I, V = cfg['num_heads'], cfg['hidden_size'], cfg['inter_size'], cfg['vocab_size']
+    Dh = D // H
+
+    def shard(no_comm):
+        s = NativeSession(dict(cfg, quant_mode=0, tp_size=tp, tp_rank=0, no_comm=no_comm))
+        for k, v in w.items():
+            if k.endswith('attention.qkv.weight'):
+                v = v.reshape(3, H, Dh, D)[:, :H // tp].reshape(3 * D // tp, D)
+            elif k.endswith('attention.dense.weight'):
+                v = v[:, :D // tp]
+            elif k.endswith('mlp.fc.weight') or k.endswith('mlp.gate.weight'):
+                v = v[:I // tp]
+            elif k.endswith('mlp.proj.weight'):
+                v = v[:, :I // tp]
+            elif k == 'lm_head.weight':
+                v = v[:V // tp]
+            s.set_tensor(k, np.ascontiguousarray(v))
+        return s
+
+    s = shard(1)
+    s.finalize()
+    s.setup(1, 16, 8)
+    s.fake_context(16, seed=3)
+    s.step(2, use_graph=False)
+    s.step(4, use_graph=True)
+    assert np.isfinite(s.output_ids()).all()
+    s.close()
+    s2 = shard(0)
+    with pytest.raises(RuntimeError, match='communicator'):
+        s2.finalize()
+    s2.close()

@@ -42,6 +42,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) unsigned gu32;
+constexpr int kKsplitFlagBytes = 8192; // split-K: two flag words per tile at the head of the workspace (<= 1024 tiles)
 
 // one LDS-DMA instruction: 64 lanes x 16 bytes, global (wave-uniform base + per-lane 32-bit offset) -> LDS [m0 + lane * 16]
 __device__ __forceinline__ void glds16s(const char* base, uint32_t off, uint32_t lds_byte)
@@ -631,10 +632,12 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
         // the reader re-arms its own).  Stores and loads bypass the caches that are not shared (sc1: write-through / L2-served), the
         // flag is stored behind a drained vmcnt - guide G16 R1; no fence, no cache invalidation.
         constexpr int VSTRIDE = NW * 64 * 16, SLAB = 2 * MTH * NTH * VSTRIDE;
+        // (the flags sit at a FIXED place, the head of the workspace: behind the slabs their position moved with the tile count, and a
+        //  launch with fewer tiles than an earlier one found its flags inside old slab data - wrong sums on the first launch of a shape)
         char* ws = reinterpret_cast<char*>(p.ksplit_ws);
-        char* out_slab = ws + ((size_t) wg * 2 + (1 - khalf)) * SLAB + tid * 16;
-        const char* in_slab = ws + ((size_t) wg * 2 + khalf) * SLAB + tid * 16;
-        gu32* flags = (gu32*) (ws + (size_t) total_tiles * 2 * SLAB);
+        gu32* flags = (gu32*) ws;
+        char* out_slab = ws + kKsplitFlagBytes + ((size_t) wg * 2 + (1 - khalf)) * SLAB + tid * 16;
+        const char* in_slab = ws + kKsplitFlagBytes + ((size_t) wg * 2 + khalf) * SLAB + tid * 16;
         auto exchange = [&](auto hc) {
             constexpr int HK = decltype(hc)::value; // the X-half this workgroup keeps and finishes
 #pragma unroll
@@ -942,8 +945,11 @@ void* ksplit_workspace(hipStream_t stream, size_t bytes)
     if (e.second < bytes)
     {
         // (a hipMalloc: not inside a stream capture - the first use of a shape comes from the tactic profile or an eager prefill)
+        // the flags must read zero when the first kernel on this workspace starts: cleared ON THAT STREAM (a hipMemset on the NULL
+        // stream is not ordered against a non-blocking stream - a recycled allocation then shows the pair garbage flags: found by
+        // tests that ran clean alone and failed behind other tests of the same process)
         void* d = nullptr;
-        if (hipMalloc(&d, bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess)
+        if (hipMalloc(&d, bytes) != hipSuccess || hipMemsetAsync(d, 0, bytes, stream) != hipSuccess)
             return nullptr;
         if (e.first)
             (void) hipFree(e.first);
@@ -997,7 +1003,9 @@ int launch_sqp(const GemmParams& pin, hipStream_t stream)
             return 1;
         grid = 2 * tiles;
         constexpr size_t SLAB = (size_t) 2 * MTH * NTH * WR * WC * 64 * 16;
-        p.ksplit_ws = ksplit_workspace(stream, (size_t) tiles * 2 * SLAB + (size_t) tiles * 2 * 4);
+        if (tiles * 2 * 4 > kKsplitFlagBytes)
+            return 1;
+        p.ksplit_ws = ksplit_workspace(stream, (size_t) kKsplitFlagBytes + (size_t) tiles * 2 * SLAB);
         if (!p.ksplit_ws)
         {
             set_error("gemm_sqp: no split-K workspace");
