@@ -225,6 +225,7 @@ struct tllm_session
     // travels as its int8 image); session key fuse_o_projection = 0 keeps the GEMV launch
     int fuse_o_cfg = -1;
     int fused_retries = 0;          // requests tllm_session_generate ran a second time behind an expired in-launch wait
+    int dual_mlp_cfg = -1;          // session key dual_mlp_gemm = 0: prefill fc / gate as two GEMMs + the SwiGLU-quantiser pass (A/B)
     int fused_max_spins = -1;       // session key fused_max_spins: bound of the in-launch waits (tests: 0 = the first miss times out)
     bool o_fused = false;
     uint64_t* fused_xchg = nullptr; // granule exchange, shared by all layers
@@ -696,8 +697,7 @@ struct tllm_session
             RUN(launch_rmsnorm(r, st));
             const void* p_in = inter_buf;
             bool mlp_fused = false;
-    int fused_retries = 0;          // requests tllm_session_generate ran a second time behind an expired in-launch wait
-            if (sq && !per_token && M >= 32)
+            if (sq && !per_token && M >= 32 && dual_mlp_cfg != 0)
             {
                 // fc and gate in one kernel with SwiGLU + the static quantiser in its epilogue (gemm_sqp.hip, DUAL): the two fp16
                 // [M, Ir] intermediates and the pointwise pass between the GEMMs disappear.  The int8 result goes to inter_buf
@@ -1170,6 +1170,7 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->fuse_qkv_cfg = geti("fuse_qkv_attention", -1);
     s->fuse_o_cfg = geti("fuse_o_projection", -1);
     s->fused_max_spins = geti("fused_max_spins", -1);
+    s->dual_mlp_cfg = geti("dual_mlp_gemm", -1);
     s->fused_timeline = geti("fused_timeline", 0) != 0;
     if (kv.count("gemm_tactics") && !kv["gemm_tactics"].empty())
     {
