@@ -229,8 +229,8 @@ void tllm_gemv_set_mfma_rows(int32_t n);
 /* Test/bench knob: kernel id of the prefill GEMM (0 = tactic table, else the static rule).  1..12: lock-step tile shapes of
  * kernels/gemm_glds.hip (8 = 128x128, 6 = 256x192, 2 = 256x256, 4 = 128x256 are the production ones); 15..63: the phased
  * SmoothQuant pipeline of kernels/gemm_sqp.hip (20 = 256x192, 42 = 256x128, one tile per workgroup; 63 / 62 their persistent
- * forms, r05; 64 = 256x128 as two workgroups per tile splitting K, r06; 21..33 are ablations with wrong results on purpose);
- * 50..57: the same pipeline on fp16 operands (50 = 256x192, 54 = 256x128, 55 / 56 persistent, 57 split-K); 101..106: the weight-only kernel of kernels/gemm_woq.hip (101 = 256x192, 102 = 128x128,
+ * forms, r05; 64 / 65 = 256x128 / 128x128 as two workgroups per tile splitting K, r06; 21..33 are ablations with wrong results on purpose);
+ * 50..58: the same pipeline on fp16 operands (50 = 256x192, 54 = 256x128, 55 / 56 persistent, 57 / 58 split-K); 101..106: the weight-only kernel of kernels/gemm_woq.hip (101 = 256x192, 102 = 128x128,
  * 106 = 256x128); -2: the fused SwiGLU GEMM in its one-tile form.  The ids are what tllm_gemm_profile reports. */
 void tllm_gemm_set_tile_cfg(int32_t cfg);
 

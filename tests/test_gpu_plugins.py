@@ -882,8 +882,13 @@ def test_persistent_prefill_gemm_several_tiles_per_workgroup(cfg, m, n, k, resid
     (64, 1024, 4096, 11008, True),   # the down-projection: 86 K-tiles, 43 per half
     (64, 1000, 4000, 1664, False),   # ragged rows and columns, 13 K-tiles (7 + 6)
     (64, 300, 1000, 512, False),     # 2 x 8 tiles: a few pairs only
+    (65, 1024, 4096, 4096, True),    # 128 x 128 tiles: 512 workgroups, two per CU
+    (65, 1000, 4000, 1664, False),
+    (65, 512, 4096, 11008, True),    # the down-projection of a 512-token prefill
     (57, 1024, 4096, 4096, True),    # fp16 operands
-    (57, 1000, 4000, 832, False)])   # fp16, ragged, 13 K-tiles
+    (57, 1000, 4000, 832, False),    # fp16, ragged, 13 K-tiles
+    (58, 512, 4096, 4096, True),     # fp16, 128 x 128 tiles
+    (58, 1000, 4000, 832, False)])
 def test_split_k_prefill_gemm_equals_the_one_pass_form(cfg, m, n, k, residual):
     """gemm_sqp.hip KSPLIT (ids 64 / 57): two workgroups per 256 x 128 tile, each half of the K-tiles, the accumulators of the other
     X-half handed to the partner through write-through slabs + a drained flag (guide G16 R1).  SmoothQuant: int32 partial sums are
@@ -906,7 +911,7 @@ def test_split_k_prefill_gemm_equals_the_one_pass_form(cfg, m, n, k, residual):
     lib.tllm_gemm_set_tile_cfg.restype = None
     dev = torch.device('cuda', 0)
     torch.manual_seed(cfg + m + k)
-    sq = cfg == 64
+    sq = cfg in (64, 65)
     res = (torch.randn((m, n), device=dev) * 3).half() if residual else None
     if sq:
         a = torch.randint(-128, 128, (m, k), dtype=torch.int8, device=dev)
@@ -950,7 +955,8 @@ def test_split_k_prefill_gemm_equals_the_one_pass_form(cfg, m, n, k, residual):
     assert torch.equal(outs[0], outs[1])
 
 
-def test_split_k_gemm_alternating_tile_counts_on_one_workspace():
+@pytest.mark.parametrize('cfg', [64, 65])
+def test_split_k_gemm_alternating_tile_counts_on_one_workspace(cfg):
     """Regression (r06): the split-K pair flags once sat BEHIND the slabs, so their place moved with the tile count - a launch with
     fewer tiles than an earlier one on the same stream found its flags inside old slab data, skipped the wait, and added a partner's
     sums that were not there yet (seen as a wrong FIRST prefill of a session behind other tests).  Large and small problems alternate
@@ -984,7 +990,7 @@ def test_split_k_gemm_alternating_tile_counts_on_one_workspace():
         probs.append((GemmParams(3, 1, m, n, k, a.data_ptr(), k, w.data_ptr(), k, sc.data_ptr(), sr.data_ptr(), 1, 1, c.data_ptr(), n),
                       c, ref, (a, w, sc, sr)))
     torch.cuda.synchronize()
-    lib.tllm_gemm_set_tile_cfg(64)
+    lib.tllm_gemm_set_tile_cfg(cfg)
     try:
         with torch.cuda.stream(st):
             for rnd in range(6):

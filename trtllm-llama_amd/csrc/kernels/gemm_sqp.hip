@@ -87,8 +87,9 @@ __device__ __forceinline__ int swz_g(int row)
 // the pair sits on one XCD (workgroup ids are remapped to XCD-contiguous), both must be resident: grid <= CUs, checked by the launcher.
 template <int WR, int WC, int MTH, int NTH, int DMA_POS0, int DMA_POS1, bool PRIO, int ABL, int RSP, bool DUAL = false, bool SCL = true,
     bool F16 = false, bool PERSIST = false, bool KSPLIT = false>
-__global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams p)
+__global__ __launch_bounds__(64 * WR * WC, (KSPLIT && MTH == 1) ? 4 : 1) void gemm_sqp_kernel(const GemmParams p)
 {
+    // (split-K of the 128 x 128 tile: TWO workgroups per CU - four waves per SIMD - so that 512 workgroups are resident at once)
     static_assert(!KSPLIT || (!PERSIST && !DUAL), "split-K: the one-tile form, single GEMM");
     static_assert(SCL || !DUAL, "the fused SwiGLU epilogue reads its scales from LDS");
     static_assert(!PERSIST || SCL || F16, "the persistent form: SmoothQuant with staged scales (fp16 out, or the fused SwiGLU int8 out), or fp16 operands");
@@ -668,23 +669,24 @@ __global__ __launch_bounds__(64 * WR * WC) void gemm_sqp_kernel(const GemmParams
                 __hip_atomic_store(flags + wg * 2 + khalf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
+            // the partner's sums of this X-half: agent-scope 8-byte loads (sc1: past this CU's L1, whatever the producer's XCD) that
+            // hipcc counts itself - any tile shape, no hand-placed wait
             acc_t in[2][MTH][NTH];
+            typedef __attribute__((address_space(1))) unsigned long long gu64;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int m = 0; m < MTH; ++m)
 #pragma unroll
                     for (int n = 0; n < NTH; ++n)
-                        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(in[j][m][n]) : "v"(in_slab + ((j * MTH + m) * NTH + n) * VSTRIDE) : "memory");
-            // (the loads are invisible to hipcc's vmcnt bookkeeping: wait here, naming every destination - guide section 5.7 form (ii))
-            if constexpr (MTH == 2 && NTH == 2)
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(in[0][0][0]), "+v"(in[0][0][1]), "+v"(in[0][1][0]), "+v"(in[0][1][1]), "+v"(in[1][0][0]), "+v"(in[1][0][1]),
-                             "+v"(in[1][1][0]), "+v"(in[1][1][1])
-                             :
-                             : "memory");
-            else
-                static_assert(MTH == 2 && NTH == 2, "split-K is instantiated for the 256 x 128 tile");
+                    {
+                        const gu64* src = (const gu64*) (in_slab + ((j * MTH + m) * NTH + n) * VSTRIDE);
+                        const unsigned long long lo = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned long long hi = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 raw = {(unsigned) lo, (unsigned) (lo >> 32), (unsigned) hi, (unsigned) (hi >> 32)};
+                        in[j][m][n] = __builtin_bit_cast(acc_t, raw);
+                    }
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -995,11 +997,20 @@ int launch_sqp(const GemmParams& pin, hipStream_t stream)
     }
     if constexpr (KSPLIT)
     {
-        // two workgroups per tile, one per CU (the tile's LDS leaves no room for a second), both resident: 2 x tiles <= CUs
+        // two workgroups per tile, both resident
         int dev = 0, cus = 0;
         (void) hipGetDevice(&dev);
         (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (2 * tiles > cus || p.K * (F16 ? 2 : 1) / 128 < 4)
+        // (both workgroups of every pair must be resident: the occupancy query of THIS instance - registers and LDS - x the CUs)
+        static std::atomic<int> per_cu{-1};
+        if (per_cu < 0)
+        {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kfn), 64 * WR * WC, smem) != hipSuccess)
+                nb = 0;
+            per_cu = nb;
+        }
+        if (2 * tiles > cus * per_cu || p.K * (F16 ? 2 : 1) / 128 < 4)
             return 1;
         grid = 2 * tiles;
         constexpr size_t SLAB = (size_t) 2 * MTH * NTH * WR * WC * 64 * 16;
@@ -1070,6 +1081,13 @@ int launch_gemm_sqp(const GemmParams& pin, int cfg, hipStream_t stream)
             || (reinterpret_cast<uintptr_t>(p.residual) & 15))
             return 1;
         return launch_sqp<4, 2, 2, 2, 0, 4, false, 16, 0, false, true, false, false, true>(p, stream);
+    case 65: // split-K-2 of the 128 x 128 tile on 8 waves, two workgroups per CU (N = 4096 at M <= 512: 19 / 36 us for the O / down
+             // shapes against 21 / 43 of id 64 and 37 / 89 of the one-pass forms, profiles/r06_sqgemm_wave_tiles.txt)
+        if (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.residual) & 15))
+            return 1;
+        return launch_sqp<4, 2, 1, 2, 1, 3, true, 0, 0, false, true, false, false, true>(p, stream);
+    // (split-K of the 256 x 192 tile: 256 VGPRs with a spill, and slower than id 64 on every shape at M = 256 / 512 - not kept)
     case 63: // the same with the DMA slots of id 13 (after MFMA 2 / 8 of a phase): the production form
         if (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
             || (reinterpret_cast<uintptr_t>(p.residual) & 15) || p.K < 256)
@@ -1132,6 +1150,11 @@ int launch_gemm_f16p(const GemmParams& pin, int cfg, hipStream_t stream)
             || (reinterpret_cast<uintptr_t>(p.residual) & 15) || (reinterpret_cast<uintptr_t>(p.silu_gate) & 15))
             return 1;
         return launch_sqp<4, 2, 2, 2, 0, 4, false, 16, 0, false, false, true, false, true>(p, stream);
+    case 58: // split-K-2 of the 128 x 128 tile, two workgroups per CU (the fp16 twin of id 65)
+        if (p.out_dtype != DT_HALF || (p.ldc & 7) || (p.N & 7) || (reinterpret_cast<uintptr_t>(p.c) & 15)
+            || (reinterpret_cast<uintptr_t>(p.residual) & 15) || (reinterpret_cast<uintptr_t>(p.silu_gate) & 15))
+            return 1;
+        return launch_sqp<4, 2, 1, 2, 1, 3, true, 0, 0, false, false, true, false, true>(p, stream);
     default: return 1;
     }
 }

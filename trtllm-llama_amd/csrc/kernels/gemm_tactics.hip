@@ -40,8 +40,8 @@ std::mutex g_mu;
 std::map<Key, Entry> g_table;
 
 // candidates (the static rule's pick for the problem is the incumbent: see gemm_profile)
-const int kSqCandidates[] = {63, 20, 8, 62, 64, 42, 6, 15, 18, 1, 3, 2, 4}; // 64: split-K-2 of the 256 x 128 tile (r06)
-const int kFp16Candidates[] = {55, 6, 8, 50, 56, 57, 54, 51, 52, 53, 1, 3, 2, 4, 5, 7}; // 50..: the phased pipeline on fp16 operands (gemm_sqp.hip)
+const int kSqCandidates[] = {63, 20, 8, 62, 64, 65, 42, 6, 15, 18, 1, 3, 2, 4}; // 64 / 65: split-K-2 of the 256 x 128 / 128 x 128 tile (r06)
+const int kFp16Candidates[] = {55, 6, 8, 50, 56, 57, 58, 54, 51, 52, 53, 1, 3, 2, 4, 5, 7}; // 50..: the phased pipeline on fp16 operands (gemm_sqp.hip)
 
 __global__ void fill_random_kernel(uint32_t* p, size_t n_words, uint32_t seed, int fp16)
 {
