@@ -45,6 +45,7 @@ def parse():
                     help='A/B: QKV projection and attention as two launches (session key fuse_qkv_attention = 0)')
     ap.add_argument('--gemv-o-projection', action='store_true',
                     help='A/B: the O-projection as a GEMV launch of its own (session key fuse_o_projection = 0)')
+    ap.add_argument('--session-key', action='append', default=[], metavar='KEY=INT', help='debug: extra session key(s) for A/B runs')
     ap.add_argument('--no-prefill', dest='prefill', action='store_false', help='skip the prefill (TTFT) and SQ-GEMM MFMA reports')
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
     ap.add_argument('--no-batch-sweep', dest='batch_sweep', action='store_false',
@@ -194,7 +195,8 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     int8_kv = mode != 'fp16'  # BASELINE.json configs: fp16 + fp16 KV; every int8 config with int8 KV
     qm = QM[mode] | (INT8_KV if int8_kv else 0)
     sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=world, tp_rank=rank, fuse_qkv_attention=0 if args.two_launch_attention else -1,
-                              fuse_o_projection=0 if getattr(args, 'gemv_o_projection', False) else -1))
+                              fuse_o_projection=0 if getattr(args, 'gemv_o_projection', False) else -1,
+                              **{k: int(v) for k, v in (kv.split('=') for kv in getattr(args, 'session_key', []))}))
     weights = synth_weights(torch, cfg, mode, int8_kv, world, rank, dev)
     for k, v in weights.items():
         sess.set_tensor(k, v)

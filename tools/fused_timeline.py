@@ -1,5 +1,5 @@
 """Stage clock of the fused QKV + attention launch (GPU box): where the 256 workgroups are at which microsecond.
-   python tools/fused_timeline.py [context]"""
+   python tools/fused_timeline.py [context [session_key=value ...]]"""
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,8 @@ from tensorrt_llm.runtime.native import NativeSession, _lib
 cfg = dict(bench.LLAMA_7B)
 dev = torch.device('cuda', 0)
 w = bench.synth_weights(torch, cfg, 'sq', True, 1, 0, dev)
-s = NativeSession(dict(cfg, quant_mode=bench.QM['sq'] | bench.INT8_KV, tp_size=1, tp_rank=0, fused_timeline=1))
+keys = {a.split('=')[0]: int(a.split('=')[1]) for a in sys.argv[2:]}  # session keys: python tools/fused_timeline.py 1024 key=value ...
+s = NativeSession(dict(cfg, quant_mode=bench.QM['sq'] | bench.INT8_KV, tp_size=1, tp_rank=0, fused_timeline=1, **keys))
 for k, v in w.items():
     s.set_tensor(k, v)
 s.finalize()

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
-
-( timeout 1200 python tools/prefill_lens.py 2>&1 | grep -v amdgpu.ids ) > gpurun_out/r06_prefill_lens.txt
-tail -5 gpurun_out/r06_t4.log | cut -c1-170; cat gpurun_out/r06_prefill_lens.txt
+( timeout 300 python tools/fused_timeline.py 1024 2>&1 | grep -v amdgpu.ids | tail -22; echo "=== early"; timeout 300 python tools/fused_timeline.py 1024 fused_early_attention=1 2>&1 | grep -v amdgpu.ids | tail -22 ) > gpurun_out/r06_early_tl.txt 2>&1
+bash tools/r06_ab.sh "" "--session-key fused_early_attention=1" 2 > /dev/null 2>&1
+cat gpurun_out/r06_early_tl.txt gpurun_out/r06_ab.txt
