@@ -13,6 +13,7 @@
 // exp underflows to the same 0).
 #include "dev_utils.h"
 #include "kernels.h"
+#include "launch_util.h"
 #include <atomic>
 #include <cstdlib>
 
@@ -739,7 +740,6 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
             const int spad = (p.seq + 63) / 64 * 64;
             // RoPE + KV write (+ int8 quantisation) + the V^T image in one launch
             hipLaunchKernelGGL((rope_kv_vt_kernel<DH>), dim3(spad / 64, p.num_heads, p.batch), dim3(256), 0, stream, p, spad);
-            static std::atomic<bool> attr_done{false};
             {
                 // 64-query workgroups while 128-query ones would not fill the chip
                 bool narrow = (int64_t) ((p.seq + 127) / 128) * p.num_heads * p.batch < 256;
@@ -749,16 +749,7 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
                 // 256, where the unpaired choice is the 64-query kernel, 28.0 -> 24.1, 24.5 -> 21.0, 18.5 -> 16.4, 15.8 -> 14.3,
                 // 12.5 -> 12.0): with more workgroups than CUs the dispatcher already back-fills the CUs of the short blocks and
                 // pairing only makes every workgroup long (S = 1536: 44 -> 58 us, S = 2048: 61.6 -> 72.4).
-                static std::atomic<int> cus_cache{0};
-                int cus = cus_cache.load();
-                if (!cus)
-                {
-                    int dev = 0;
-                    (void) hipGetDevice(&dev);
-                    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-                        cus = 256;
-                    cus_cache.store(cus);
-                }
+                const int cus = launch_util::device_cus();
                 const int64_t wg128 = (int64_t) ((p.seq + 127) / 128) * p.num_heads * p.batch;
                 const bool pair = wg128 <= cus && 4 * wg128 >= cus;
                 if (pair)
@@ -774,19 +765,8 @@ int launch_dh(const ContextAttnParams& p, hipStream_t stream)
                 const size_t smem = stg > (narrow ? 2 : 4) * slab ? stg : 4 * slab;
                 auto kfn = narrow ? context_attn_mfma_ks_kernel<DH, 2>
                                   : (pair ? context_attn_mfma_ks_kernel<DH, 4, true, 3> : context_attn_mfma_ks_kernel<DH, 4>);
-                if (!attr_done)
-                {
-                    if (stages > 64 * 1024 || 4 * slab > 64 * 1024)
-                    {
-                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(context_attn_mfma_ks_kernel<DH, 4, true, 3>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                    }
-                    attr_done = true;
-                }
+                if (stages > 64 * 1024 || 4 * slab > 64 * 1024)
+                    launch_util::ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), 96 * 1024);
                 const int qbw = narrow ? 64 : 128;
                 // paired: ceil(nblk64 / 2) workgroups per head - the same count as 128-query blocks
                 hipLaunchKernelGGL(kfn, dim3(p.num_heads, (p.seq + qbw - 1) / qbw, p.batch), dim3(narrow ? 256 : 512), smem, stream, p, spad);

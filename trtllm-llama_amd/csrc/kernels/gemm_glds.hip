@@ -19,6 +19,7 @@
 // (float(acc) * (s_col * s_row)), transposed through LDS so that every lane stores 16 contiguous bytes of a C row.
 #include "dev_utils.h"
 #include "kernels.h"
+#include "launch_util.h"
 #include <atomic>
 #include <map>
 
@@ -483,13 +484,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream)
     static_assert(smem <= 160 * 1024, "LDS budget");
     static_assert(smem >= (size_t) WM * WN * KG * 32 * (NT * 64 + 16), "epilogue scratch must fit the operand stages");
     auto kfn = gemm_glds_kernel<WT, WM, WN, MT, NT, KG, BKB, S, LW>;
-    static std::atomic<bool> attr_done{false}; // idempotent; atomic so concurrent first launches do not race
-    if (!attr_done)
-    {
-        if (smem > 64 * 1024)
-            (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
-        attr_done = true;
-    }
+    launch_util::ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), smem);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kfn, dim3(tiles), dim3(64 * (WM * WN * KG + LW)), smem, stream, p);
     hipError_t e = hipGetLastError();
@@ -572,16 +567,7 @@ static bool glds_serves(const GemmParams& p)
 // out the tile that exists in gemm_sqp.hip only (its launcher refused the problem: alignment, 32-bit DMA offsets).
 static int static_shape_cfg(const GemmParams& p, bool phased_ok = true)
 {
-    static std::atomic<int> cus_cache{0};
-    int cus = cus_cache.load();
-    if (!cus)
-    {
-        int dev = 0;
-        (void) hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        cus_cache.store(cus);
-    }
+    const int cus = launch_util::device_cus();
     double best = 1e30;
     int cfg = 8;
     for (const Shape& s : kShapes)

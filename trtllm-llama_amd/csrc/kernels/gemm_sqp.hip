@@ -23,6 +23,7 @@
 // so the same involution is applied to each lane's global SOURCE piece.
 #include "dev_utils.h"
 #include "kernels.h"
+#include "launch_util.h"
 #include <atomic>
 #include <cstdlib>
 #include <map>
@@ -971,45 +972,23 @@ int launch_sqp(const GemmParams& pin, hipStream_t stream)
         + (PERSIST ? (DUAL ? BM * (BN / 2 + 16) : WR * 16 * (BN * 2 + 16)) : 0);
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kfn = gemm_sqp_kernel<WR, WC, MTH, NTH, DP0, DP1, PRIO, ABL, RSP, DUAL, SCL, F16, PERSIST, KSPLIT>;
-    static std::atomic<bool> attr_done{false};
-    if (!attr_done)
-    {
-        if (smem > 64 * 1024)
-            (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
-        attr_done = true;
-    }
+    launch_util::ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), smem);
     constexpr int BNO = DUAL ? BN / 2 : BN; // output columns per tile
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BNO - 1) / BNO);
     int grid = tiles;
     if (PERSIST)
     {
         // every workgroup the same number of tiles (+-1): ceil(tiles / rounds) workgroups, rounds = ceil(tiles / CUs)
-        static int cus = 0;
-        if (!cus)
-        {
-            int dev = 0, n = 0;
-            (void) hipGetDevice(&dev);
-            (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-            cus = n > 0 ? n : 256;
-        }
+        const int cus = launch_util::device_cus();
         const int rounds = (tiles + cus - 1) / cus;
         grid = (tiles + rounds - 1) / rounds;
     }
     if constexpr (KSPLIT)
     {
         // two workgroups per tile, both resident
-        int dev = 0, cus = 0;
-        (void) hipGetDevice(&dev);
-        (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         // (both workgroups of every pair must be resident: the occupancy query of THIS instance - registers and LDS - x the CUs)
-        static std::atomic<int> per_cu{-1};
-        if (per_cu < 0)
-        {
-            int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kfn), 64 * WR * WC, smem) != hipSuccess)
-                nb = 0;
-            per_cu = nb;
-        }
+        const int cus = launch_util::device_cus();
+        const int per_cu = launch_util::blocks_per_cu(reinterpret_cast<const void*>(kfn), 64 * WR * WC, smem);
         if (2 * tiles > cus * per_cu || p.K * (F16 ? 2 : 1) / 128 < 4)
             return 1;
         grid = 2 * tiles;

@@ -27,6 +27,7 @@
 // the k-steps of the one being computed.
 #include "dev_utils.h"
 #include "kernels.h"
+#include "launch_util.h"
 #include <atomic>
 
 namespace tllm
@@ -325,13 +326,7 @@ int launch_woq_cfg(const GemmParams& p, hipStream_t stream)
     static_assert(smem <= 160 * 1024, "LDS budget");
     static_assert(smem >= (size_t) WM * WN * 32 * (NT * 64 + 16), "epilogue scratch must fit the operand stages");
     auto kfn = gemm_woq_kernel<BITS, WM, WN, MT, NT, S>;
-    static std::atomic<bool> attr_done{false};
-    if (!attr_done)
-    {
-        if (smem > 64 * 1024)
-            (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
-        attr_done = true;
-    }
+    launch_util::ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), smem);
     const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     hipLaunchKernelGGL(kfn, dim3(tiles), dim3(64 * WM * WN), smem, stream, p);
     hipError_t e = hipGetLastError();
@@ -382,16 +377,7 @@ int launch_gemm_woq(const GemmParams& p, hipStream_t stream)
     if (cfg <= 0)
     {
         // fewest workgroup rounds over the CUs (the rule of gemm_glds.hip): at M = 1024 256 x 192 for QKV / gate / up, 128 x 128 for O / down
-        static std::atomic<int> cus_cache{0};
-        int cus = cus_cache.load();
-        if (!cus)
-        {
-            int dev = 0;
-            (void) hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-                cus = 256;
-            cus_cache.store(cus);
-        }
+        const int cus = launch_util::device_cus();
         // cost = workgroup rounds x tile area x the measured cost of a tile of that kind per area, relative to 256 x 192
         // (profiles/r04_tile256x128.txt): 256 x 128 fills the chip in ONE round for O / down at M = 2048 where 128 x 128 takes two
         struct Cand

@@ -20,6 +20,7 @@
 #pragma once
 #include "dev_utils.h"
 #include "kernels.h"
+#include "launch_util.h"
 #include "weight_layout.h"
 #include "gemv_args.h"
 #include <algorithm>
@@ -681,38 +682,13 @@ int launch_inst(const GemvArgs& a, hipStream_t stream)
         set_error("gemv: K=%d x M=%d does not fit LDS", a.p.K, a.p.M);
         return -1;
     }
-    // per-instantiation launch state (LDS attribute, CU count, occupancy per LDS size): plugins may be enqueued from several
-    // host threads (one per rank is the rule, but nothing forbids more), so the lazily filled cache sits behind a mutex
-    static std::mutex launch_mu;
-    static bool attr_done = false;
-    static int cus = 0;
-    static std::map<size_t, int> occ_cache;
-    int fit_blocks = 2;
-    {
-        std::lock_guard<std::mutex> lock(launch_mu);
-        if (smem > 64 * 1024 && !attr_done)
-        {
-            (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_done = true;
-        }
-        // persistent grid: no more workgroups than the chip holds at once, every wave the same number of row groups
-        if (!cus)
-        {
-            int dev = 0;
-            (void) hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-                cus = 256;
-        }
-        auto it = occ_cache.find(smem);
-        if (it == occ_cache.end())
-        {
-            int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kfn, 256, smem) != hipSuccess || nb < 1)
-                nb = 2;
-            it = occ_cache.emplace(smem, nb > 8 ? 8 : nb).first;
-        }
-        fit_blocks = it->second;
-    }
+    // per-instantiation, per-DEVICE launch state (LDS attribute, CU count, occupancy per LDS size) behind launch_util's mutex:
+    // plugins may be enqueued from several host threads (one per rank is the rule, but nothing forbids more)
+    launch_util::ensure_dynamic_lds(reinterpret_cast<const void*>(kfn), smem > 64 * 1024 ? 160 * 1024 : 0);
+    // persistent grid: no more workgroups than the chip holds at once, every wave the same number of row groups
+    const int cus = launch_util::device_cus();
+    int fit_blocks = launch_util::blocks_per_cu(reinterpret_cast<const void*>(kfn), 256, smem);
+    fit_blocks = fit_blocks < 1 ? 2 : (fit_blocks > 8 ? 8 : fit_blocks);
     int blocks = (a.ngroups + 3) / 4;
     // persistent workgroups per CU: what fits (occupancy query) for the SwiGLU kernel (gate|up: 16.4 us with 4 per CU, 17.6 with
     // 2); two for the plain projections (QKV: 9.9 us with 2, 10.4 with 3 - 4: fewer, longer-lived waves amortise the RMSNorm

@@ -26,6 +26,7 @@
 #include "dev_utils.h"
 #include "gemv_args.h"
 #include "kernels.h"
+#include "launch_util.h"
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
@@ -439,16 +440,7 @@ int launch_gemv_mfma_sq(const GemvParams& p, hipStream_t stream)
     else if ((reinterpret_cast<uintptr_t>(p.x) & 15) || (p.ldx & 15))
         return 1;
     const int pitch = p.K + 16;
-    static std::atomic<int> cus_cache{0};
-    int cus = cus_cache.load();
-    if (!cus)
-    {
-        int dev = 0;
-        (void) hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        cus_cache.store(cus);
-    }
+    const int cus = launch_util::device_cus();
     if ((int64_t) 16 * p.ldw + 256 >= (1ll << 32))
         return 1; // 32-bit DMA offsets inside a row group
     const int ngroups = p.N / 16;

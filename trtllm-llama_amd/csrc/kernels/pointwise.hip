@@ -3,6 +3,7 @@
 // All HBM/latency-bound: 16-byte accesses, one workgroup per row, wave64 shuffles for reductions.
 #include "dev_utils.h"
 #include "kernels.h"
+#include "launch_util.h"
 #include <atomic>
 #include <cstdlib>
 
@@ -1087,12 +1088,7 @@ int launch_beam_step(const BeamParams& p, hipStream_t stream)
         set_error("beam step: beam %d x %d slots does not fit the staging buffer", p.beam, p.out_stride);
         return -1;
     }
-    static std::atomic<bool> attr_done{false};
-    if (!attr_done)
-    {
-        (void) hipFuncSetAttribute(reinterpret_cast<const void*>(beam_step_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_done = true;
-    }
+    launch_util::ensure_dynamic_lds(reinterpret_cast<const void*>(beam_step_kernel), 96 * 1024);
     hipLaunchKernelGGL(beam_step_kernel, dim3(p.batch), dim3(1024), smem, stream, p);
     return check_launch("beam_step");
 }
