@@ -45,6 +45,8 @@ def parse():
                     help='A/B: QKV projection and attention as two launches (session key fuse_qkv_attention = 0)')
     ap.add_argument('--gemv-o-projection', action='store_true',
                     help='A/B: the O-projection as a GEMV launch of its own (session key fuse_o_projection = 0)')
+    ap.add_argument('--one-launch-mlp', action='store_true',
+                    help='A/B: the gated MLP of a decode step as ONE launch (session key fuse_mlp=1; measured slower, off by default)')
     ap.add_argument('--session-key', action='append', default=[], metavar='KEY=INT', help='debug: extra session key(s) for A/B runs')
     ap.add_argument('--no-prefill', dest='prefill', action='store_false', help='skip the prefill (TTFT) and SQ-GEMM MFMA reports')
     ap.add_argument('--no-fp16-ref', action='store_true', help='skip the fp16 config run used for the int8/fp16 ratio')
@@ -162,11 +164,18 @@ def step_launches(cfg, mode, world, form, l_mean, int8_kv, smax):
     if not form & 2:
         out.append(dict(key='o_proj', id=4, kernel='gemv (O-projection + residual)', what='O-projection + residual', bytes=o, calls=L,
                         match=['gemv_ksplit_kernel', 'gemv_kernel<%d, 0, 0' % wt, 'gemv_kernel<%d, 2, 0' % wt]))
-    out.append(dict(key='gate_up', id=5, kernel='gemv_kernel<%d, 1, 1, 1, 2, 4>' % wt, what='RMSNorm -> gate|up GEMV -> SwiGLU',
-                    bytes=gate_up, calls=L, match=['gemv_kernel<%d, 1, 1' % wt]))
-    out.append(dict(key='down', id=6, kernel='gemv_ksplit_kernel<3, 3>' if mode == 'sq' else 'gemv (down projection + residual)',
-                    what='down projection + residual', bytes=down, calls=L,
-                    match=['gemv_ksplit_kernel', 'gemv_kernel<%d, 0, 0' % wt, 'gemv_kernel<%d, 2, 0' % wt]))
+    if form & 4:
+        # (one launch: the intermediate row is written once and read once per workgroup, 256 x Ir bytes of L2 / fabric traffic that
+        #  is not part of the algorithmic HBM bytes)
+        out.append(dict(key='mlp', id=8, kernel='mlp_fused_kernel<%d>' % ((Ir + 1023) // 1024),
+                        what='RMSNorm -> gate|up GEMV -> SwiGLU -> down projection + residual', bytes=gate_up + down - 2 * row, calls=L,
+                        match=['mlp_fused_kernel']))
+    else:
+        out.append(dict(key='gate_up', id=5, kernel='gemv_kernel<%d, 1, 1, 1, 2, 4>' % wt, what='RMSNorm -> gate|up GEMV -> SwiGLU',
+                        bytes=gate_up, calls=L, match=['gemv_kernel<%d, 1, 1' % wt]))
+        out.append(dict(key='down', id=6, kernel='gemv_ksplit_kernel<3, 3>' if mode == 'sq' else 'gemv (down projection + residual)',
+                        what='down projection + residual', bytes=down, calls=L,
+                        match=['gemv_ksplit_kernel', 'gemv_kernel<%d, 0, 0' % wt, 'gemv_kernel<%d, 2, 0' % wt]))
     out.append(dict(key='head', id=None, kernel='gemv_kernel<0, 1, 0, ...> (ln_f -> lm_head, fp32 logits)', what='final RMSNorm -> lm_head GEMV',
                     bytes=head, calls=1, match=['gemv_kernel<0, 1, 0']))
     return out
@@ -196,6 +205,7 @@ def run_config(torch, dist, args, mode, rank, world, dev):
     qm = QM[mode] | (INT8_KV if int8_kv else 0)
     sess = NativeSession(dict(cfg, quant_mode=qm, tp_size=world, tp_rank=rank, fuse_qkv_attention=0 if args.two_launch_attention else -1,
                               fuse_o_projection=0 if getattr(args, 'gemv_o_projection', False) else -1,
+                              fuse_mlp=1 if getattr(args, 'one_launch_mlp', False) else 0,
                               **{k: int(v) for k, v in (kv.split('=') for kv in getattr(args, 'session_key', []))}))
     weights = synth_weights(torch, cfg, mode, int8_kv, world, rank, dev)
     for k, v in weights.items():
@@ -783,7 +793,8 @@ def main():
                  # the launches one layer is made of in this run, timed one by one (the same numbers as roofline.kernels)
                  'layer_kernel_us': {k: v for k, v in res['kernel_us'].items() if k != 'head'},
                  'decode_form': {'qkv_and_attention_in_one_launch': bool(res['decode_form'] & 1),
-                                 'o_projection_in_that_launch': bool(res['decode_form'] & 2)},
+                                 'o_projection_in_that_launch': bool(res['decode_form'] & 2),
+                                 'mlp_in_one_launch': bool(res['decode_form'] & 4)},
                  # the layer as the graph replay runs it: (device time per step - the head GEMV - the sampler, both from the eager
                  # profile below) / layers.  layer_kernel_us above times the launches ONE BY ONE
                  'layer_us_in_graph_replay': (res['dev_ms'] / args.steps - (prof['gemv_head'][0] + prof['other'][0]) / prof_steps) * 1e3 / args.layers,

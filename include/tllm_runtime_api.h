@@ -124,6 +124,8 @@ void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer);
  * last fused QKV-projection + attention launch stamped at its stages (kernels/qkv_attn_fused.hip; tools/fused_timeline.py);
  * NULL when the session does not run that launch. */
 void* tllm_session_fused_timeline_ptr(tllm_session_t s);
+/* ... and of the last one-launch MLP ([256 workgroups][16]; kernels/mlp_fused.hip). */
+void* tllm_session_mlp_timeline_ptr(tllm_session_t s);
 /* The step-dependent tensors the reference's Python loop builds on the host every step (PY/runtime/generation.py:556-579,
  * :686-689, :735-750, :812-821) live in device memory here and are advanced by the sampler kernel; this copies them out so
  * that tests can pin them to the reference's values (any pointer may be NULL):
@@ -165,7 +167,8 @@ int64_t tllm_session_step_bytes(tllm_session_t s, int32_t context_len);
 /* Live per-kernel timing for bench.py's roofline: launches ONLY kernel K<which> of every layer (1 = RMSNorm+QKV GEMV - or, when
  * the session runs the one-launch projection + attention, that launch WITHOUT its later stages; 2 = decode attention,
  * 4 = O-projection GEMV, 5 = RMSNorm+gate|up GEMV+SwiGLU, 6 = down GEMV, 7 = the one-launch projection + attention exactly
- * as the generation step runs it, with every stage tllm_session_decode_form reports) back to back,
+ * as the generation step runs it, with every stage tllm_session_decode_form reports, 8 = the one-launch MLP - RMSNorm + gate|up +
+ * SwiGLU + down + residual, kernels/mlp_fused.hip - where the session runs it; 5 / 6 then time the two GEMVs it replaces) back to back,
  * `sweeps` passes over the layers (each layer has its own weights, so every launch streams cold HBM exactly as in a
  * real step), bracketed by one HIP event pair on the session's stream.  avg_us = elapsed / launches (inter-launch
  * gaps included).  Activations are whatever the buffers hold: timing only, call tllm_session_fake_context or
@@ -179,7 +182,8 @@ int32_t tllm_session_fused_retries(tllm_session_t s);
 
 /* Which launches a generation step of this session is made of (decided at setup; a time-out of the one-launch form clears it):
  * bit 0 = QKV projection + RoPE + cache append + attention in one launch (kernels/qkv_attn_fused.hip), bit 1 = the O-projection +
- * residual as a stage of that launch.  -1 before setup. */
+ * residual as a stage of that launch, bit 2 = the gated MLP (gate|up GEMV + down GEMV) in one launch (kernels/mlp_fused.hip, r06;
+ * opt-in with the session key fuse_mlp = 1: bit-identical, measured slower than the two GEMVs).  -1 before setup. */
 int32_t tllm_session_decode_form(tllm_session_t s);
 
 /* Instrumented generation steps (eager, a hipEvent pair around every launch) for the roofline report:

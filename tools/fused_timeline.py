@@ -48,3 +48,20 @@ for rnd in range(3):
     print(f'   partial hand-off (last member past barrier D -> member 0 has everything in LDS): median {np.median((t[:H, 11] - pd.max(0)) / 100.0):.2f} us')
 for k in ('o_proj', 'gate_up', 'down'):
     print(k, s.time_kernel(k, sweeps=8))
+if s.decode_form() & 4:
+    lib.tllm_session_mlp_timeline_ptr.argtypes = [ctypes.c_void_p]
+    lib.tllm_session_mlp_timeline_ptr.restype = ctypes.c_void_p
+    mnames = {0: 'first tiles requested', 1: 'operand quantised', 2: 'row pairs done (wave 0)', 7: 'down rows requested, all pairs done', 3: 'line published',
+              8: "leader: members' tags seen", 4: 'all 16 group lines seen', 5: 'intermediate row in LDS', 6: 'end'}
+    for rnd in range(2):
+        us, n = s.time_kernel('mlp', sweeps=4)
+        torch.cuda.synchronize()
+        t = np.zeros((256, 16), np.uint64)
+        assert hip.hipMemcpy(t.ctypes.data, lib.tllm_session_mlp_timeline_ptr(s._h), t.nbytes, 2) == 0
+        t = t.astype(np.int64)
+        t0 = t[:, 0].min()
+        print(f'--- one-launch MLP, round {rnd}: {us:.2f} us per launch; last launch, us since the first workgroup (min / median / max)')
+        for k in (0, 1, 2, 7, 3, 8, 4, 5, 6):
+            r = (t[:, k] - t0) / 100.0
+            print(f'   {mnames[k]:36s} {r.min():7.2f} {np.median(r):7.2f} {r.max():7.2f}')
+        print(f'   flag sweeps beyond the first: {np.bincount(t[:, 12].astype(np.int64)).tolist()}')

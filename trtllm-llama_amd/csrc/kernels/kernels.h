@@ -240,6 +240,45 @@ bool qkv_attn_fused_serves(int32_t K, int32_t num_heads, int32_t head_size, int3
     int32_t o_stage = 0);
 int launch_qkv_attn_fused(const FusedQkvAttnParams& p, hipStream_t stream);
 
+// ---------------------------------------------------------------------------------------------
+// Decode step, batch 1, SmoothQuant static: RMSNorm + gate|up + SwiGLU + quantiser + down-projection + residual in ONE launch
+// (kernels/mlp_fused.hip, r06): 256 workgroups, the intermediate row handed over inside the launch (write-through bytes, a flag
+// byte per workgroup polled through the scalar path), the down-projection's rows requested ahead of it.
+// ---------------------------------------------------------------------------------------------
+struct FusedMlpParams
+{
+    int32_t K = 0, I = 0, N = 0; // hidden size (gate|up K), intermediate size (gate|up rows, down K), down rows (= K for LLaMA)
+    const void* x = nullptr;     // fp16 [K]: the layer's residual stream behind the attention block (also the residual of the output)
+    void* x_out = nullptr;       // fp16 [N]: may be x itself (every workgroup has consumed x before any workgroup writes)
+    const void* gamma = nullptr; // fp16 [K]: post_layernorm
+    float eps = 1e-6f;
+    const float* act_quant = nullptr; // f32 [1]: static quantiser of the normalised row
+    const void* w_fc = nullptr;       // s8 [I, ldw]
+    const void* w_gate = nullptr;     // s8 [I, ldw]
+    int64_t ldw = 0;
+    const void* scale_fc = nullptr;   // f32 [I] (per_channel) or [1]
+    const void* scale_gate = nullptr;
+    int32_t per_channel = 0;
+    const float* row_fc = nullptr;    // f32 [1]: activation scale of the dequantisation (fc); row_gate null -> the same
+    const float* row_gate = nullptr;
+    const float* out_quant = nullptr; // f32 [1]: static quantiser of silu(fc) * gate
+    void* inter = nullptr;            // optional s8 [I]: the intermediate row as the two-launch form leaves it (taps)
+    const void* w_proj = nullptr;     // s8 [N, ldw_proj]
+    int64_t ldw_proj = 0;
+    const void* scale_proj = nullptr; // f32 [N] (per_channel_proj) or [1]
+    int32_t per_channel_proj = 0;
+    const float* row_proj = nullptr;  // f32 [1]
+    uint8_t* flags = nullptr;         // the exchange area (a 64-byte line per workgroup: its int8 outputs + the tag; a line per group
+                                      // of 16): mlp_fused_flag_bytes(), zero before the first launch
+    uint32_t* error = nullptr;        // device word: bit 16 after a bounded wait expired (a launch that finds it set returns at once)
+    int32_t max_spins = 50000;
+    void* x_pro_out = nullptr;  // optional s8 [K]: the quantised operand (tap)
+    uint64_t* timing = nullptr; // optional [256][16] stage clock
+};
+size_t mlp_fused_flag_bytes();
+bool mlp_fused_serves(int32_t K, int32_t I, int32_t N);
+int launch_mlp_fused(const FusedMlpParams& p, hipStream_t stream);
+
 // RoPE table builder (host -> device buffer owned by caller): cos/sin(pos / 10000^(2j/rot)) in fp32,
 // formula of K/decoderMaskedMultiheadAttentionUtils.h:1511-1515.
 void fill_rope_table_host(float* table, int32_t max_pos, int32_t rotary_dim);

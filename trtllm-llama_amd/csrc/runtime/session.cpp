@@ -232,6 +232,13 @@ struct tllm_session
     uint32_t* step_epoch = nullptr; // advanced by the sampler once per generation step (the granule tags derive from it)
     uint32_t* fused_err = nullptr;  // raised by a bounded wait that expired
     uint32_t timing_tag = 0;        // explicit tags of eager launches outside a step (tllm_session_time_kernel)
+    // r06: the gated MLP of a decode step (gate|up GEMV + down GEMV) in ONE launch (kernels/mlp_fused.hip): batch 1, tp 1, static
+    // SmoothQuant, the 7B extents.  Bit-identical to the two GEMV launches but measured 1 us per layer SLOWER (26.4 against
+    // 16.4 + 9.0 us, profiles/r06_mlp_one_launch.txt), so it runs only when asked for: session key fuse_mlp = 1
+    int fuse_mlp_cfg = 0;
+    bool mlp_fused_dec = false;  // decided at setup
+    uint8_t* mlp_flags = nullptr; // one byte per workgroup (shared by all layers), zero before the first launch and after a failed one
+    uint64_t* mlp_timing = nullptr;
     uint64_t* fused_timing = nullptr; // session key fused_timeline = 1: stage clock of the fused launch, [Hr * 8][16] ticks
     bool fused_timeline = false;
     void* ctx_q8 = nullptr;
@@ -1066,7 +1073,45 @@ struct tllm_session
             }
             // K5
             const bool q_inter = sq && !per_token;
-            if (ok < 0 || ok == 5)
+            const bool mlp_one = mlp_fused_dec && !fused_ar && (ok < 0 || ok == 8);
+            if (mlp_one)
+            {
+                // K5 + K6 in one launch (kernels/mlp_fused.hip)
+                FusedMlpParams f;
+                f.K = D;
+                f.I = Ir;
+                f.N = L.proj.N;
+                f.x = x;
+                f.x_out = x;
+                f.gamma = L.ln2;
+                f.eps = eps;
+                f.act_quant = L.ln2_scale;
+                f.w_fc = L.fc.w;
+                f.w_gate = L.gate.w;
+                f.ldw = L.fc.ldw;
+                f.scale_fc = L.fc.scale_col;
+                f.scale_gate = L.gate.scale_col;
+                f.per_channel = L.fc.per_channel;
+                f.row_fc = L.fc.act_scale;
+                f.row_gate = L.gate.act_scale ? L.gate.act_scale : L.fc.act_scale;
+                f.out_quant = L.mlp_qscale;
+                f.inter = taps ? q8 : nullptr; // (the compact row: only a tap reads it)
+                f.w_proj = L.proj.w;
+                f.ldw_proj = L.proj.ldw;
+                f.scale_proj = L.proj.scale_col;
+                f.per_channel_proj = L.proj.per_channel;
+                f.row_proj = L.proj.act_scale;
+                f.flags = mlp_flags;
+                f.error = fused_err;
+                if (fused_max_spins >= 0)
+                    f.max_spins = fused_max_spins;
+                f.x_pro_out = taps ? tap_ptr(2, li) : nullptr;
+                f.timing = mlp_timing;
+                RUN(timed(PC_GEMV_LAYER, st, [&] { return launch_mlp_fused(f, st) ? 1 : 0; }));
+                if (taps)
+                    HIP_OK(hipMemcpyAsync(tap_ptr(3, li), q8, (size_t) B * Ir, hipMemcpyDeviceToDevice, st));
+            }
+            if (!mlp_one && (ok < 0 || ok == 5))
             {
                 int rc5;
                 if (fused_ar)
@@ -1086,7 +1131,7 @@ struct tllm_session
                 RUN(rc5);
             }
             // K6
-            if (ok < 0 || ok == 6)
+            if (!mlp_one && (ok < 0 || ok == 6))
             {
                 const int pro6 = q_inter ? PRO_NONE : pro_q;
                 if (taps)
@@ -1169,6 +1214,7 @@ tllm_session_t tllm_session_create(const char* config_text)
     s->debug_taps = geti("debug_taps", 0) != 0;
     s->fuse_qkv_cfg = geti("fuse_qkv_attention", -1);
     s->fuse_o_cfg = geti("fuse_o_projection", -1);
+    s->fuse_mlp_cfg = geti("fuse_mlp", 0);
     s->fused_max_spins = geti("fused_max_spins", -1);
     s->dual_mlp_cfg = geti("dual_mlp_gemm", -1);
     s->fused_timeline = geti("fused_timeline", 0) != 0;
@@ -1628,6 +1674,30 @@ int32_t tllm_session_setup_beam(tllm_session_t s, int32_t batch_size, int32_t be
     s->qkv_attn_fused = false;
     s->o_fused = false;
     s->fused_xchg = nullptr;
+    s->mlp_fused_dec = false;
+    s->mlp_flags = nullptr;
+    s->mlp_timing = nullptr;
+    if (s->fuse_mlp_cfg > 0 && B == 1 && s->beam == 1 && s->tp == 1 && s->sq && !s->per_token && !s->layers.empty()
+        && mlp_fused_serves(D, s->Ir, D))
+    {
+        bool ok = true;
+        for (auto& L : s->layers)
+            ok = ok && L.fc.wtype == W_INT8_SQ && L.gate.wtype == W_INT8_SQ && L.proj.wtype == W_INT8_SQ && L.fc.K == D && L.gate.K == D
+                && L.fc.N == s->Ir && L.gate.N == s->Ir && L.fc.ldw == L.gate.ldw && L.fc.per_channel == L.gate.per_channel
+                && L.proj.N == D && L.proj.K == s->Ir && L.fc.scale_col && L.gate.scale_col && L.proj.scale_col && L.fc.act_scale
+                && L.proj.act_scale && L.ln2 && L.ln2_scale && L.mlp_qscale && L.fc.ldw % 16 == 0 && L.proj.ldw % 16 == 0;
+        if (ok)
+        {
+            RUN(s->dalloc(&s->mlp_flags, mlp_fused_flag_bytes()));
+            HIP_OK(hipMemset(s->mlp_flags, 0, mlp_fused_flag_bytes()));
+            s->mlp_fused_dec = true;
+            if (s->fused_timeline)
+            {
+                RUN(s->dalloc(&s->mlp_timing, (size_t) 256 * 16 * 8));
+                HIP_OK(hipMemset(s->mlp_timing, 0, (size_t) 256 * 16 * 8));
+            }
+        }
+    }
     // (SmoothQuant, or - r05 - weight-only int8: the same 4 KB weight rows against the normalised fp16 row)
     // (... or - r06 - fp16: rows of 8 KB, two tiles per row pair; BASELINE.json configs[1])
     const bool woq8_all = !s->sq && !s->layers.empty() && s->layers[0].qkv.wtype == W_INT8_WOQ;
@@ -1683,7 +1753,7 @@ constexpr int kFusedTimedOut = 2;
 
 static int check_comm(tllm_session_t s)
 {
-    if (s->qkv_attn_fused && s->fused_err)
+    if ((s->qkv_attn_fused || s->mlp_fused_dec) && s->fused_err)
     {
         // the fused projection + attention launch waits (bounded) for sibling workgroups of the same launch; an expired wait means
         // the grid was not resident at once - the rows behind it are not attention outputs
@@ -1698,13 +1768,14 @@ static int check_comm(tllm_session_t s)
             (void) hipMemset(s->fused_err, 0, 4);
             s->qkv_attn_fused = false; // later steps take the two-launch path
             s->o_fused = false;
+            s->mlp_fused_dec = false;  // ... and the two GEMV launches of the MLP
             if (s->graph)
             {
                 (void) hipGraphExecDestroy(s->graph);
                 s->graph = nullptr;
             }
-            set_error("session: the fused QKV + attention launch timed out waiting for a sibling workgroup (code %u); the results of "
-                      "this call are invalid, later steps run the projection and the attention as two launches", e);
+            set_error("session: a fused decode launch (QKV + attention: codes 1 - 8, MLP: 16) timed out waiting for a sibling workgroup "
+                      "(code %u); the results of this call are invalid, later steps run the unfused launches", e);
             return kFusedTimedOut;
         }
     }
@@ -2196,6 +2267,11 @@ void* tllm_session_fused_timeline_ptr(tllm_session_t s)
     return s ? s->fused_timing : nullptr;
 }
 
+void* tllm_session_mlp_timeline_ptr(tllm_session_t s)
+{
+    return s ? s->mlp_timing : nullptr;
+}
+
 void* tllm_session_kv_cache_ptr(tllm_session_t s, int32_t layer)
 {
     if (!s || layer < 0 || layer >= (int) s->layers.size())
@@ -2227,9 +2303,14 @@ int32_t tllm_session_time_kernel(tllm_session_t s, int32_t which, int32_t sweeps
     tllm_stream_t stream)
 {
     if (!s || !s->B || sweeps < 1 || !avg_us || !launches
-        || !(which == 1 || which == 2 || which == 4 || which == 5 || which == 6 || which == 7))
+        || !(which == 1 || which == 2 || which == 4 || which == 5 || which == 6 || which == 7 || which == 8))
     {
-        set_error("tllm_session_time_kernel: bad arguments (which in {1,2,4,5,6,7}) / setup not called");
+        set_error("tllm_session_time_kernel: bad arguments (which in {1,2,4,5,6,7,8}) / setup not called");
+        return 1;
+    }
+    if (which == 8 && !s->mlp_fused_dec)
+    {
+        set_error("tllm_session_time_kernel: kernel 8 is the one-launch MLP, which this session does not run");
         return 1;
     }
     if (which == 7 && !s->qkv_attn_fused)
@@ -2243,7 +2324,7 @@ int32_t tllm_session_time_kernel(tllm_session_t s, int32_t which, int32_t sweeps
     (void) hipEventCreate(&b);
     // (id 7 with the O-projection stage adds O(ctx) to x on every launch: the residual row is put back afterwards)
     std::vector<char> x_keep;
-    if (which == 7)
+    if (which == 7 || which == 8)
     {
         x_keep.resize((size_t) s->B * s->hidden * 2);
         HIP_OK(hipMemcpyAsync(x_keep.data(), s->x, x_keep.size(), hipMemcpyDeviceToHost, st));
@@ -2279,7 +2360,7 @@ int32_t tllm_session_decode_form(tllm_session_t s)
 {
     if (!s || !s->B)
         return -1;
-    return (s->qkv_attn_fused ? 1 : 0) | (s->qkv_attn_fused && s->o_fused ? 2 : 0);
+    return (s->qkv_attn_fused ? 1 : 0) | (s->qkv_attn_fused && s->o_fused ? 2 : 0) | (s->mlp_fused_dec ? 4 : 0);
 }
 
 int32_t tllm_session_profile(tllm_session_t s, int32_t n_steps, float* ms_per_class, int64_t* launches_per_class,

@@ -21,6 +21,37 @@ __device__ __forceinline__ unsigned long long sld(const void* p)
     return v;
 }
 
+// 16 lines (stride 64 B) in one batch through the scalar path: how long does a sweep of N distinct lines take?
+__device__ __forceinline__ unsigned sld16(const void* g)
+{
+    unsigned v[16];
+    asm volatile("s_load_dword %0, %16, 0x0 glc\n\ts_load_dword %1, %16, 0x40 glc\n\ts_load_dword %2, %16, 0x80 glc\n\t"
+                 "s_load_dword %3, %16, 0xc0 glc\n\ts_load_dword %4, %16, 0x100 glc\n\ts_load_dword %5, %16, 0x140 glc\n\t"
+                 "s_load_dword %6, %16, 0x180 glc\n\ts_load_dword %7, %16, 0x1c0 glc\n\ts_load_dword %8, %16, 0x200 glc\n\t"
+                 "s_load_dword %9, %16, 0x240 glc\n\ts_load_dword %10, %16, 0x280 glc\n\ts_load_dword %11, %16, 0x2c0 glc\n\t"
+                 "s_load_dword %12, %16, 0x300 glc\n\ts_load_dword %13, %16, 0x340 glc\n\ts_load_dword %14, %16, 0x380 glc\n\t"
+                 "s_load_dword %15, %16, 0x3c0 glc\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(v[0]), "=&s"(v[1]), "=&s"(v[2]), "=&s"(v[3]), "=&s"(v[4]), "=&s"(v[5]), "=&s"(v[6]), "=&s"(v[7]), "=&s"(v[8]),
+                 "=&s"(v[9]), "=&s"(v[10]), "=&s"(v[11]), "=&s"(v[12]), "=&s"(v[13]), "=&s"(v[14]), "=&s"(v[15])
+                 : "s"(g)
+                 : "memory");
+    unsigned r = 0;
+    for (int i = 0; i < 16; ++i)
+        r |= v[i];
+    return r;
+}
+__device__ __forceinline__ unsigned sld4x16(const void* g)
+{
+    typedef unsigned u16v __attribute__((ext_vector_type(16)));
+    u16v a, b, c, d;
+    asm volatile("s_load_dwordx16 %0, %4, 0x0 glc\n\ts_load_dwordx16 %1, %4, 0x40 glc\n\ts_load_dwordx16 %2, %4, 0x80 glc\n\t"
+                 "s_load_dwordx16 %3, %4, 0xc0 glc\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d)
+                 : "s"(g)
+                 : "memory");
+    return a[0] | b[0] | c[0] | d[0];
+}
+
 template <int NL>
 __global__ __launch_bounds__(512) void probe(const uint4* w, unsigned long long* flags, unsigned long long* out, uint32_t tag, int mode,
     int dp, int dq, int hop, uint4* sink)
@@ -62,6 +93,10 @@ __global__ __launch_bounds__(512) void probe(const uint4* w, unsigned long long*
             ++polls;
             if (mode == 0)
                 g = __hip_atomic_load((const gu64*) f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (mode == 2) // a sweep of 16 lines (the partner's line first; the others only cost time)
+                g = sld(f) | (sld16(flags + ((b * 8) & 127) * 16) & 0);
+            else if (mode == 3) // a sweep of 4 lines with 64-byte loads
+                g = sld(f) | (sld4x16(flags + ((b * 8) & 127) * 16) & 0);
             else
                 g = sld(f);
             if (polls == 1)
@@ -119,7 +154,7 @@ int main(int argc, char** argv)
     unsigned long long *flags, *out;
     hipMalloc(&w, wbytes * 8); // eight different regions: every launch streams cold bytes
     hipMalloc(&sink, 512 * 16);
-    hipMalloc(&flags, 256 * 16 * 8);
+    hipMalloc(&flags, 256 * 16 * 8 + 4096);
     hipMalloc(&out, 256 * 16 * 8);
     hipMemset(w, 1, wbytes * 8);
     hipMemset(flags, 0, 256 * 16 * 8);
@@ -127,7 +162,7 @@ int main(int argc, char** argv)
     uint32_t tag = 1;
     printf("publish at %.2f us, first poll at %.2f us after the workgroup's start, partner %d workgroups away; %d KB per CU in flight\n", dp / 100., dq / 100.,
         hop, NL * 8);
-    for (int mode : {-1, 0, 1, 0, 1})
+    for (int mode : {-1, 0, 1, 2, 3, 2, 3})
     {
         std::vector<double> v_end, v_first, v_seen, v_polls, v_lat;
         for (int rep = 0; rep < 8; ++rep, ++tag)
@@ -155,7 +190,7 @@ int main(int argc, char** argv)
                 }
             }
         }
-        printf("mode %2d (%s): stream ends %.2f us (median over workgroups)", mode, mode < 0 ? "no poll" : mode == 0 ? "vector sc1" : "scalar glc", med(v_end));
+        printf("mode %2d (%s): stream ends %.2f us (median over workgroups)", mode, mode < 0 ? "no poll" : mode == 0 ? "vector sc1" : mode == 1 ? "scalar glc" : mode == 2 ? "scalar glc + 16 more lines" : "scalar glc + 4 x 64 B", med(v_end));
         if (mode >= 0)
             printf(" | first poll returns after %.2f us | tag seen %.2f us after max(publish, first poll issue) | polls %.0f | %.2f us per poll",
                 med(v_first), med(v_seen), med(v_polls), med(v_lat));

@@ -194,14 +194,14 @@ class NativeSession:
         _check(_lib().tllm_session_profile(self._h, n_steps, ms, cnt, stream), 'profile')
         return {n: (float(ms[i]), int(cnt[i])) for i, n in enumerate(self.PROFILE_CLASSES)}
 
-    LAYER_KERNELS = {'qkv': 1, 'attention': 2, 'o_proj': 4, 'gate_up': 5, 'down': 6, 'front': 7}
+    LAYER_KERNELS = {'qkv': 1, 'attention': 2, 'o_proj': 4, 'gate_up': 5, 'down': 6, 'front': 7, 'mlp': 8}
 
     def fused_retries(self) -> int:
         """requests generate() repeated behind an expired in-launch wait of the one-launch projection + attention"""
         return int(_lib().tllm_session_fused_retries(self._h))
 
     def decode_form(self) -> int:
-        """bit 0: QKV projection + attention in one launch, bit 1: + the O-projection stage"""
+        """bit 0: QKV projection + attention in one launch, bit 1: + the O-projection stage, bit 2: the gated MLP in one launch"""
         return int(_lib().tllm_session_decode_form(self._h))
 
     def time_kernel(self, which: str, sweeps: int = 4, stream: int = 0):
