@@ -7,7 +7,7 @@ down-projection's K is then NOT a multiple of the 128-byte K-tile: 1376 = 10.75 
 O-projection's merge prologue, vocabulary shard Vr = 8000 / 4000, and the 7- / 8-way peer-to-peer exchange.  Sharding rules:
 T/examples/llama/weight.py:86-172 via the product's own split helpers; SmoothQuant scales: per-channel factors split with
 the columns of column-parallel GEMMs and shared by row-parallel ones (Q/convert.py:125-141).  Reference = the un-sharded
-session on the same quantised tensors (itself held to the oracle in test_gpu_bench_geometry.py)."""
+session on the same quantised tensors (itself held to the oracle in test_gpu_bench_geometry.py) and - tp = 4, r06 - the oracle itself."""
 import os
 import socket
 import sys
@@ -137,7 +137,7 @@ def prepare(tmp_path_factory):
     np.save(os.path.join(path, 'ids.npy'), ids)
     json.dump(dict(cfg=cfg, quant_mode=qmodel['quant_mode']), open(os.path.join(path, 'meta.json'), 'w'))
     sys.path.insert(0, os.path.join(ROOT, 'trtllm-llama_amd'))
-    _prepared.update(path=path, cfg=cfg, et=qmodel['engine_tensors'], qm=qmodel['quant_mode'], ids=ids)
+    _prepared.update(path=path, cfg=cfg, et=qmodel['engine_tensors'], qm=qmodel['quant_mode'], ids=ids, qmodel=qmodel)
     return _prepared
 
 
@@ -180,3 +180,15 @@ def test_tp_sessions_at_7b_per_rank_extents_match_the_unsharded_session(world, t
     np.testing.assert_array_equal(out[:, :S], ref_out[:, :S])
     print(f'tp={world}: arg-max of the sharded and the un-sharded logits on the same prefix agree on {agree} of {NEW * B} rows')
     assert agree >= 0.75 * NEW * B
+    if world == 4:
+        # BASELINE.json configs[4] against the ORACLE directly (not through the un-sharded HIP session): the numpy restatement of
+        # the SmoothQuant model on the un-sharded tensors, fed the tokens the sharded run generated; the bound of the
+        # kernel-vs-oracle comparison of the SmoothQuant model (tests/test_gpu_bench_geometry.py), at every step
+        from oracle import quant_oracle as QO
+        oref, _ = QO.run_model(prep['qmodel'], prep['ids'], LENS, NEW, feed_ids=out[:, S:S + NEW - 1])
+        oscale = max(max(float(np.abs(r).max()) for r in oref), 1.0)
+        for i in range(NEW):
+            d = np.abs(logits[i] - oref[i])
+            print(f'tp={world} vs oracle, step {i}: max |d| {d.max():.4g} mean |d| {d.mean():.4g} (scale {oscale:.4g})')
+            assert np.isfinite(logits[i]).all()
+            assert d.max() < 8e-2 * oscale and d.mean() < 1.2e-2 * oscale, (i, float(d.max()), float(d.mean()), oscale)
