@@ -52,10 +52,21 @@ CASES = [('sq_static_pc', 1, [(3, 3), (49, 40), (700, 700), (2300, 2300), (4000,
 
 @pytest.mark.parametrize('mode,int8_kv,shapes', CASES, ids=[f'{m}-kv{"8" if k else "16"}' for m, k, _ in CASES])
 def test_one_launch_generation_vs_oracle_across_the_envelope(mode, int8_kv, shapes):
+    run_cases(mode, int8_kv, shapes, one_launch=True)
+
+
+def test_general_launches_at_batch_1_vs_oracle():
+    """The same comparison for the launches every OTHER configuration runs (session key fuse_qkv_attention = 0: QKV GEMV, split
+    attention + merge, O-projection GEMV), at batch 1 and the 7B dimensions - the leg the one-launch path is held to bit for bit in
+    tests/test_gpu_fused_qkv_attn.py, here against the oracle itself."""
+    run_cases('sq_static_pc', 1, [(49, 40), (2300, 2300)], one_launch=False)
+
+
+def run_cases(mode, int8_kv, shapes, one_launch):
     cfg, qmodel = model(mode, int8_kv)
     sq = mode.startswith('sq')
     lw = qmodel['oracle']['layers'][0]
-    s = NativeSession(dict(cfg, quant_mode=qmodel['quant_mode'], debug_taps=1))
+    s = NativeSession(dict(cfg, quant_mode=qmodel['quant_mode'], debug_taps=1, fuse_qkv_attention=-1 if one_launch else 0))
     for k, v in qmodel['engine_tensors'].items():
         s.set_tensor(k, v)
     s.finalize()
@@ -64,9 +75,12 @@ def test_one_launch_generation_vs_oracle_across_the_envelope(mode, int8_kv, shap
         NEW = STEPS + 1
         smax = S + NEW
         s.setup(1, S, NEW)
-        assert s.decode_form() & 1, 'this geometry must take the one-launch projection + attention'
-        if mode == 'sq_static_pc' or mode == 'woq8':
-            assert s.decode_form() & 2, 'static SmoothQuant / weight-only int8: the O-projection stage must be on'
+        if one_launch:
+            assert s.decode_form() & 1, 'this geometry must take the one-launch projection + attention'
+            if mode == 'sq_static_pc' or mode == 'woq8':
+                assert s.decode_form() & 2, 'static SmoothQuant / weight-only int8: the O-projection stage must be on'
+        else:
+            assert s.decode_form() & 3 == 0
         s.fake_context(length, seed=5 + S)
         start = read_cache(s, 0, (1, 2, H, smax, DH), kv_dtype)
         if not int8_kv:
