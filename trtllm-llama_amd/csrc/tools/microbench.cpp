@@ -74,6 +74,7 @@ int main(int argc, char** argv)
         {"x sq N65536 K4096 rmsq ", 3, 2, 0, 1, 65536, D},
         {"x sq N6144  K8192 rmsq ", 3, 2, 0, 1, 6144, 8192},
         {"x sq N12288 K4096 none ", 3, 0, 0, 1, 3 * D, D},
+        {"x sq gateup none swi+q ", 3, 0, 3, 2, I, D}, // (against "sq gateup rms+q swi+q": what the RMSNorm + quantiser prologue costs)
         {"x sq N22016 K4096 rmsq ", 3, 2, 0, 1, 2 * I, D},
         {"x sq N2048  K4096 rmsq ", 3, 2, 0, 1, 2048, D},
         {"x sq N256   K4096 rmsq ", 3, 2, 0, 1, 256, D},
